@@ -1,0 +1,286 @@
+"""Host-side feeders of the hot path: the MI355X build's counterparts of the reference's
+``DataLoader`` (util.py:17-107), ``Sampler`` (util.py:110-273) and ``Evaluator`` (util.py:276-350).
+
+Same class names, constructor arguments, method names and RNG consumption order as the reference
+(``random.shuffle`` of the index list at construction / after add_exemplar / after split_data / at
+epoch wrap; ``np.random.shuffle`` in split_data), so a seeded run draws the same batches; pinned by
+tests/golden/{sampler,split,dataloader,evaluator}.npz which were produced by the reference itself.
+
+What is different is the representation: sub-sequences are packed once into an int32 matrix
+``rows[n, maxlen+1]`` (inputs right-aligned in zeros, label last) so a batch is one fancy-index
+gather that can be handed to the device as a single contiguous buffer, instead of per-row Python
+loops on every step (reference util.py:218-239).
+"""
+import json
+import math
+import os
+import random
+from collections import defaultdict
+
+import numpy as np
+
+_DATA_ROOT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+# --------------------------------------------------------------------------------------- DataLoader
+class DataLoader:
+    """Loads ``period_N`` interaction logs (reference util.py:17-107).
+
+    Sources, tried in order: ``<root>/<dataset>.npz`` (packed int32 arrays ``sess_<p>``/``item_<p>``
+    in file order, written by tools/pack_dataset.py) or ``<root>/<dataset>/period_<p>.txt``
+    ("sessId itemId" per line, util.py:46)."""
+
+    def __init__(self, dataset, root=None):
+        self.item_set = set()
+        self.is_remove_item = True
+        self.dataset = dataset
+        self.root = root or _DATA_ROOT
+        self._packed = None
+        npz = os.path.join(self.root, dataset + ".npz")
+        if os.path.isfile(npz):
+            self._packed = np.load(npz)
+
+    def num_periods(self):
+        if self._packed is not None:
+            return len([k for k in self._packed.files if k.startswith("item_")])
+        d = os.path.join(self.root, self.dataset)
+        return len([f for f in os.listdir(d) if f.endswith(".txt")])
+
+    def _read(self, period):
+        if self._packed is not None:
+            return (self._packed["sess_%d" % period].astype(np.int64),
+                    self._packed["item_%d" % period].astype(np.int64))
+        path = os.path.join(self.root, self.dataset, "period_%d.txt" % period)
+        arr = np.loadtxt(path, dtype=np.int64, ndmin=2)
+        return arr[:, 0], arr[:, 1]
+
+    @staticmethod
+    def _group(sess, item):
+        """Sessions in first-appearance order, items in file order (dict insertion order, util.py:42-52)."""
+        if len(sess) == 0:
+            return []
+        uniq, first, inv = np.unique(sess, return_index=True, return_inverse=True)
+        order_of_group = np.argsort(first, kind="stable")          # groups by first appearance
+        rank = np.empty_like(order_of_group)
+        rank[order_of_group] = np.arange(len(uniq))
+        g = rank[inv]
+        idx = np.argsort(g, kind="stable")                          # stable: keeps file order in a group
+        counts = np.bincount(g, minlength=len(uniq))
+        items_sorted = item[idx]
+        out, p = [], 0
+        for c in counts:
+            out.append(items_sorted[p:p + c].tolist())
+            p += c
+        return out
+
+    def train_loader(self, period):
+        sess, item = self._read(period)
+        self.item_set.update(np.unique(item).tolist())
+        sessions = self._group(sess, item)
+        info = 'Train set information: total number of action: %d.' % len(item)
+        print(info)
+        return sessions, info
+
+    def evaluate_loader(self, period):
+        sess, item = self._read(period)
+        total_num = len(item)
+        removed_num = 0
+        if self.is_remove_item:
+            known = np.fromiter(self.item_set, dtype=np.int64, count=len(self.item_set))
+            keep = np.isin(item, known)
+            removed_num += int((~keep).sum())
+            sess, item = sess[keep], item[keep]
+        # (items that survive are already members of item_set: util.py:84-85 adds nothing new)
+        sessions = self._group(sess, item)
+        if self.is_remove_item:
+            removed_num += sum(1 for s in sessions if len(s) == 1)
+            sessions = [s for s in sessions if len(s) != 1]
+        info = ('Test set information: original total number of action: %d, removed number of action: %d.'
+                % (total_num, removed_num))
+        return sessions, info
+
+    def max_item(self):
+        return max(self.item_set)
+
+
+# --------------------------------------------------------------------------------------- Sampler
+def pack_rows(sessions, maxlen):
+    """[n, maxlen+1] int32: up to the last `maxlen` inputs right-aligned in zeros, then the label
+    (= last item).  Rows of sessions shorter than 2 are all-zero and flagged invalid
+    (the reference skips them when batching, util.py:226-227)."""
+    n = len(sessions)
+    rows = np.zeros((n, maxlen + 1), dtype=np.int32)
+    valid = np.zeros(n, dtype=bool)
+    for i, s in enumerate(sessions):
+        L = len(s)
+        if L <= 1:
+            continue
+        valid[i] = True
+        k = min(L - 1, maxlen)
+        rows[i, maxlen - k:maxlen] = s[L - 1 - k:L - 1]
+        rows[i, maxlen] = s[L - 1]
+    return rows, valid
+
+
+class Sampler:
+    def __init__(self, data, maxlen, batch_size, is_subseq=False):
+        self.maxlen = maxlen
+        self.batch_size = batch_size
+        self.batch_counter = 0
+        self.logits = []
+        self.prepared_data = []
+        if not is_subseq:
+            # a session of length l yields itself and its prefixes down to length 2 (util.py:138-143)
+            for session in data:
+                self.prepared_data.append(session)
+                for cut in range(1, len(session) - 1):
+                    self.prepared_data.append(session[:len(session) - cut])
+        else:
+            self.prepared_data.extend(data)
+        self._repack()
+
+    # -- internal
+    def _repack(self):
+        self._rows, self._valid = pack_rows(self.prepared_data, self.maxlen)
+        self._logit_mat = None
+        self.data_indices = list(range(len(self.prepared_data)))
+        random.shuffle(self.data_indices)
+
+    def _next_indices(self):
+        lo = self.batch_counter * self.batch_size
+        idx = np.asarray(self.data_indices[lo:lo + self.batch_size], dtype=np.int64)
+        idx = idx[self._valid[idx]] if len(idx) else idx
+        self.batch_counter += 1
+        if self.batch_counter == self.batch_num():
+            self.batch_counter = 0
+            random.shuffle(self.data_indices)
+        return idx
+
+    # -- reference surface
+    def label_generator(self, session):
+        rows, _ = pack_rows([session], self.maxlen)
+        return rows[0, :self.maxlen].copy(), np.array(session[-1], dtype=np.int32)
+
+    def add_exemplar(self, exemplar):
+        """exemplar: iterable of [session, teacher_logits] (util.py:173-186)."""
+        self.logits = []
+        for session, logits in exemplar:
+            self.prepared_data.append(session)
+            self.logits.append(logits)
+        self._repack()
+
+    def split_data(self, valid_portion, return_train=False):
+        n = len(self.prepared_data)
+        sidx = np.arange(n, dtype='int32')
+        np.random.shuffle(sidx)
+        n_train = int(np.round(n * (1. - valid_portion)))
+        valid_data = [self.prepared_data[s] for s in sidx[n_train:]]
+        train_data = [self.prepared_data[s] for s in sidx[:n_train]]
+        self.prepared_data = train_data
+        self._repack()
+        return (valid_data, train_data) if return_train else valid_data
+
+    def next_batch(self):
+        """Fast path: (seq [b, maxlen] int32, pos [b] int32) as contiguous arrays."""
+        idx = self._next_indices()
+        rows = self._rows[idx]
+        return np.ascontiguousarray(rows[:, :self.maxlen]), np.ascontiguousarray(rows[:, self.maxlen])
+
+    def next_exemplar_batch(self):
+        """Fast path: (seq, pos, row indices into the exemplar list) -- teacher logits stay wherever
+        the caller keeps them (e.g. one [E, Np] device tensor) and are gathered by index."""
+        idx = self._next_indices()
+        rows = self._rows[idx]
+        return np.ascontiguousarray(rows[:, :self.maxlen]), np.ascontiguousarray(rows[:, self.maxlen]), idx
+
+    def sampler(self):
+        seq, pos = self.next_batch()
+        return tuple(seq), tuple(pos)
+
+    def exemplar_sampler(self):
+        seq, pos, idx = self.next_exemplar_batch()
+        return tuple(seq), tuple(pos), tuple(self.logits[i] for i in idx)
+
+    def data_size(self):
+        return len(self.prepared_data)
+
+    def batch_num(self):
+        return math.ceil(len(self.prepared_data) * 1.0 / self.batch_size)
+
+
+# --------------------------------------------------------------------------------------- Evaluator
+def recall_mrr(ranks):
+    """(MRR@20, RECALL@20, MRR@10, RECALL@10) from 0-based ranks (reference util.py:329-339)."""
+    r = np.asarray(ranks, dtype=np.int64)
+    n = len(r)
+    out = []
+    for k in (20, 10):
+        hit = r[r < k]
+        # sequential float64 sum in list order, as Python's sum() over the filtered list does
+        mrr = 0.0
+        for x in hit.tolist():
+            mrr += 1.0 / (x + 1)
+        out.extend([mrr / n, len(hit) / n])
+    return tuple(out)
+
+
+class Evaluator:
+    """Evaluates the rank of the ground-truth next item among all `max_item` items
+    (reference util.py:276-350).  `model.predict(sess, seq, item_idx)` must return the full rank
+    matrix as in the reference; when the model offers `rank_targets(seq, pos, max_item)` (the HIP
+    count-greater kernel) that is used instead -- only pred[label-1] is ever read (util.py:325)."""
+
+    def __init__(self, data, is_subseq, maxlen, batch_size, max_item, mode, model, sess):
+        self.max_item = max_item
+        self.model = model
+        self.sess = sess
+        self.ranks = []
+        self.mode = mode
+        self.desc = 'Validating epoch ' if mode == 'valid' else 'Testing epoch '
+        self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq)
+
+    def evaluate(self, epoch):
+        self.ranks = []
+        fast = getattr(self.model, "rank_targets", None)
+        for _ in range(self.evaluate_sampler.batch_num()):
+            seq, pos = self.evaluate_sampler.next_batch()
+            if len(pos) == 0:
+                continue
+            if fast is not None:
+                self.ranks.extend(int(x) for x in fast(seq, pos, self.max_item))
+            else:
+                pred = self.model.predict(self.sess, seq, list(range(1, self.max_item + 1)))
+                self.ranks.extend(int(p[i - 1]) for p, i in zip(pred, pos))
+        return self.display(epoch)
+
+    def results(self):
+        return recall_mrr(self.ranks)
+
+    def display(self, epoch):
+        r = self.results()
+        info = 'epoch:%d, %s (MRR@20: %.4f, RECALL@20: %.4f, MRR@10: %.4f, RECALL@10: %.4f)' \
+               % (epoch, self.mode, r[0], r[1], r[2], r[3])
+        print(info)
+        return info
+
+
+def load_exemplars(exemplar_pre):
+    """Flatten {item: [[session, logits], ...]} to a list (reference main.py:54-65)."""
+    out = []
+    for item in exemplar_pre.values():
+        if isinstance(item, list):
+            out.extend(i for i in item if i)
+    return out
+
+
+def group_by_label(data, batch_size, maxlen):
+    """Bucket candidate sub-sequences by label in the reference's visiting order
+    (ExemplarGenerator.__init__, util.py:382-393): batches drawn from a shuffled is_subseq Sampler.
+    Returns (order of labels, {label: [n_label, maxlen+1] int32 rows}, item frequency dict)."""
+    smp = Sampler(data, maxlen, batch_size, is_subseq=True)
+    buckets = defaultdict(list)
+    for _ in range(smp.batch_num()):
+        idx = smp._next_indices()
+        for i in idx.tolist():
+            buckets[int(smp._rows[i, maxlen])].append(i)
+    return {k: smp._rows[np.asarray(v, dtype=np.int64)] for k, v in buckets.items()}

@@ -1,0 +1,97 @@
+"""Exemplar selection: the MI355X build's counterpart of the reference's ``ExemplarGenerator``
+(util.py:353-461: ``__init__`` grouping + multinomial quotas, ``herding``, ``herding_selection``).
+
+The reference issues one ``sess.run`` per distinct label (~17k per DIGINETICA period, util.py:447-455)
+and runs the greedy herding loop in numpy on the host.  Here all candidates go through ONE batched
+eval-mode encode on the GPU, the herding loop runs as one segmented HIP kernel launch over all label
+groups (csrc/herding.hip), and the teacher logits of the selected rows stay on the device as one
+[E, N] tensor instead of Python float lists (util.py:433).
+"""
+from collections import defaultdict
+
+import numpy as np
+
+from . import data as _data
+
+
+def draw_quotas(groups, exemplar_size, disable_m, max_item):
+    """Per-item exemplar quotas (util.py:393-399): multinomial(m, freq/sum(freq)) on numpy's legacy
+    global RNG; `disable_m` (--equal_exemplar) uses uniform probabilities over all max_item items."""
+    item_count = np.zeros(max_item)
+    for label, rows in groups.items():
+        item_count[label - 1] += len(rows)
+    if disable_m:
+        item_count = np.ones_like(item_count)
+    item_prob = item_count / item_count.sum()
+    return np.int32(np.random.multinomial(n=exemplar_size, pvals=item_prob, size=1)[0])
+
+
+def herding_max_steps(m):
+    """Loop bound of `while ... and step_t < 1.1 * m` (util.py:425), evaluated in float64 as Python does."""
+    lim = 1.1 * float(m)
+    k = int(lim)
+    while k < lim:
+        k += 1
+    return k
+
+
+class ExemplarStore:
+    """Selected exemplars of one period: sessions as [E, maxlen+1] int32 rows (inputs ‖ label) and
+    their teacher logits [E, N] (float32, device tensor when produced by the GPU path)."""
+
+    def __init__(self, rows, logits, max_item):
+        self.rows = rows
+        self.logits = logits
+        self.max_item = max_item
+
+    def __len__(self):
+        return int(self.rows.shape[0])
+
+    def sessions(self):
+        """Sessions in the reference's stored form: non-zero inputs followed by the label (util.py:433)."""
+        return [r[r != 0].tolist() for r in np.asarray(self.rows)]
+
+
+class ExemplarGenerator:
+    """Same constructor arguments as the reference (util.py:366-374)."""
+
+    def __init__(self, data, exemplar_size, disable_m, batch_size, maxlen, dropout_rate, max_item):
+        self.exemplars = defaultdict(list)
+        self.m = exemplar_size
+        self.max_item = max_item
+        self.maxlen = maxlen
+        self.dropout_rate = dropout_rate
+        self.sess_by_item = _data.group_by_label(data, batch_size, maxlen)
+        self.item_count = draw_quotas(self.sess_by_item, exemplar_size, disable_m, max_item)
+        self.store = None
+
+    def _segments(self):
+        labels = list(self.sess_by_item.keys())
+        sizes = np.array([len(self.sess_by_item[k]) for k in labels], dtype=np.int64)
+        offs = np.zeros(len(labels) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(sizes)
+        quota = np.array([min(int(self.item_count[k - 1]), int(n)) for k, n in zip(labels, sizes)], dtype=np.int32)
+        rows = np.concatenate([self.sess_by_item[k] for k in labels]) if labels else np.zeros((0, self.maxlen + 1), np.int32)
+        return labels, offs, quota, rows
+
+    def herding_selection(self, sess, model):
+        """Select exemplars by herding (util.py:436-461).  `model` is an ader_amd.model.Ader; `sess` is
+        accepted for call-surface compatibility.  Returns the number of exemplars saved."""
+        labels, offs, quota, rows = self._segments()
+        sel_idx, sel_cnt = model.engine.herding_select(rows[:, :self.maxlen], offs, quota, self.max_item)
+        keep = []
+        for g, label in enumerate(labels):
+            c = int(sel_cnt[g])
+            ids = sel_idx[offs[g]:offs[g] + c] + offs[g]
+            keep.append(ids)
+        keep = np.concatenate(keep) if keep else np.zeros(0, np.int64)
+        sel_rows = rows[keep]
+        logits = model.engine.teacher_logits(sel_rows[:, :self.maxlen], self.max_item)
+        self.store = ExemplarStore(sel_rows, logits, self.max_item)
+        # reference-shaped view: {item: [[session, logits_row], ...]} -- logits rows are views of the store
+        p = 0
+        for g, label in enumerate(labels):
+            c = int(sel_cnt[g])
+            self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
+            p += c
+        return int(len(keep))

@@ -1,0 +1,139 @@
+"""Host feeders (ader_amd.data) against golden vectors produced by the reference's own util.py
+(tests/golden/make_golden.py).  Bit-exact: integer/index work."""
+import json
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from ader_amd import data as D
+
+
+def unragged(flat, off):
+    return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+
+
+def test_sampler_prefix_label_batches(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sampler.npz"))
+    sess = unragged(g["in_flat"], g["in_off"])
+    random.seed(0)
+    np.random.seed(0)
+    sm = D.Sampler(sess, 50, 16, is_subseq=False)
+    assert sm.prepared_data == unragged(g["prepared_flat"], g["prepared_off"])
+    assert sm.data_indices == g["indices0"].tolist()
+    assert sm.batch_num() == int(g["batch_num"])
+    seqs, poss = [], []
+    for s in sm.prepared_data:
+        if len(s) >= 2:
+            a, b = sm.label_generator(s)
+            seqs.append(a)
+            poss.append(int(b))
+    assert np.array_equal(np.stack(seqs), g["lg_seq"])
+    assert np.array_equal(np.array(poss), g["lg_pos"])
+    nb = sm.batch_num()
+    bseq, bpos, bsz = [], [], []
+    for _ in range(2 * nb + nb // 2):
+        seq, pos = sm.sampler()
+        bsz.append(len(seq))
+        bseq.extend(seq)
+        bpos.extend(pos)
+    assert bsz == g["batches_size"].tolist()
+    assert np.array_equal(np.stack(bseq), g["batches_seq"])
+    assert np.array_equal(np.array(bpos), g["batches_pos"])
+
+
+def test_sampler_subseq_and_exemplar_paths(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sampler.npz"))
+    sess = unragged(g["in_flat"], g["in_off"])
+    random.seed(3)
+    sm2 = D.Sampler(sess, 50, 7, is_subseq=True)
+    assert sm2.data_indices == g["sub_indices0"].tolist()
+    assert len(sm2.prepared_data) == int(g["sub_prepared_n"])
+    random.seed(5)
+    ex_s = unragged(g["ex_in_flat"], g["ex_in_off"])
+    ex = [[s, l.tolist()] for s, l in zip(ex_s, g["ex_in_logits"])]
+    sm3 = D.Sampler([], 50, 2)
+    sm3.add_exemplar(ex)
+    eseq, epos, elog, esz = [], [], [], []
+    for _ in range(2 * sm3.batch_num() + 1):
+        s, p, l = sm3.exemplar_sampler()
+        esz.append(len(s))
+        eseq.extend(s)
+        epos.extend(p)
+        elog.extend(l)
+    assert esz == g["ex_sizes"].tolist()
+    assert np.array_equal(np.stack(eseq), g["ex_seq"])
+    assert np.array_equal(np.array(epos), g["ex_pos"])
+    assert np.array_equal(np.array(elog, dtype=np.float64), g["ex_logits"])
+
+
+def test_split_data(golden_dir):
+    g = np.load(os.path.join(golden_dir, "split.npz"))
+    s = np.load(os.path.join(golden_dir, "sampler.npz"))
+    sess = unragged(s["in_flat"], s["in_off"])
+    random.seed(0)
+    np.random.seed(0)
+    sm = D.Sampler(sess, 50, 16)
+    valid, train = sm.split_data(0.1, return_train=True)
+    assert valid == unragged(g["valid_flat"], g["valid_off"])
+    assert train == unragged(g["train_flat"], g["train_off"])
+    assert sm.data_indices == g["indices_after"].tolist()
+    assert sm.batch_num() == int(g["batch_num"])
+    seq, pos = sm.sampler()
+    assert np.array_equal(np.stack(seq), g["first_batch_seq"])
+    assert np.array_equal(np.array(pos), g["first_batch_pos"])
+
+
+def test_evaluator_results(golden_dir):
+    g = np.load(os.path.join(golden_dir, "evaluator.npz"))
+    for k in ("edges", "all_hit", "none", "mixed"):
+        got = D.recall_mrr(g[k + "_ranks"].tolist())
+        assert np.array_equal(np.array(got, dtype=np.float64), g[k + "_results"]), k
+    ev = D.Evaluator.__new__(D.Evaluator)
+    ev.ranks = g["edges_ranks"].tolist()
+    ev.mode = "valid"
+    assert ev.display(3) == str(g["edges_display"])
+
+
+def test_group_by_label_and_quota(golden_dir):
+    from ader_amd.exemplar import draw_quotas
+    g = np.load(os.path.join(golden_dir, "exemplar_init.npz"))
+    data = unragged(g["data_flat"], g["data_off"])
+    for tag, disable_m in (("prop", False), ("equal", True)):
+        random.seed(0)
+        np.random.seed(0)
+        groups = D.group_by_label(data, 32, 50)
+        assert list(groups.keys()) == g[tag + "_group_order"].tolist()
+        assert [len(v) for v in groups.values()] == g[tag + "_group_sizes"].tolist()
+        assert np.array_equal(np.concatenate(list(groups.values())), g[tag + "_rows"])
+        quota = draw_quotas(groups, 100, disable_m, 40)
+        assert np.array_equal(quota, g[tag + "_quota"])
+
+
+def _crc(list_of_lists):
+    flat = np.array([x for s in list_of_lists for x in s], dtype=np.int64)
+    off = np.zeros(len(list_of_lists) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in list_of_lists])
+    return int(zlib.crc32(flat.tobytes()) ^ zlib.crc32(off.tobytes()))
+
+
+@pytest.mark.parametrize("dataset", ["DIGINETICA", "YOOCHOOSE"])
+def test_dataloader_periods(golden_dir, dataset):
+    root = os.path.join(os.path.dirname(os.path.dirname(golden_dir)), "data")
+    if not os.path.isfile(os.path.join(root, dataset + ".npz")):
+        pytest.skip("packed dataset not present")
+    ref = json.load(open(os.path.join(golden_dir, "dataloader.json")))[dataset]
+    dl = D.DataLoader(dataset, root=root)
+    assert dl.num_periods() == len(ref) + 1
+    for row in ref:
+        tr, _ = dl.train_loader(row["period"] - 1)
+        te, info = dl.evaluate_loader(row["period"])
+        assert len(tr) == row["train_sessions"]
+        assert sum(len(s) for s in tr) == row["train_actions"]
+        assert _crc(tr) == row["train_crc"]
+        assert len(te) == row["test_sessions"]
+        assert _crc(te) == row["test_crc"]
+        assert info == row["test_info"]
+        assert dl.max_item() == row["max_item"]

@@ -1,0 +1,136 @@
+"""Self-checks of the model oracle (oracle/ader_ref_cpu.py).  The reference ships no tests or golden
+vectors for the TF graph and TensorFlow cannot run here, so these are the hand-derived cases of
+SURVEY section 4 plus fp64 finite differences -- they pin the restatement's internal consistency, not
+TF output ("parity unpinned" for the model math)."""
+import numpy as np
+import torch
+
+from oracle import ader_ref_cpu as R
+
+T, H, L = 6, 8, 2
+
+
+def small(dtype=torch.float64, seed=0, item_num=20):
+    p = R.init_params(item_num, T, H, L, seed=seed, dtype=dtype)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in p:                                # non-trivial LN params / biases
+        if k.endswith(("_b", "bq", "bk", "bv", "b1", "b2")):
+            p[k] = (torch.randn(p[k].shape, generator=g, dtype=torch.float64) * 0.1).to(dtype)
+        if k.endswith("_g"):
+            p[k] = (1 + torch.randn(p[k].shape, generator=g, dtype=torch.float64) * 0.1).to(dtype)
+    return p
+
+
+def test_layernorm_of_zero_row_is_beta():
+    g = torch.rand(H, dtype=torch.float64)
+    b = torch.rand(H, dtype=torch.float64)
+    out = R.layernorm(torch.zeros(3, H, dtype=torch.float64), g, b)
+    assert torch.equal(out, b.expand(3, H))
+
+
+def test_row0_embedding_is_zero_and_pads_do_not_leak():
+    p = small()
+    p["emb"][0] = 123.0                         # must be ignored (modules.py:124-126)
+    seq_a = torch.tensor([[0, 0, 0, 3, 4, 5]])
+    rep_a = R.forward_rep(p, seq_a, L, 1)
+    p["emb"][0] = -7.0
+    rep_b = R.forward_rep(p, seq_a, L, 1)
+    assert torch.equal(rep_a, rep_b)
+
+
+def test_fully_masked_softmax_row_is_uniform():
+    p = small()
+    seq = torch.tensor([[0, 0, 0, 0, 2, 9]])
+    _, inter = R.forward_rep(p, seq, 1, 1, return_intermediates=True)
+    # pad query rows attend uniformly over all T keys (every score equals the padding constant);
+    # their block output is re-zeroed by the mask (ADER.py:80)
+    assert torch.all(inter["blk0"][0, :4] == 0)
+    assert torch.all(inter["blk0"][0, 4:].abs().sum(-1) > 0)
+
+
+def test_causality_last_position_only_sees_the_past():
+    p = small()
+    a = torch.tensor([[1, 2, 3, 4, 5, 6]])
+    b = torch.tensor([[1, 2, 3, 4, 5, 7]])
+    _, ia = R.forward_rep(p, a, L, 1, return_intermediates=True)
+    _, ib = R.forward_rep(p, b, L, 1, return_intermediates=True)
+    assert torch.equal(ia["final"][0, :5], ib["final"][0, :5])
+    assert not torch.equal(ia["final"][0, 5], ib["final"][0, 5])
+
+
+def test_loss_matches_manual_onehot_ce_and_kd():
+    p = small()
+    seq = torch.tensor([[0, 0, 1, 2, 3, 4], [0, 5, 6, 7, 8, 9], [0, 0, 0, 0, 10, 11]])
+    pos = torch.tensor([5, 10])
+    tl = torch.randn(1, 12, dtype=torch.float64)
+    lam = 0.37
+    loss = R.loss_fn(p, seq, pos, 15, L, 1, ex_logits=tl, lambda_=lam, training=False)
+    rep = R.forward_rep(p, seq, L, 1)
+    lg = R.logits_from_rep(p, rep, 15)
+    ce = torch.stack([-torch.log_softmax(lg[i], -1)[pos[i] - 1] for i in range(2)]).mean()
+    kd = -(torch.softmax(tl[0], -1) * torch.log_softmax(lg[2, :12], -1)).sum()
+    assert torch.allclose(loss, ce + lam * kd, rtol=1e-12, atol=1e-12)
+
+
+def test_heads_split_on_channels():
+    p = small()
+    seq = torch.tensor([[0, 1, 2, 3, 4, 5]])
+    r1 = R.forward_rep(p, seq, L, 1)
+    r2 = R.forward_rep(p, seq, L, 2)
+    assert not torch.allclose(r1, r2)
+
+
+def test_gradients_by_finite_differences_fp64():
+    p = small()
+    seq = torch.tensor([[0, 0, 1, 2, 3, 4], [6, 5, 6, 7, 8, 9], [0, 0, 0, 0, 10, 11]])
+    pos = torch.tensor([5, 10])
+    tl = torch.randn(1, 12, dtype=torch.float64)
+    kw = dict(ex_logits=tl, lambda_=0.5, training=True, rate=0.25, seed=3, step=7)
+    loss, grads = R.loss_and_grads(p, seq, pos, 15, L, 1, **kw)
+    rs = np.random.RandomState(0)
+    for name in ("emb", "pos", "b0.wq", "b0.wk", "b1.wv", "b1.w1", "b0.w2", "b0.ln1_g", "b1.ln2_b", "lnf_g", "b0.bq", "b1.b2"):
+        flat = p[name].view(-1)
+        for _ in range(3):
+            i = int(rs.randint(0, flat.numel()))
+            if name == "emb" and i < H:          # row 0 never receives gradient
+                continue
+            old = flat[i].item()
+            eps = 1e-6
+            flat[i] = old + eps
+            lp = R.loss_fn(p, seq, pos, 15, L, 1, **kw).item()
+            flat[i] = old - eps
+            lm = R.loss_fn(p, seq, pos, 15, L, 1, **kw).item()
+            flat[i] = old
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - grads[name].view(-1)[i].item()) < 1e-6 * max(1.0, abs(fd)), (name, i)
+    assert torch.all(grads["emb"][0] == 0)
+
+
+def test_dropout_mask_spec_statistics_and_determinism():
+    k1 = R.dropout_keep(200000, 0, 0, 5, 1, 0.3)
+    k2 = R.dropout_keep(200000, 0, 0, 5, 1, 0.3)
+    k3 = R.dropout_keep(200000, 0, 0, 6, 1, 0.3)
+    assert np.array_equal(k1, k2) and not np.array_equal(k1, k3)
+    assert abs(k1.mean() - 0.7) < 0.005
+    # a shard starting at element 1000 sees the same mask as the slice of the full tensor
+    assert np.array_equal(R.dropout_keep(500, 1000, 0, 5, 1, 0.3), k1[1000:1500])
+
+
+def test_tf_adam_first_step_moves_by_lr():
+    p = {"w": torch.tensor([1.0, -2.0], dtype=torch.float32)}
+    opt = R.TFAdam(p)
+    opt.step(p, {"w": torch.tensor([0.5, -3.0])}, 1e-3)
+    # t=1: m = .1 g, v = .001 g^2, lr_t = lr*sqrt(.001)/.1  ->  step = lr * g/|g| (up to eps)
+    assert torch.allclose(p["w"], torch.tensor([1.0 - 1e-3, -2.0 + 1e-3]), atol=1e-7)
+
+
+def test_rank_matches_double_argsort():
+    p = small(dtype=torch.float32)
+    seq = torch.tensor([[0, 0, 1, 2, 3, 4], [6, 5, 6, 7, 8, 9]])
+    ranks = R.rank_all(p, seq, 20, L, 1).numpy()
+    rep = R.forward_rep(p, seq, L, 1)
+    lg = R.logits_from_rep(p, rep, 20).detach().numpy()
+    for b in range(2):
+        for t in (1, 7, 20):
+            assert R.rank_of_target(lg[b], t) == ranks[b, t - 1]
+    assert R.metrics([0, 9, 10, 19, 20]) == (sum(1 / (r + 1) for r in (0, 9, 10, 19)) / 5, 4 / 5, (1 + 0.1) / 5, 2 / 5)
