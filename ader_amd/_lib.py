@@ -1,0 +1,82 @@
+"""ctypes binding of libader_hip.so (the C ABI declared in include/ader_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a launcher reports an error this
+module raises.  (PyTorch is used only for device memory, streams and torch.distributed.)"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_size_t, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libader_hip.so")
+
+P, I, U, F, L, Z = c_void_p, c_int, c_uint, c_float, c_long, c_size_t
+_DROP = [U, U, F, U]
+
+_SIGS = {
+    "ader_embed_fwd": [P, P, P, P, I, I, I, I] + _DROP + [P, P],
+    "ader_embed_bwd": [P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_ln_fwd": [P, L, P, L, P, P, P, P, P, P, I, I, P],
+    "ader_ln_bwd_slabs": [I],
+    "ader_ln_bwd": [P, L, P, L, P, P, P, P, L, P, L, P, P, P, I, I, P],
+    "ader_gemm_rows": [P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_gemm_atb_slabs": [I],
+    "ader_gemm_atb": [P, P, P, P, P, I, I, P],
+    "ader_mask_dropgrad": [P, P, P, P, I, I] + _DROP + [P],
+    "ader_attn_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_attn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_logits_sub": [I],
+    "ader_logits_parts": [I],
+    "ader_logits_ranges": [I, I],
+    "ader_row_lse": [P, L, I, P, I, P, P],
+    "ader_build_rowinfo": [P, I, P, P, I, I, I, F, F, I, P, P, P, P, P],
+    "ader_logits_loss_fwd": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P, P],
+    "ader_logits_loss_bwd": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P, P],
+    "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
+    "ader_rank_targets": [P, P, I, I, I, I, P, P, P, P, P],
+    "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P],
+    "ader_fill": [P, Z, F, P],
+    "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
+    "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
+}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges"}
+
+
+class AderHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load the HIP library (import torch first so both share one HIP runtime instance)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise AderHipError("libader_hip.so not built: run `python -m ader_amd.build` (no CPU fallback exists)")
+    import torch  # noqa: F401  (loads libamdhip64 that libader_hip.so resolves against)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argt in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argt
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a launcher; raises on a non-zero return code."""
+    rc = getattr(load(), name)(*args)
+    if name not in _NO_CHECK and rc != 0:
+        raise AderHipError("%s failed with code %d" % (name, rc))
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,357 @@
+// Row-wise / element-wise kernels of the ADER hot path (HBM- or Infinity-Cache-bound):
+// embedding gather + prologue, LayerNorm fwd/bwd, dropout-gradient masks, slab reductions, Adam.
+// Reference semantics cited per kernel; gfx950 only.
+#include "common.h"
+#include "../../include/ader_hip.h"
+
+#define MAXPL 4   // max elements per lane in row kernels: H <= 256
+
+// ---------------------------------------------------------------------------------------------
+// x0 = dropout(E0[seq]*sqrt(H) + P[t]) * (seq != 0)
+//   reference: modules.py:118-130 (row 0 of the table reads as zeros, items scaled by sqrt(H)),
+//   ADER.py:41-60 (positional table, dropout, mask).  One wave per (b,t) row; the table row is read
+//   in place (no zero-pad concat copy of the whole table as the TF graph does).
+__global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ seq, const float* __restrict__ emb,
+                                                   const float* __restrict__ pos, float* __restrict__ x,
+                                                   int rows, int T, int H, int V, float sqrtH, DropArgs d,
+                                                   int* __restrict__ status) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    int id = seq[row];
+    if (id < 0 || id >= V) {
+        if (lane == 0) atomicOr(status, ADER_ST_BAD_ID);
+        id = 0;
+    }
+    const int t = row % T;
+    const float* e = emb + (size_t)id * H;
+    const float* p = pos + (size_t)t * H;
+    float* o = x + (size_t)row * H;
+    for (int c = lane; c < H; c += 64) {
+        float v = (id != 0 ? e[c] * sqrtH : 0.0f) + p[c];
+        v = drop_apply(d, (uint32_t)row * (uint32_t)H + (uint32_t)c, v);
+        o[c] = (id != 0) ? v : 0.0f;
+    }
+}
+
+// Backward of the prologue.  g = dx0 * mask * keep * scale is written back in place (it is the
+// gradient w.r.t. the positional rows before the batch sum); sqrt(H)*g is scatter-added into dE[id].
+// dE rows hit by several (b,t) use float atomics (order-dependent last bits; deterministic variant:
+// ader_embed_bwd_sorted).
+__global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ seq, float* __restrict__ dx,
+                                                   float* __restrict__ demb, int rows, int H, int V, float sqrtH,
+                                                   DropArgs d) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    int id = seq[row];
+    if (id < 0 || id >= V) id = 0;
+    float* g = dx + (size_t)row * H;
+    float* de = demb + (size_t)id * H;
+    for (int c = lane; c < H; c += 64) {
+        float v = 0.0f;
+        if (id != 0) {
+            v = g[c];
+            if (d.thr != 0) v = drop_keep(d, (uint32_t)row * (uint32_t)H + (uint32_t)c) ? v * d.scale : 0.0f;
+            atomicAdd(de + c, v * sqrtH);
+        }
+        g[c] = v;
+    }
+}
+
+// Deterministic scatter: rows pre-sorted by id (order[] = argsort(seq) stable, computed by the caller);
+// one wave per distinct id run sums its rows in order and adds once (no atomics: each id is owned by one wave).
+__global__ __launch_bounds__(256) void k_embed_bwd_sorted(const int* __restrict__ seq, const int* __restrict__ order,
+                                                          const int* __restrict__ run_start, int n_runs,
+                                                          const float* __restrict__ g, float* __restrict__ demb,
+                                                          int rows, int H, float sqrtH) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int run = blockIdx.x * 4 + wave;
+    if (run >= n_runs) return;
+    const int s = run_start[run], e = (run + 1 < n_runs) ? run_start[run + 1] : rows;
+    const int id = seq[order[s]];
+    if (id == 0) return;
+    for (int c = lane; c < H; c += 64) {
+        float acc = 0.0f;
+        for (int i = s; i < e; ++i) acc += g[(size_t)order[i] * H + c];
+        demb[(size_t)id * H + c] += acc * sqrtH;
+    }
+}
+
+// dpos[t][c] = sum_b g[b*T + t][c]   (sequential over b: deterministic)
+__global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ g, float* __restrict__ dpos, int B, int T, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * H) return;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc += g[(size_t)b * T * H + i];
+    dpos[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward, reference modules.py:44-48: biased variance, eps inside the sqrt,
+//   y = gamma * ((x-mean)/sqrt(var+eps)) + beta.   One wave per row.
+// Optional outputs: xnz = sign(|sum_c x|), ynz = sign(|sum_c y|) -- the key / query masks of
+// multihead_attention (modules.py:188, 208) when called on the attention block input.
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, long x_rs, float* __restrict__ y, long y_rs,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float* __restrict__ mean_o, float* __restrict__ std_o,
+                                                float* __restrict__ xnz, float* __restrict__ ynz, int rows, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * x_rs;
+    float v[MAXPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < H) ? xr[c] : 0.0f;
+        s += v[i];
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)H;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+        const int c = lane + 64 * i;
+        const float dlt = (c < H) ? (v[i] - mean) : 0.0f;
+        q += dlt * dlt;
+    }
+    q = wave_sum(q);
+    const float sd = sqrtf(q / (float)H + LN_EPS);
+    float* yr = y + (size_t)row * y_rs;
+    float ys = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < H) {
+            const float o = gamma[c] * ((v[i] - mean) / sd) + beta[c];
+            yr[c] = o;
+            ys += o;
+        }
+    }
+    if (ynz) ys = wave_sum(ys);
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (std_o) std_o[row] = sd;
+        if (xnz) xnz[row] = (s != 0.0f) ? 1.0f : 0.0f;
+        if (ynz) ynz[row] = (ys != 0.0f) ? 1.0f : 0.0f;
+    }
+}
+
+// LayerNorm backward.  dx = (1/sd) * (dxh - mean(dxh) - xh*mean(dxh*xh)), dxh = dy*gamma; dx (+)= add.
+// Per-WG partial sums of dgamma = sum dy*xh and dbeta = sum dy go to slab[WG][2][H] (deterministic
+// reduction by k_reduce_slabs).  Grid-stride over rows.
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, long dy_rs, const float* __restrict__ x, long x_rs,
+                                                const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                const float* __restrict__ std_i, const float* __restrict__ add, long add_rs,
+                                                float* __restrict__ dx, long dx_rs, float* __restrict__ slab, int rows, int H) {
+    __shared__ float red[4][2][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float dg[MAXPL], db[MAXPL], gm[MAXPL];
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+        dg[i] = 0.0f; db[i] = 0.0f;
+        const int c = lane + 64 * i;
+        gm[i] = (c < H) ? gamma[c] : 0.0f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* dyr = dy + (size_t)row * dy_rs;
+        const float* xr = x + (size_t)row * x_rs;
+        const float mean = mean_i[row], sd = std_i[row];
+        float xh[MAXPL], dxh[MAXPL];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXPL; ++i) {
+            const int c = lane + 64 * i;
+            float g = 0.0f;
+            xh[i] = 0.0f;
+            if (c < H) { g = dyr[c]; xh[i] = (xr[c] - mean) / sd; }
+            dxh[i] = g * gm[i];
+            s1 += dxh[i];
+            s2 += dxh[i] * xh[i];
+            dg[i] += g * xh[i];
+            db[i] += g;
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        float* dxr = dx + (size_t)row * dx_rs;
+#pragma unroll
+        for (int i = 0; i < MAXPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H) {
+                float o = (dxh[i] - s1 - xh[i] * s2) / sd;
+                if (add) o += add[(size_t)row * add_rs + c];
+                dxr[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) { red[wave][0][lane + 64 * i] = dg[i]; red[wave][1][lane + 64 * i] = db[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float a = ((red[0][0][c] + red[1][0][c]) + red[2][0][c]) + red[3][0][c];
+        const float b = ((red[0][1][c] + red[1][1][c]) + red[2][1][c]) + red[3][1][c];
+        slab[((size_t)blockIdx.x * 2 + 0) * H + c] = a;
+        slab[((size_t)blockIdx.x * 2 + 1) * H + c] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward entry of the FFN tail  x2 = (dropout(h2) + y) * mask   (modules.py:262-266, ADER.py:80):
+//   g = dx2 * mask (gradient of the residual y);  dh2 = g * keep * scale.
+__global__ __launch_bounds__(256) void k_mask_dropgrad(const float* __restrict__ dx2, const int* __restrict__ seq,
+                                                       float* __restrict__ g, float* __restrict__ dh2, int rows, int H, DropArgs d) {
+    const size_t n = (size_t)rows * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / H);
+        float v = (seq[row] != 0) ? dx2[i] : 0.0f;
+        g[i] = v;
+        if (d.thr != 0) v = drop_keep(d, (uint32_t)i) ? v * d.scale : 0.0f;
+        dh2[i] = v;
+    }
+}
+
+// dst[r][c] = sum_s src[s*slab_stride + r*ld + c]  (s ascending: deterministic).  Rows r < n_rows go to
+// dst, row n_rows (if dst_extra) goes to dst_extra -- the "ones row" of the weight-gradient GEMM = bias grad.
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ src, long slab_stride, int S, int ld,
+                                                      int n_rows, int n_cols, float* __restrict__ dst,
+                                                      float* __restrict__ dst_extra) {
+    const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = i / n_cols, c = i % n_cols;
+    const float* p = src + (size_t)r * ld + c;
+    float acc = 0.0f;
+    for (int s = 0; s < S; ++s) acc += p[(size_t)s * slab_stride];
+    if (r < n_rows) dst[(size_t)r * n_cols + c] = acc;
+    else dst_extra[c] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense Adam over one flat parameter buffer, TF ApplyAdam semantics (ADER.py:96):
+//   m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= (m*lr_t)/(sqrt(v)+eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host).
+// HBM-bound: 4 streams in, 3 out, 16 B per lane per access.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                              const float* __restrict__ g, size_t n, float lr_t, float omb1, float omb2, float eps) {
+    const size_t n4 = n >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float4* p4 = (float4*)p; float4* m4 = (float4*)m; float4* v4 = (float4*)v; const float4* g4 = (const float4*)g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+#define ADAM1(f) mm.f += (gg.f - mm.f) * omb1; vv.f += (gg.f * gg.f - vv.f) * omb2; pp.f -= (mm.f * lr_t) / (sqrtf(vv.f) + eps);
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float mm = m[i], vv = v[i];
+        const float gg = g[i];
+        mm += (gg - mm) * omb1; vv += (gg * gg - vv) * omb2;
+        p[i] -= (mm * lr_t) / (sqrtf(vv) + eps);
+        m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, float val) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = val;
+}
+
+// ============================================================================================= C ABI
+static inline DropArgs mk_drop(unsigned key, unsigned thr, float scale, unsigned base) {
+    DropArgs d; d.key = key; d.thr = thr; d.scale = scale; d.base = base; return d;
+}
+static inline int cap_grid(size_t n, int per_block, int cap) {
+    size_t g = (n + per_block - 1) / per_block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" {
+
+int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x, int rows, int T, int H, int V,
+                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, int* status, void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_embed_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, H, V,
+                       sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base), status);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
+                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+    const int rows = B * T;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
+                       sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+    hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_ln_fwd(const float* x, long x_rs, float* y, long y_rs, const float* gamma, const float* beta, float* mean_o,
+                float* std_o, float* xnz, float* ynz, int rows, int H, void* stream) {
+    if (rows <= 0) return 0;
+    if (H > 64 * MAXPL) return -2;
+    hipLaunchKernelGGL(k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_rs, y, y_rs, gamma, beta, mean_o,
+                       std_o, xnz, ynz, rows, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// slab must hold ader_ln_bwd_slabs(rows) * 2 * H floats; dgamma/dbeta receive the reduced sums.
+int ader_ln_bwd_slabs(int rows) { return cap_grid((size_t)rows, 16, 256); }
+
+int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const float* gamma, const float* mean_i,
+                const float* std_i, const float* add, long add_rs, float* dx, long dx_rs, float* slab, float* dgamma,
+                float* dbeta, int rows, int H, void* stream) {
+    if (rows <= 0) return 0;
+    if (H > 64 * MAXPL) return -2;
+    const int G = ader_ln_bwd_slabs(rows);
+    hipLaunchKernelGGL(k_ln_bwd, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, dy_rs, x, x_rs, gamma, mean_i, std_i, add, add_rs,
+                       dx, dx_rs, slab, rows, H);
+    // slab layout [G][2][H]: row 0 = dgamma partial, row 1 = dbeta partial
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
+                       dgamma, dbeta);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, unsigned drop_key,
+                       unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_mask_dropgrad, dim3(cap_grid((size_t)rows * H, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx2, seq, g,
+                       dh2, rows, H, mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_rows, int n_cols, float* dst, float* dst_extra,
+                      void* stream) {
+    const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
+                       n_cols, dst, dst_extra);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,
+                   void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam, dim3(cap_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n, lr_t,
+                       1.0f - beta1, 1.0f - beta2, eps);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_fill(float* p, size_t n, float val, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_fill, dim3(cap_grid(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, n, val);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,453 @@
+"""Device state and step orchestration of the ADER hot path on one MI355X.
+
+Holds the trainable state of the reference graph (item table [V,H], positional table [T,H], per block
+LN1, dense Q/K/V, LN2, conv1d x2, final LN) in ONE flat float32 buffer (plus Adam m/v and the gradient in the
+same layout, so dense Adam is a single flat kernel and the data-parallel gradient exchange is a single buffer),
+the saved activations, and issues the HIP launchers of include/ader_hip.h on torch's current stream.
+
+Nothing here computes on the CPU: without libader_hip.so / a GPU the constructor raises.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_BIAS_DROP_RES_MASK, EPI_RELUDROPGRAD, EPI_ADD = range(5)
+SITE_EMB = 0
+
+
+def site_attn(l):
+    return 1 + 3 * l
+
+
+def site_ffn1(l):
+    return 2 + 3 * l
+
+
+def site_ffn2(l):
+    return 3 + 3 * l
+
+
+# ------------------------------------------------------------------ dropout counter keys (host side of the spec)
+def _lowbias32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_key(seed, step, site):
+    a = _lowbias32((seed & 0xFFFFFFFF) ^ 0x9E3779B9)
+    b = (a + (step & 0xFFFFFFFF) * 0x85EBCA6B + site * 0xC2B2AE35) & 0xFFFFFFFF
+    return _lowbias32(b)
+
+
+class _Drop:
+    """(key, thr, scale, base) of one dropout site for one step."""
+
+    __slots__ = ("key", "thr", "scale", "base")
+
+    def __init__(self, seed, step, site, rate, training, base):
+        if training and rate > 0.0:
+            self.key = dropout_key(seed, step, site)
+            self.thr = int(round(float(rate) * 16777216.0))
+            self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
+        else:
+            self.key, self.thr, self.scale = 0, 0, 1.0
+        self.base = base & 0xFFFFFFFF
+
+    def args(self):
+        return (self.key, self.thr, self.scale, self.base)
+
+
+def param_layout(item_num, T, H, L, align=64):
+    """name -> (offset, shape) in the flat buffer; every tensor starts on a 256-byte boundary."""
+    names = [("emb", (item_num + 1, H)), ("pos", (T, H))]
+    for l in range(L):
+        p = "b%d." % l
+        names += [(p + "ln1_g", (H,)), (p + "ln1_b", (H,)),
+                  (p + "wq", (H, H)), (p + "bq", (H,)), (p + "wk", (H, H)), (p + "bk", (H,)),
+                  (p + "wv", (H, H)), (p + "bv", (H,)),
+                  (p + "ln2_g", (H,)), (p + "ln2_b", (H,)),
+                  (p + "w1", (H, H)), (p + "b1", (H,)), (p + "w2", (H, H)), (p + "b2", (H,))]
+    names += [("lnf_g", (H,)), ("lnf_b", (H,))]
+    layout, off = {}, 0
+    for n, shp in names:
+        layout[n] = (off, shp)
+        off += int(np.prod(shp))
+        off = (off + align - 1) // align * align
+    return layout, off
+
+
+class Engine:
+    MAX_ROWS = 1024   # padded batch rows per launch (logits kernels keep per-row state in LDS)
+
+    def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.AderHipError("ader_amd.Engine needs an MI355X (no CPU fallback)")
+        _lib.load()
+        assert hidden_units <= 159 and maxlen <= 64 and hidden_units % num_heads == 0
+        self.item_num, self.T, self.H, self.L, self.heads = item_num, maxlen, hidden_units, num_blocks, num_heads
+        self.V = item_num + 1
+        self.seed = seed
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.layout, self.P = param_layout(item_num, maxlen, hidden_units, num_blocks)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.theta = torch.zeros(self.P, **f32)
+        self.adam_m = torch.zeros(self.P, **f32)
+        self.adam_v = torch.zeros(self.P, **f32)
+        self.grad = torch.zeros(self.P, **f32)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.loss = torch.zeros(1, **f32)
+        self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
+        self.b1p, self.b2p = np.float32(self.beta1), np.float32(self.beta2)   # TF keeps beta powers in float32 variables
+        self.global_step = 0
+        self.row0 = 0            # global index of local row 0 (data-parallel shard offset of the dropout counters)
+        self._grad_hi = 0
+        self._ws = {}
+        self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
+        # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
+        self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
+        self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
+        self.init_params(seed)
+
+    # ---------------------------------------------------------------------------------------- parameters
+    def view(self, buf, name):
+        off, shp = self.layout[name]
+        return buf[off:off + int(np.prod(shp))].view(*shp)
+
+    def param(self, name):
+        return self.view(self.theta, name)
+
+    def gradient(self, name):
+        return self.view(self.grad, name)
+
+    def init_params(self, seed):
+        """TF defaults at the reference call sites: Glorot-uniform tables/kernels, zero biases, LN gamma=1 beta=0."""
+        g = torch.Generator().manual_seed(seed)
+        for name, (off, shp) in self.layout.items():
+            base = name.split(".")[-1]
+            if base in ("emb", "pos", "wq", "wk", "wv", "w1", "w2"):
+                lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+                t = ((torch.rand(shp, generator=g, dtype=torch.float64) * 2 - 1) * lim).float()
+            elif base.endswith("_g"):
+                t = torch.ones(shp)
+            else:
+                t = torch.zeros(shp)
+            self.param(name).copy_(t)
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.b1p, self.b2p = np.float32(self.beta1), np.float32(self.beta2)
+        self.global_step = 0
+
+    def load_params(self, params):
+        for k, v in params.items():
+            self.param(k).copy_(torch.as_tensor(v, dtype=torch.float32))
+
+    def export_params(self):
+        return {k: self.param(k).detach().cpu().clone() for k in self.layout}
+
+    def state_dict(self):
+        return {"theta": self.theta.detach().cpu().clone(), "m": self.adam_m.detach().cpu().clone(),
+                "v": self.adam_v.detach().cpu().clone(), "b1p": float(self.b1p), "b2p": float(self.b2p),
+                "global_step": self.global_step}
+
+    def load_state_dict(self, sd):
+        self.theta.copy_(sd["theta"])
+        self.adam_m.copy_(sd["m"])
+        self.adam_v.copy_(sd["v"])
+        self.b1p, self.b2p = np.float32(sd["b1p"]), np.float32(sd["b2p"])
+        self.global_step = int(sd["global_step"])
+
+    # ---------------------------------------------------------------------------------------- workspaces
+    def buf(self, name, shape, dtype=torch.float32):
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _dev_i32(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32)).to(self.device)
+
+    # ---------------------------------------------------------------------------------------- forward
+    def forward(self, seq, training=False, rate=0.0, step=0, save=False):
+        """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward."""
+        B, T, H, L = seq.shape[0], self.T, self.H, self.L
+        rows = B * T
+        st = self._stream()
+        tag = "t" if save else "e"
+        A = {"B": B, "seq": seq, "rate": rate, "training": training, "step": step}
+        per_row = T * H
+        d0 = _Drop(self.seed, step, SITE_EMB, rate, training, self.row0 * per_row)
+        x = self.buf(tag + "x0", (rows, H))
+        call("ader_embed_fwd", ptr(seq), self._pp["emb"], self._pp["pos"], ptr(x), rows, T, H, self.V,
+             *d0.args(), ptr(self.status), st)
+        A["d_emb"] = d0
+        for l in range(L):
+            p = "b%d." % l
+            n = lambda s: "%s%d%s" % (tag, l, s)   # noqa: E731
+            q_in = self.buf(n("qin"), (rows, H))
+            mean1, std1 = self.buf(n("m1"), (rows,)), self.buf(n("s1"), (rows,))
+            kmask, qmask = self.buf(n("km"), (rows,)), self.buf(n("qm"), (rows,))
+            call("ader_ln_fwd", ptr(x), H, ptr(q_in), H, self._pp[p + "ln1_g"], self._pp[p + "ln1_b"],
+                 ptr(mean1), ptr(std1), ptr(kmask), ptr(qmask), rows, H, st)
+            Q, K, Vv = self.buf(n("Q"), (rows, H)), self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
+            nd = (0, 0, 1.0, 0)
+            call("ader_gemm_rows", ptr(q_in), self._pp[p + "wq"], self._pp[p + "bq"], ptr(Q), None, None,
+                 rows, H, EPI_BIAS, 0, *nd, st)
+            call("ader_gemm_rows", ptr(x), self._pp[p + "wk"], self._pp[p + "bk"], ptr(K), None, None,
+                 rows, H, EPI_BIAS, 0, *nd, st)
+            call("ader_gemm_rows", ptr(x), self._pp[p + "wv"], self._pp[p + "bv"], ptr(Vv), None, None,
+                 rows, H, EPI_BIAS, 0, *nd, st)
+            x1 = self.buf(n("x1"), (rows, H))
+            Pm = self.buf(n("P"), (B * self.heads * T * T,))
+            da = _Drop(self.seed, step, site_attn(l), rate, training, self.row0 * self.heads * T * T)
+            call("ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask), ptr(qmask), ptr(x1), ptr(Pm), B, T, H,
+                 self.heads, *da.args(), st)
+            y = self.buf(n("y"), (rows, H))
+            mean2, std2 = self.buf(n("m2"), (rows,)), self.buf(n("s2"), (rows,))
+            call("ader_ln_fwd", ptr(x1), H, ptr(y), H, self._pp[p + "ln2_g"], self._pp[p + "ln2_b"],
+                 ptr(mean2), ptr(std2), None, None, rows, H, st)
+            h1d = self.buf(n("h1"), (rows, H))
+            d1 = _Drop(self.seed, step, site_ffn1(l), rate, training, self.row0 * per_row)
+            call("ader_gemm_rows", ptr(y), self._pp[p + "w1"], self._pp[p + "b1"], ptr(h1d), None, None,
+                 rows, H, EPI_BIAS_RELU_DROP, 0, *d1.args(), st)
+            x2 = self.buf(n("x2"), (rows, H))
+            d2 = _Drop(self.seed, step, site_ffn2(l), rate, training, self.row0 * per_row)
+            call("ader_gemm_rows", ptr(h1d), self._pp[p + "w2"], self._pp[p + "b2"], ptr(x2), ptr(y), ptr(seq),
+                 rows, H, EPI_BIAS_DROP_RES_MASK, 0, *d2.args(), st)
+            A[l] = dict(x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv, P=Pm, x1=x1,
+                        y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
+            x = x2
+        rep = self.buf(tag + "rep", (B, H))
+        meanf, stdf = self.buf(tag + "mf", (B,)), self.buf(tag + "sf", (B,))
+        x_last = x.view(B, T, H)[:, T - 1, :]
+        call("ader_ln_fwd", ptr(x_last), T * H, ptr(rep), H, self._pp["lnf_g"], self._pp["lnf_b"],
+             ptr(meanf), ptr(stdf), None, None, B, H, st)
+        A.update(xL=x, rep=rep, meanf=meanf, stdf=stdf)
+        if save:
+            self._act = A
+        return rep
+
+    # ---------------------------------------------------------------------------------------- loss rows
+    def _rowinfo(self, B, pos, n_train, ex_pos, ex_trow, N, Np, w_train, w_ex, teacher):
+        Bp = (B + 63) // 64 * 64
+        st = self._stream()
+        lab = self.buf("ri_lab", (Bp,), torch.int32)
+        ncol = self.buf("ri_ncol", (Bp,), torch.int32)
+        wrow = self.buf("ri_w", (Bp,))
+        trow = self.buf("ri_trow", (Bp,), torch.int32)
+        tlse = self.buf("ri_tlse", (Bp,))
+        n_ex = B - n_train
+        call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos), ptr(ex_trow), n_ex, N, Np, float(w_train), float(w_ex), Bp,
+             ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
+        if teacher is not None and n_ex > 0:
+            call("ader_row_lse", ptr(teacher), teacher.stride(0), Np, ptr(trow), Bp, ptr(tlse), st)
+            tptr, ldt = ptr(teacher), teacher.stride(0)
+        else:
+            tlse.zero_()
+            tptr, ldt = None, 0
+        return Bp, (ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), ptr(tlse), tptr, ldt)
+
+    # ---------------------------------------------------------------------------------------- train step
+    def loss_and_grad(self, seq, pos, max_item, *, ex_pos=None, teacher=None, ex_trow=None, lambda_=0.0, rate=0.0,
+                      n_train_global=None, n_ex_global=None):
+        """Forward + backward of one step (no optimiser).  seq [B,T] holds the train rows first and the exemplar rows
+        after (main.py:229); pos [n_train]; exemplars are either distilled (teacher [*,Np] + ex_trow [n_ex] row indices,
+        ADER.py:132-137) or one-hot (ex_pos [n_ex], ADER.py:126-131).  Leaves the loss in self.loss (device scalar) and
+        the gradient of every parameter in self.grad."""
+        seq = self._dev_i32(seq)
+        pos = self._dev_i32(pos)
+        B, T, H, L = seq.shape[0], self.T, self.H, self.L
+        assert B <= self.MAX_ROWS, "at most %d rows per step" % self.MAX_ROWS
+        n_train = pos.shape[0]
+        n_ex = B - n_train
+        N = int(max_item)
+        assert 1 <= N <= self.item_num
+        Np = 0
+        if n_ex > 0:
+            if teacher is not None:
+                ex_trow = self._dev_i32(ex_trow if ex_trow is not None else np.arange(n_ex))
+                Np = teacher.shape[1]
+                assert teacher.dtype == torch.float32 and teacher.stride(1) == 1 and Np <= N
+            else:
+                ex_pos = self._dev_i32(ex_pos)
+                assert ex_pos.shape[0] == n_ex
+        w_train = 1.0 / float(n_train_global if n_train_global is not None else max(n_train, 1))
+        w_ex = (lambda_ / float(n_ex_global if n_ex_global is not None else n_ex)) if n_ex > 0 else 0.0
+        step = self.global_step
+        st = self._stream()
+        rows = B * T
+        rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
+        A = self._act
+        Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
+                               N, Np, w_train, w_ex, teacher)
+        emb = self.param("emb")
+        parts = call("ader_logits_parts", N)
+        part = self.buf("lg_part", (parts * Bp * 3,))
+        lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
+        call("ader_logits_loss_fwd", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(part), ptr(lse), ptr(rowloss), ptr(self.loss), st)
+        # ---- backward
+        demb = self.gradient("emb")
+        if N < self._grad_hi:   # catalog shrank (never in the reference flow): clear stale rows
+            demb[N + 1:self._grad_hi + 1].zero_()
+        self._grad_hi = max(self._grad_hi, N)
+        ranges = call("ader_logits_ranges", N, Bp)
+        slab = self.buf("lg_slab", (ranges * Bp * 160,))
+        drep = self.buf("drep", (B, H))
+        call("ader_logits_loss_bwd", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), ptr(demb), st)
+        wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))
+        dx = self.buf("dx_a", (rows, H))
+        dx.zero_()
+        xL = A["xL"]
+        call("ader_ln_bwd", ptr(drep), H, ptr(xL.view(B, T, H)[:, T - 1, :]), T * H, self._pp["lnf_g"],
+             ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab),
+             self._gp["lnf_g"], self._gp["lnf_b"], B, H, st)
+        g = self.buf("bw_g", (rows, H))
+        dh2 = self.buf("bw_dh2", (rows, H))
+        da_ = self.buf("bw_da", (rows, H))
+        dy = self.buf("bw_dy", (rows, H))
+        dx1 = self.buf("bw_dx1", (rows, H))
+        dQ, dK, dV = self.buf("bw_dQ", (rows, H)), self.buf("bw_dK", (rows, H)), self.buf("bw_dV", (rows, H))
+        dqin = self.buf("bw_dqin", (rows, H))
+        dxn = self.buf("dx_b", (rows, H))
+        nd = (0, 0, 1.0, 0)
+        for l in reversed(range(L)):
+            p = "b%d." % l
+            S = A[l]
+            W = lambda s: self._pp[p + s]      # noqa: E731
+            G = lambda s: self._gp[p + s]   # noqa: E731
+            call("ader_mask_dropgrad", ptr(dx), ptr(seq), ptr(g), ptr(dh2), rows, H, *S["d2"].args(), st)
+            call("ader_gemm_rows", ptr(dh2), W("w2"), None, ptr(da_), ptr(S["h1d"]), None, rows, H, EPI_RELUDROPGRAD, 1,
+                 *S["d1"].args(), st)
+            call("ader_gemm_rows", ptr(da_), W("w1"), None, ptr(dy), ptr(g), None, rows, H, EPI_ADD, 1, *nd, st)
+            call("ader_gemm_atb", ptr(S["h1d"]), ptr(dh2), ptr(wslab), G("w2"), G("b2"), rows, H, st)
+            call("ader_gemm_atb", ptr(S["y"]), ptr(da_), ptr(wslab), G("w1"), G("b1"), rows, H, st)
+            call("ader_ln_bwd", ptr(dy), H, ptr(S["x1"]), H, W("ln2_g"), ptr(S["mean2"]), ptr(S["std2"]), None, 0, ptr(dx1), H,
+                 ptr(wslab), G("ln2_g"), G("ln2_b"), rows, H, st)
+            call("ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]),
+                 ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
+            call("ader_gemm_rows", ptr(dQ), W("wq"), None, ptr(dqin), ptr(dx1), None, rows, H, EPI_ADD, 1, *nd, st)
+            call("ader_ln_bwd", ptr(dqin), H, ptr(S["x"]), H, W("ln1_g"), ptr(S["mean1"]), ptr(S["std1"]), None, 0, ptr(dxn), H,
+                 ptr(wslab), G("ln1_g"), G("ln1_b"), rows, H, st)
+            call("ader_gemm_rows", ptr(dK), W("wk"), None, ptr(dxn), ptr(dxn), None, rows, H, EPI_ADD, 1, *nd, st)
+            call("ader_gemm_rows", ptr(dV), W("wv"), None, ptr(dxn), ptr(dxn), None, rows, H, EPI_ADD, 1, *nd, st)
+            call("ader_gemm_atb", ptr(S["q_in"]), ptr(dQ), ptr(wslab), G("wq"), G("bq"), rows, H, st)
+            call("ader_gemm_atb", ptr(S["x"]), ptr(dK), ptr(wslab), G("wk"), G("bk"), rows, H, st)
+            call("ader_gemm_atb", ptr(S["x"]), ptr(dV), ptr(wslab), G("wv"), G("bv"), rows, H, st)
+            dx, dxn = dxn, dx
+        call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), self._gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+        return self.loss
+
+    def adam(self, lr):
+        """tf.train.AdamOptimizer step on every variable (dense, incl. the whole table; ADER.py:96)."""
+        lr_t = float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
+        call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, lr_t, self.beta1,
+             self.beta2, self.eps, self._stream())
+        self.b1p = np.float32(self.b1p * np.float32(self.beta1))
+        self.b2p = np.float32(self.b2p * np.float32(self.beta2))
+        self.global_step += 1
+
+    def train_step(self, seq, pos, max_item, lr, **kw):
+        """One `sess.run(train_op)` (main.py:233-256): forward, loss, backward, [gradient exchange], Adam.
+        Returns the loss as a 1-element device tensor (no host sync)."""
+        loss = self.loss_and_grad(seq, pos, max_item, **kw)
+        if self.grad_hook is not None:
+            self.grad_hook(self)
+        self.adam(lr)
+        return loss
+
+    def check_status(self):
+        s = int(self.status.item())
+        if s:
+            self.status.zero_()
+            raise _lib.AderHipError("device status %d: item id outside [0, item_num] in input_seq" % s)
+
+    # ---------------------------------------------------------------------------------------- inference paths
+    def encode(self, seq):
+        """Eval-mode representation (is_training=False): rep [n,H] for any n (chunks of MAX_ROWS)."""
+        seq = self._dev_i32(seq)
+        n = seq.shape[0]
+        out = torch.empty((n, self.H), dtype=torch.float32, device=self.device)
+        for s in range(0, n, self.MAX_ROWS):
+            e = min(n, s + self.MAX_ROWS)
+            out[s:e] = self.forward(seq[s:e], training=False)
+        return out
+
+    def _ncol_all(self, Bp, B, N):
+        t = self.buf("ncol_all", (Bp,), torch.int32)
+        t.zero_()
+        t[:B] = N
+        return t
+
+    def logits_from_rep(self, rep, max_item, out=None):
+        """Dense logits [n, N] = rep . E[1..N]^T  (ADER.py:92)."""
+        n, N = rep.shape[0], int(max_item)
+        if out is None:
+            out = torch.empty((n, N), dtype=torch.float32, device=self.device)
+        for s in range(0, n, self.MAX_ROWS):
+            e = min(n, s + self.MAX_ROWS)
+            B = e - s
+            Bp = (B + 63) // 64 * 64
+            r = rep[s:e].contiguous()
+            call("ader_logits_store", ptr(r), self._pp["emb"], B, Bp, self.H, N, ptr(self._ncol_all(Bp, B, N)),
+                 ptr(out[s:e]), out.stride(0), self._stream())
+        return out
+
+    def logits(self, seq, max_item):
+        return self.logits_from_rep(self.encode(seq), max_item)
+
+    def teacher_logits(self, seq, max_item):
+        return self.logits(seq, max_item)
+
+    def rank_targets(self, seq, pos, max_item):
+        """0-based rank of pos[b] among items 1..N for every row (Evaluator path, util.py:323-325) -> int32 numpy [n]."""
+        seq = self._dev_i32(seq)
+        pos = self._dev_i32(pos)
+        n, N = seq.shape[0], int(max_item)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        for s in range(0, n, self.MAX_ROWS):
+            e = min(n, s + self.MAX_ROWS)
+            B = e - s
+            Bp = (B + 63) // 64 * 64
+            rep = self.forward(seq[s:e], training=False)
+            tl = self.buf("rk_tl", (Bp,))
+            rk = self.buf("rk_rank", (Bp,), torch.int32)
+            tgt = self.buf("rk_tgt", (Bp,), torch.int32)
+            tgt.zero_()
+            tgt[:B] = pos[s:e]
+            call("ader_rank_targets", ptr(rep), self._pp["emb"], B, Bp, self.H, N, ptr(tgt), ptr(self._ncol_all(Bp, B, N)),
+                 ptr(tl), ptr(rk), self._stream())
+            out[s:e] = rk[:B]
+        return out.cpu().numpy()
+
+    def herding_select(self, seq_rows, offs, quota, max_item):
+        """Segmented herding over label groups (util.py:436-461).  seq_rows [n,T] candidates in group order, offs [G+1],
+        quota [G] = min(m, n_g).  Returns (sel [n] local indices per group span, sel_cnt [G]) as numpy."""
+        from .exemplar import herding_max_steps
+        rep = self.encode(seq_rows)
+        n, G = rep.shape[0], len(quota)
+        seg = torch.as_tensor(np.asarray(offs, dtype=np.int64)).to(self.device)
+        q = torch.as_tensor(np.asarray(quota, dtype=np.int32)).to(self.device)
+        ms = torch.as_tensor(np.array([herding_max_steps(int(m)) for m in quota], dtype=np.int32)).to(self.device)
+        D = torch.empty(max(n * self.H, 1), dtype=torch.float32, device=self.device)
+        chosen = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+        sel = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        cnt = torch.zeros(max(G, 1), dtype=torch.int32, device=self.device)
+        call("ader_herding_select", ptr(rep), ptr(seg), ptr(q), ptr(ms), G, n, self.H, ptr(D), ptr(chosen), ptr(sel), ptr(cnt),
+             None, self._stream())
+        return sel.cpu().numpy().astype(np.int64), cnt.cpu().numpy()

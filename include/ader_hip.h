@@ -1,0 +1,104 @@
+/* ader_hip.h -- C ABI of libader_hip.so: the MI355X (gfx950) kernels of the ADER / SASRec training hot path.
+ *
+ * The reference (doublemul/ADER) is pure Python/TensorFlow and has NO native interface: the boundary these
+ * entry points replace is the set of TF ops executed by `sess.run` at main.py:233-256 (train step),
+ * util.py:323 -> ADER.py:140-150 (ranking) and util.py:452-455 + util.py:401-434 (exemplar selection).
+ * Each function below names the reference op site it replaces.
+ *
+ * Conventions: plain device pointers (float32 / int32 unless noted), sizes as ints, `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Launchers only enqueue work (no sync, no allocation: graph-capturable);
+ * they return 0 on success, a hipError_t value on a HIP error, or a negative code for unsupported shapes
+ * (-2: dimension out of range, -3: bad enum).  Inputs are borrowed for the duration of the enqueued work.
+ * Limits of this build: H (hidden_units) <= 159, maxlen T <= 64, padded batch rows Bp <= 1024 and Bp % 64 == 0.
+ */
+#ifndef ADER_HIP_H
+#define ADER_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dropout everywhere: keep(idx) = (lowbias32((idx + drop_base) ^ drop_key) >> 8) >= drop_thr, value * drop_scale when
+ * kept; drop_thr == 0 disables it.  (tf.layers.dropout sites ADER.py:55, modules.py:214,257,262; TF's RNG stream is
+ * not reproducible, the counter spec is the build's own and is restated in oracle/ader_ref_cpu.py.) */
+
+/* ---- embedding prologue: modules.py:118-130 + ADER.py:41-60 ------------------------------------------- */
+int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x, int rows, int T, int H, int V,
+                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, int* status, void* stream);
+/* backward: dx [B*T,H] is overwritten with the masked/dropout-scaled gradient; sqrt(H)*that is scatter-added into
+ * demb (must already hold the logits-side gradient); dpos [T,H] is overwritten. */
+int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
+                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+
+/* ---- LayerNorm: modules.py:23-50 (`normalize`) ---------------------------------------------------------- */
+/* xnz/ynz (optional) = sign(|sum_c x|), sign(|sum_c y|): the key / query masks of modules.py:188,208. */
+int ader_ln_fwd(const float* x, long x_row_stride, float* y, long y_row_stride, const float* gamma, const float* beta,
+                float* mean_out, float* std_out, float* xnz, float* ynz, int rows, int H, void* stream);
+int ader_ln_bwd_slabs(int rows);
+/* dx = LN'(dy) (+ add); dgamma/dbeta overwritten.  slab: ader_ln_bwd_slabs(rows)*2*H floats of scratch. */
+int ader_ln_bwd(const float* dy, long dy_row_stride, const float* x, long x_row_stride, const float* gamma,
+                const float* mean_in, const float* std_in, const float* add, long add_row_stride, float* dx,
+                long dx_row_stride, float* slab, float* dgamma, float* dbeta, int rows, int H, void* stream);
+
+/* ---- dense layers: modules.py:172-174 (Q/K/V), modules.py:254-266 (FFN) -------------------------------- */
+enum { ADER_EPI_BIAS = 0, ADER_EPI_BIAS_RELU_DROP = 1, ADER_EPI_BIAS_DROP_RES_MASK = 2, ADER_EPI_RELUDROPGRAD = 3,
+       ADER_EPI_ADD = 4 };
+/* C[M,H] = epilogue(A[M,H] . (trans_b ? W^T : W) + bias).  aux/seq per epilogue, see csrc/gemm.hip. */
+int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, const float* aux, const int* seq, int M,
+                   int H, int epilogue, int trans_b, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                   unsigned drop_base, void* stream);
+int ader_gemm_atb_slabs(int M);
+/* dW[H,H] = A^T . G, db[H] = column sums of G (db may be NULL).  slab: ader_gemm_atb_slabs(M)*160*160 floats. */
+int ader_gemm_atb(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
+/* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
+int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, unsigned drop_key,
+                       unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+
+/* ---- attention core: modules.py:177-223 --------------------------------------------------------------- */
+int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask,
+                  const float* qmask, float* out, float* P, int B, int T, int H, int heads, unsigned drop_key,
+                  unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* P, const float* kmask,
+                  const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads,
+                  unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+
+/* ---- full-catalog logits + loss: ADER.py:88-93, 108-137 ------------------------------------------------ */
+/* Row descriptors, all [Bp]: lab (1-based target item or 0), ncol (valid columns: N, or Np for distilled rows, 0 for
+ * padding rows), wrow (loss weight), trow (row of `teacher` or -1), tlse (log-sum-exp of that teacher row). */
+int ader_logits_sub(int N);
+int ader_logits_parts(int N);
+int ader_logits_ranges(int N, int Bp);
+/* Builds the row descriptors of one step on the device (train rows first, exemplar rows after, ADER.py:113-118). */
+int ader_build_rowinfo(const int* pos, int n_train, const int* ex_pos, const int* ex_trow, int n_ex, int N, int Np,
+                       float w_train, float w_ex, int Bp, int* lab, int* ncol, float* wrow, int* trow, void* stream);
+int ader_row_lse(const float* x, long ld, int ncols, const int* rows, int nrows, float* out, void* stream);
+int ader_logits_loss_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
+                         const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt,
+                         float* part, float* lse, float* rowloss, float* loss, void* stream);
+int ader_logits_loss_bwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
+                         const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt,
+                         const float* lse, float* slab, float* drep, float* demb, void* stream);
+/* out[b, 0:N] = rep[b] . E[1..N]^T  (model.logits fetch util.py:452; teacher logits util.py:433) */
+int ader_logits_store(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* ncol_all, float* out,
+                      long ldo, void* stream);
+/* 0-based rank of target[b] among items 1..N, ties -> lower index first: replaces argsort(argsort(-logits)) (ADER.py:103)
+ * + the host gather pred[label-1] (util.py:325). */
+int ader_rank_targets(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* target, const int* ncol,
+                      float* tlogit, int* rank, void* stream);
+
+/* ---- optimiser: tf.train.AdamOptimizer (ADER.py:96), dense over one flat buffer ------------------------ */
+int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,
+                   void* stream);
+int ader_fill(float* p, size_t n, float value, void* stream);
+int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_rows, int n_cols, float* dst,
+                      float* dst_extra, void* stream);
+
+/* ---- herding exemplar selection: util.py:401-434 ------------------------------------------------------- */
+int ader_herding_select(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
+                        int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
