@@ -30,7 +30,8 @@ _SIGS = {
     "ader_row_lse": [P, L, I, P, I, P, P],
     "ader_build_rowinfo": [P, I, P, P, I, I, I, F, F, I, P, P, P, P, P],
     "ader_logits_loss_fwd": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P, P],
-    "ader_logits_loss_bwd": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P, P],
+    "ader_logits_bwd_drep": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P],
+    "ader_logits_bwd_demb": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P],
     "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
     "ader_rank_targets": [P, P, I, I, I, I, P, P, P, P, P],
     "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P],

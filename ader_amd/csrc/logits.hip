@@ -479,26 +479,37 @@ int ader_logits_loss_fwd(const float* rep, const float* emb, int B, int Bp, int 
     return 0;
 }
 
-// Backward: dRep [B,H] (via slabs: ader_logits_ranges(N,Bp) * Bp * 160 floats) and dE rows 1..N (overwritten).
-int ader_logits_loss_bwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
+// Backward, part 1: dRep [B,H] (slab: ader_logits_ranges(N,Bp) * Bp * 160 floats of scratch).
+int ader_logits_bwd_drep(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
                          const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt, const float* lse,
-                         float* slab, float* drep, float* demb, void* stream) {
+                         float* slab, float* drep, void* stream) {
     if (B <= 0) return 0;
     LogitArgs a;
     int rc = fill_args(a, rep, emb, B, Bp, H, N, lab, ncol, wrow, trow, tlse, teacher, ldt);
     if (rc) return rc;
-    static bool f1 = false, f2 = false;
+    static bool f1 = false;
     rc = set_lds(k_logits_bwd_drep, kBwdLds, f1);
     if (rc) return rc;
+    a.lse = lse; a.slab = slab; a.ranges = ader_logits_ranges(N, Bp);
+    const int nchunk = Bp / TB;
+    hipLaunchKernelGGL(k_logits_bwd_drep, dim3(a.ranges * nchunk), dim3(512), kBwdLds, (hipStream_t)stream, a);
+    HIP_LAUNCH_CHECK();
+    return ader_reduce_slabs(slab, (long)Bp * HP, a.ranges, HP, B, H, drep, nullptr, stream);
+}
+
+// Backward, part 2: table gradient rows 1..N (overwritten; every row written exactly once, no atomics).
+int ader_logits_bwd_demb(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
+                         const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt, const float* lse,
+                         float* demb, void* stream) {
+    if (B <= 0) return 0;
+    LogitArgs a;
+    int rc = fill_args(a, rep, emb, B, Bp, H, N, lab, ncol, wrow, trow, tlse, teacher, ldt);
+    if (rc) return rc;
+    static bool f2 = false;
     rc = set_lds(k_logits_bwd_de, kBwdLds, f2);
     if (rc) return rc;
-    a.lse = lse; a.slab = slab; a.ranges = ader_logits_ranges(N, Bp); a.demb1 = demb + H;
-    hipStream_t st = (hipStream_t)stream;
-    const int nchunk = Bp / TB;
-    hipLaunchKernelGGL(k_logits_bwd_drep, dim3(a.ranges * nchunk), dim3(512), kBwdLds, st, a);
-    rc = ader_reduce_slabs(slab, (long)Bp * HP, a.ranges, HP, B, H, drep, nullptr, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_logits_bwd_de, dim3((N + TI - 1) / TI), dim3(512), kBwdLds, st, a);
+    a.lse = lse; a.demb1 = demb + H;
+    hipLaunchKernelGGL(k_logits_bwd_de, dim3((N + TI - 1) / TI), dim3(512), kBwdLds, (hipStream_t)stream, a);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -66,6 +66,51 @@ class _Drop:
         return (self.key, self.thr, self.scale, self.base)
 
 
+class SectionTimer:
+    """HIP-event timing of named launch groups on the stream the kernels are launched on (bench.py roofline leg).
+    Events are recorded around each section; elapsed times are read back after a sync with collect()."""
+
+    def __init__(self):
+        self.pending = []
+        self.totals = {}
+        self.counts = {}
+
+    class _Ctx:
+        def __init__(self, owner, name):
+            self.o, self.name = owner, name
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+        def __exit__(self, *exc):
+            self.b.record(torch.cuda.current_stream())
+            self.o.pending.append((self.name, self.a, self.b))
+
+    def section(self, name):
+        return SectionTimer._Ctx(self, name)
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for name, a, b in self.pending:
+            self.totals[name] = self.totals.get(name, 0.0) + a.elapsed_time(b)
+            self.counts[name] = self.counts.get(name, 0) + 1
+        self.pending = []
+        return {k: self.totals[k] / self.counts[k] for k in self.totals}
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
 def param_layout(item_num, T, H, L, align=64):
     """name -> (offset, shape) in the flat buffer; every tensor starts on a 256-byte boundary."""
     names = [("emb", (item_num + 1, H)), ("pos", (T, H))]
@@ -113,6 +158,7 @@ class Engine:
         self._grad_hi = 0
         self._ws = {}
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
+        self.timer = None        # optional SectionTimer
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -177,6 +223,9 @@ class Engine:
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
+
+    def _sec(self, name):
+        return self.timer.section(name) if self.timer is not None else _NULL
 
     def _dev_i32(self, x):
         if isinstance(x, torch.Tensor):
@@ -292,7 +341,8 @@ class Engine:
         step = self.global_step
         st = self._stream()
         rows = B * T
-        rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
+        with self._sec("blocks_fwd"):
+            rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         A = self._act
         Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
                                N, Np, w_train, w_ex, teacher)
@@ -300,7 +350,8 @@ class Engine:
         parts = call("ader_logits_parts", N)
         part = self.buf("lg_part", (parts * Bp * 3,))
         lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
-        call("ader_logits_loss_fwd", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(part), ptr(lse), ptr(rowloss), ptr(self.loss), st)
+        with self._sec("logits_fwd"):
+            call("ader_logits_loss_fwd", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(part), ptr(lse), ptr(rowloss), ptr(self.loss), st)
         # ---- backward
         demb = self.gradient("emb")
         if N < self._grad_hi:   # catalog shrank (never in the reference flow): clear stale rows
@@ -309,7 +360,12 @@ class Engine:
         ranges = call("ader_logits_ranges", N, Bp)
         slab = self.buf("lg_slab", (ranges * Bp * 160,))
         drep = self.buf("drep", (B, H))
-        call("ader_logits_loss_bwd", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), ptr(demb), st)
+        with self._sec("logits_bwd_drep"):
+            call("ader_logits_bwd_drep", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), st)
+        with self._sec("logits_bwd_demb"):
+            call("ader_logits_bwd_demb", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
+        tb = self._sec("blocks_bwd")
+        tb.__enter__()
         wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))
         dx = self.buf("dx_a", (rows, H))
         dx.zero_()
@@ -351,13 +407,15 @@ class Engine:
             call("ader_gemm_atb", ptr(S["x"]), ptr(dV), ptr(wslab), G("wv"), G("bv"), rows, H, st)
             dx, dxn = dxn, dx
         call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), self._gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+        tb.__exit__(None, None, None)
         return self.loss
 
     def adam(self, lr):
         """tf.train.AdamOptimizer step on every variable (dense, incl. the whole table; ADER.py:96)."""
         lr_t = float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
-        call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, lr_t, self.beta1,
-             self.beta2, self.eps, self._stream())
+        with self._sec("adam"):
+            call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, lr_t, self.beta1,
+                 self.beta2, self.eps, self._stream())
         self.b1p = np.float32(self.b1p * np.float32(self.beta1))
         self.b2p = np.float32(self.b2p * np.float32(self.beta2))
         self.global_step += 1
@@ -367,7 +425,8 @@ class Engine:
         Returns the loss as a 1-element device tensor (no host sync)."""
         loss = self.loss_and_grad(seq, pos, max_item, **kw)
         if self.grad_hook is not None:
-            self.grad_hook(self)
+            with self._sec("grad_exchange"):
+                self.grad_hook(self)
         self.adam(lr)
         return loss
 

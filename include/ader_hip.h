@@ -76,9 +76,14 @@ int ader_row_lse(const float* x, long ld, int ncols, const int* rows, int nrows,
 int ader_logits_loss_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
                          const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt,
                          float* part, float* lse, float* rowloss, float* loss, void* stream);
-int ader_logits_loss_bwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
+/* backward part 1: drep [B,H] = dlogit . E   (slab: ader_logits_ranges(N,Bp)*Bp*160 floats of scratch) */
+int ader_logits_bwd_drep(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
                          const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt,
-                         const float* lse, float* slab, float* drep, float* demb, void* stream);
+                         const float* lse, float* slab, float* drep, void* stream);
+/* backward part 2: demb rows 1..N = dlogit^T . rep  (overwritten, each row written once) */
+int ader_logits_bwd_demb(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const int* ncol,
+                         const float* wrow, const int* trow, const float* tlse, const float* teacher, long ldt,
+                         const float* lse, float* demb, void* stream);
 /* out[b, 0:N] = rep[b] . E[1..N]^T  (model.logits fetch util.py:452; teacher logits util.py:433) */
 int ader_logits_store(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* ncol_all, float* out,
                       long ldo, void* stream);
