@@ -1,0 +1,88 @@
+"""Data parallelism for the train step: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl").
+
+The reference is single-device (main.py:96,120,143) and has no collective; the north star adds DP only.  Rows of a
+minibatch are independent through forward/backward (LayerNorm is per row; the losses are means over rows,
+ADER.py:93,120-121,136-137), so each rank takes a contiguous slice of the train rows AND of the exemplar rows, scales
+its local loss terms by the GLOBAL sub-batch sizes (1/B_train,global and lambda/B_ex,global) and the dense gradients are
+SUM-reduced; every rank then applies the identical Adam update.  Dropout counters are keyed by the global row index
+(Engine.row0) so the masks do not depend on the number of ranks.
+
+Exchange: the gradient lives in one flat buffer (ader_amd.engine.param_layout).  It is reduced in a few large buckets
+(xGMI rings are per-link bound: few, large collectives) -- the table rows [0, max_item] first, then the small block
+parameters.  `backend="gloo"` runs the same logic on CPU tensors for the world_size-2 tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend="nccl"):
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    return rank, world, local
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, near-equal split of n rows: rank r gets [lo, hi)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def bucket_ranges(total, table_elems, bucket_elems):
+    """[(lo, hi)] covering [0, total): the used table rows in large buckets, then everything after the table."""
+    out, lo = [], 0
+    while lo < table_elems:
+        hi = min(table_elems, lo + bucket_elems)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def allreduce_flat(grad, used_table_elems, table_span, bucket_elems=64 << 20, group=None):
+    """SUM-reduce grad[0:used_table_elems] (table rows that can be non-zero) and grad[table_span:] (all other
+    parameters) in place.  Rows above max_item are zero on every rank and are skipped."""
+    for lo, hi in bucket_ranges(grad.numel(), used_table_elems, bucket_elems):
+        dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, group=group)
+    if table_span < grad.numel():
+        dist.all_reduce(grad[table_span:], op=dist.ReduceOp.SUM, group=group)
+
+
+class DataParallel:
+    """Installs the gradient exchange into an Engine.  Usage per step:
+         dp.set_step(n_train_local_offset)  (row offset of this rank's first row in the global batch)
+         engine.train_step(seq_local, pos_local, max_item, lr, n_train_global=..., n_ex_global=..., ...)"""
+
+    def __init__(self, engine, rank=None, world=None, group=None):
+        r, w, _ = env_world()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.engine = engine
+        self.group = group
+        self.max_item = engine.item_num
+        if self.world > 1:
+            engine.grad_hook = self._exchange
+            # identical replicas: broadcast rank 0's state once
+            for t in (engine.theta, engine.adam_m, engine.adam_v):
+                dist.broadcast(t, src=0, group=group)
+
+    def set_rows(self, global_row0, max_item):
+        self.engine.row0 = int(global_row0)
+        self.max_item = int(max_item)
+
+    def _exchange(self, eng):
+        H = eng.H
+        table_span = eng.layout["pos"][0]
+        allreduce_flat(eng.grad, (self.max_item + 1) * H, table_span, group=self.group)

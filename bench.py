@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Benchmark of the ADER / SASRec training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM: embedding gather ->
+causal self-attention blocks -> full-catalog logits + softmax CE -> backward -> [RCCL gradient all-reduce] -> dense
+Adam (the `sess.run(train_op)` of reference main.py:233-256).  Workload = BASELINE.json configs[4]: synthetic 1M-item
+catalog, seq_len 50, batch 512 per GPU (weak scaling), dense regime (every position a real item, ids ~ U[1,N]),
+dropout 0.3, lr 5e-4, hidden 150, 2 blocks, 1 head (reference defaults main.py:98-107).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on
+the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+
+
+def synth_batch(B, T, N, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    seq = torch.randint(1, N + 1, (B, T), generator=g, dtype=torch.int32)
+    pos = torch.randint(1, N + 1, (B,), generator=g, dtype=torch.int32)
+    return seq.to(device), pos.to(device)
+
+
+def cpu_baseline(N, B, T, H, L, heads, rate, lr):
+    """Reference-equivalent CPU step (oracle/ader_ref_cpu.py: materialised [B,N] logits, one-hot CE, autograd, dense
+    TF-style Adam) timed on this host's cores.  Bounded sample: ONE full step of the same workload after a tiny warm-up
+    step (thread pool / allocator); if the host has little memory the row count is reduced and stated."""
+    import psutil
+    from oracle import ader_ref_cpu as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    avail = psutil.virtual_memory().available / 2 ** 30
+    Bs = B if avail > 48 else max(32, B // 4)
+    params = R.init_params(N, T, H, L, seed=0)
+    opt = R.TFAdam(params)
+    rs = np.random.RandomState(0)
+    seq = rs.randint(1, N + 1, size=(Bs, T)).astype(np.int64)
+    pos = rs.randint(1, N + 1, size=Bs).astype(np.int64)
+    R.train_step(params, opt, seq[:4], pos[:4], N, L, heads, lr, training=True, rate=rate, seed=0, step=0)   # warm-up (4 rows)
+    t0 = time.perf_counter()
+    R.train_step(params, opt, seq, pos, N, L, heads, lr, training=True, rate=rate, seed=0, step=1)
+    dt = time.perf_counter() - t0
+    return {"value": Bs / dt, "unit": "sessions/s", "cores": cores, "kind": "port",
+            "sample": "1 step of B=%d rows x T=%d at the full N=%d catalog (%.1f s), torch-CPU float32 restatement, %d threads"
+                      % (Bs, T, N, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    from ader_amd import dist as adist
+    from ader_amd.engine import Engine, SectionTimer
+    import torch.distributed as dist
+
+    rank, world, local = adist.init("nccl")
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, 0.3, 5e-4
+    eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev)
+    dp = adist.DataParallel(eng, rank, world)
+    dp.set_rows(rank * B, N)
+    nbatch = 4
+    batches = [synth_batch(B, T, N, 1000 * s + rank, dev) for s in range(nbatch)]   # resident in HBM before timing
+    kw = dict(rate=rate, n_train_global=B * world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        seq, pos = batches[i % nbatch]
+        eng.train_step(seq, pos, N, lr, **kw)
+    eng.check_status()
+    if not args.no_sections:
+        eng.timer = SectionTimer()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        seq, pos = batches[i % nbatch]
+        eng.train_step(seq, pos, N, lr, **kw)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(eng.loss.item())
+    sections = eng.timer.collect() if eng.timer is not None else {}
+    eng.timer = None
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        P = eng.P
+        work = {  # algorithmic work per launch (DESIGN.md "roofline accounting")
+            "logits_fwd": ("mfma", 2.0 * B * N * H),
+            "logits_bwd_drep": ("mfma", 2.0 * B * N * H),
+            "logits_bwd_demb": ("mfma", 2.0 * B * N * H),
+            "blocks_fwd": ("mfma", L * 2.0 * B * T * (5 * H * H + 2 * T * H)),
+            "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H)),
+            "adam": ("hbm", 7.0 * P * 4),
+            "grad_exchange": ("hbm", 0.0),
+        }
+        roof = None
+        if sections:
+            dom = max((k for k in sections if k != "grad_exchange"), key=lambda k: sections[k])
+            bound, amount = work[dom]
+            sec = sections[dom] * 1e-3
+            if bound == "mfma":
+                ach, peak, unit = amount / sec / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = amount / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+            roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                    "traffic": None, "ms": sections[dom],
+                    "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(N, B, T, H, L, heads, rate, lr)
+            except Exception as e:  # report, never fake
+                cpu = {"value": None, "unit": "sessions/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        out = {
+            "metric": "train sessions/sec at batch=512 seq=50", "value": B * world * args.steps / dt, "unit": "sessions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, dense regime (BASELINE.json configs[4])",
+                       "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
+                       "dropout": rate, "optimizer": "dense TF-Adam", "parallelism": "dp%d" % world, "final_loss": loss},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

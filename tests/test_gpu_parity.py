@@ -124,7 +124,7 @@ def test_loss_and_gradients_match_oracle(cfg, mode):
     worst = {}
     for k in eng.layout:
         g = eng.gradient(k).cpu().numpy()
-        e = nerr(g, og[k].numpy())
+        e = nerr(g, og[k].numpy(), floor=1e-4)
         worst[k] = e
         assert e < 3e-4, (k, e)       # float32 kernels (incl. float atomics in the table scatter) vs float64 oracle
     assert np.all(eng.gradient("emb")[0].cpu().numpy() == 0)        # row 0 never receives gradient (modules.py:124-126)
