@@ -32,6 +32,9 @@ _SIGS = {
     "ader_logits_loss_fwd": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P, P],
     "ader_logits_bwd_drep": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P],
     "ader_logits_bwd_demb": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P],
+    "ader_lbf_ranges": [I, I],
+    "ader_lbf_fwd": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_lbf_bwd_demb": [P, P, I, I, I, I, P, P, P, P, P],
     "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
     "ader_rank_targets": [P, P, I, I, I, I, P, P, P, P, P],
     "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P],
@@ -39,7 +42,7 @@ _SIGS = {
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges"}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges"}
 
 
 class AderHipError(RuntimeError):

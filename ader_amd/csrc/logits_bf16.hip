@@ -1,0 +1,455 @@
+// Full-catalog logits + softmax cross-entropy, bf16-MFMA path (fp32 master table, fp32 accumulation and softmax).
+// Reference: ADER.py:88-93 (logits = rep . item_emb^T, one-hot softmax CE) and its gradient.  One-hot rows only
+// (vanilla loss / disable_distillation); distilled rows use the float32 path of logits.hip.
+//
+// Two streaming passes over the table instead of the TF graph's materialised [B,N] logits/softmax/one-hot:
+//
+//   k_lbf_fwd  "flash" forward: workgroup = (128 batch rows) x (item range).  Per 32-item block
+//              S^T = E.rep^T on v_mfma_f32_32x32x16_bf16 (items on the MFMA rows, batch rows on the lanes, so the
+//              softmax statistics are lane-local), online max/sum-exp, and the probabilities go straight back into
+//              the matrix core as the A operand of  O[b,:] += P^T . E  (no LDS round trip: the accumulator layout
+//              is the operand layout; the table block is read k-major with ds_read_b64_tr_b16).
+//              O/l is the softmax-weighted mean of item embeddings = d loss / d rep up to the target term, so the
+//              backward pass needs no second recompute for dRep.
+//   k_lbf_combine  merges the per-range partials: lse, loss, dRep, and the per-row exponent offset for the backward.
+//   k_lbf_bwd_de   dE tile = dlogit^T . rep per 128-item workgroup: S = rep.E^T recomputed (batch rows on the MFMA
+//              rows), p = exp2(S*log2e + off_b) packed to bf16 in registers and fed back as the A operand of
+//              dE[item,:] += P^T . rep with rep read k-major by ds_read_b64_tr_b16.  Each dE row is written once.
+//   k_lbf_target_fix  the sparse one-hot term: dE[label_b] -= w_b * rep_b.
+//
+// LDS tiles are row-major bf16 with a 168-element (336 B) row stride: ds_read_b128 operand reads are conflict-free
+// (20 r mod 64 covers 16 distinct 4-bank slots).  gfx950 only.
+#include "common.h"
+#include "../../include/ader_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define HP 160
+#define LDR 168                 // bf16 elements per LDS / rep_bf row
+#define LOG2E 1.4426950408889634f
+#define RESCALE_THR 6.0f        // lazy online-softmax rescale threshold (log2 units): p <= 2^6
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// accumulator row of register `reg` for lane half hh (C/D layout of the 32x32 MFMA)
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// 4(k) x 16(n) transposed LDS read: lane (q = (lane&15)>>2, p = lane&3) supplies the address of row k0+q, cols n0+4p..;
+// lane i of the 16-lane group receives column n0+i of rows k0..k0+3.
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
+    return o;
+}
+
+// rep fp32 [B,H] -> rep_bf [Bp, LDR] bf16, zero padded (rows >= B, cols >= H)
+__global__ __launch_bounds__(256) void k_lbf_prep(const float* __restrict__ rep, bf16* __restrict__ rep_bf, int B, int Bp, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * LDR) return;
+    const int b = i / LDR, c = i - b * LDR;
+    rep_bf[i] = (bf16)((b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f);
+}
+
+struct LbfArgs {
+    const float* emb1;          // table row of item 1 (fp32)
+    const bf16* rep_bf;         // [Bp][LDR]
+    int B, Bp, H, N, ranges;
+    float* pm; float* pl; float* pO;    // [ranges][Bp], [ranges][Bp], [ranges][Bp][HP]
+    const float* off;           // [Bp] log2(w_b) - lse2_b
+    float* demb1;               // gradient row of item 1
+};
+
+#define PF 10   // float2 prefetch registers per thread for a 32-item block (32*H/2/256 <= 10 for H <= 160)
+#define FB 32   // items per streamed block
+
+__global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* E_l = (bf16*)smem_raw;                       // [2][FB][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nchunk = a.Bp >> 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot / nchunk), bc = slot % nchunk;
+    if (range >= a.ranges) return;
+    const int H = a.H, HH = H >> 1, N = a.N;
+    const int nblk = (N + FB - 1) / FB;
+    const int per = (nblk + a.ranges - 1) / a.ranges;
+    const int blk_begin = range * per, blk_end = min(nblk, blk_begin + per);
+    const int b0 = bc * 128 + wave * 32;
+    for (int i = tid; i < 2 * FB * LDR / 2; i += 256) ((uint32_t*)E_l)[i] = 0u;
+    bf16x8 bfrag[10];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) bfrag[ks] = *(const bf16x8*)(a.rep_bf + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
+    f32x16 O[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    float2 pf[PF];
+    // float2 #idx = tid + 256 j of a block <-> (item = idx / HH, pair = idx % HH), walked incrementally
+    const int it_first = tid / HH, c2_first = tid - it_first * HH;
+    const int it_step = 256 / HH, c2_step = 256 - it_step * HH;
+#define LBF_PREFETCH(blk_)                                                                               \
+    {                                                                                                    \
+        const int i0_ = (blk_) * FB;                                                                     \
+        int it_ = it_first, c2_ = c2_first;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PF; ++j) {                                                 \
+            float2 v = make_float2(0.f, 0.f);                                                            \
+            if (it_ < FB && i0_ + it_ < N) v = *(const float2*)(a.emb1 + (size_t)(i0_ + it_) * H + 2 * c2_); \
+            pf[j] = v;                                                                                   \
+            it_ += it_step; c2_ += c2_step;                                                              \
+            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        }                                                                                                \
+    }
+#define LBF_STAGE(buf_)                                                                                  \
+    {                                                                                                    \
+        bf16* dst_ = E_l + (buf_) * FB * LDR;                                                            \
+        int it_ = it_first, c2_ = c2_first;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PF; ++j) {                                                 \
+            if (it_ < FB) {                                                                              \
+                bf16x2 v; v[0] = (bf16)pf[j].x; v[1] = (bf16)pf[j].y;                                    \
+                *(bf16x2*)(dst_ + it_ * LDR + 2 * c2_) = v;                                              \
+            }                                                                                            \
+            it_ += it_step; c2_ += c2_step;                                                              \
+            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        }                                                                                                \
+    }
+    __syncthreads();
+    if (blk_begin < blk_end) { LBF_PREFETCH(blk_begin); LBF_STAGE(0); }
+    __syncthreads();
+    int cur = 0;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    for (int blk = blk_begin; blk < blk_end; ++blk) {
+        const bool more = blk + 1 < blk_end;
+        if (more) LBF_PREFETCH(blk + 1);
+        const bf16* Eb = E_l + cur * FB * LDR;
+        {
+            const int i0 = blk * FB;
+            f32x16 S;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) S[j] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) {
+                const bf16x8 af = *(const bf16x8*)(Eb + r * LDR + 16 * ks + 8 * hh);
+                S = mfma_bf16(af, bfrag[ks], S);
+            }
+            if (i0 + FB > N) {                          // tail block: items >= N are outside the softmax
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if (i0 + acc_row(j, hh) >= N) S[j] = -INFINITY;
+            }
+            float tmax = S[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, S[j]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float t2 = tmax * LOG2E;
+            if (__any(t2 > m_run + RESCALE_THR)) {
+                const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;
+                const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float ar = __shfl(alpha, acc_row(j, hh), 64);     // O rows are batch rows
+#pragma unroll
+                    for (int nb = 0; nb < 5; ++nb) O[nb][j] *= ar;
+                }
+            }
+            const float nm = -m_run;
+            float ls = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { S[j] = __builtin_amdgcn_exp2f(fmaf(S[j], LOG2E, nm)); ls += S[j]; }
+            l_run += ls;
+            const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const bf16* base = Eb + (4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
+                const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
+                const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
+                bf16x8 b0v, b1v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
+                O[nb] = mfma_bf16(pa0, b0v, O[nb]);
+                O[nb] = mfma_bf16(pa1, b1v, O[nb]);
+            }
+        }
+        if (more) LBF_STAGE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (hh == 0) {
+        a.pm[(size_t)range * a.Bp + b0 + r] = m_run;
+        a.pl[(size_t)range * a.Bp + b0 + r] = l_tot;
+    }
+    float* o = a.pO + ((size_t)range * a.Bp + b0) * HP;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r] = O[nb][j];
+}
+
+// One workgroup per batch row: merge range partials -> lse (natural log), loss row, dRep row, backward offset.
+__global__ __launch_bounds__(256) void k_lbf_combine(LbfArgs a, const int* __restrict__ lab, const float* __restrict__ wrow,
+                                                     float* __restrict__ lse, float* __restrict__ off, float* __restrict__ rowloss,
+                                                     float* __restrict__ drep) {
+    __shared__ float red[256];
+    __shared__ float sM, sL;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = a.ranges, H = a.H;
+    if (b >= a.B) {                                  // padding rows: no loss, no gradient
+        if (tid == 0) { lse[b] = 0.0f; rowloss[b] = 0.0f; off[b] = -INFINITY; }
+        return;
+    }
+    float m = -INFINITY;
+    for (int i = tid; i < R; i += 256) m = fmaxf(m, a.pm[(size_t)i * a.Bp + b]);
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    if (tid == 0) sM = red[0];
+    __syncthreads();
+    const float M = sM;
+    float l = 0.0f;
+    for (int i = tid; i < R; i += 256) {
+        const float pm = a.pm[(size_t)i * a.Bp + b];
+        if (pm != -INFINITY) l += a.pl[(size_t)i * a.Bp + b] * __builtin_amdgcn_exp2f(pm - M);
+    }
+    red[tid] = l;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    if (tid == 0) sL = red[0];
+    __syncthreads();
+    const float L = sL;
+    const float lse2 = M + log2f(L);
+    const int t = lab[b] - 1;
+    const float w = wrow[b];
+    // target logit with the same bf16-rounded operands as the MFMA path
+    float part = 0.0f;
+    float et = 0.0f, oh = 0.0f;
+    if (tid < H) {
+        if (t >= 0) {
+            et = (float)(bf16)a.emb1[(size_t)t * H + tid];
+            part = (float)a.rep_bf[(size_t)b * LDR + tid] * et;
+        }
+        for (int i = 0; i < R; ++i) {
+            const float pm = a.pm[(size_t)i * a.Bp + b];
+            if (pm != -INFINITY) oh += a.pO[((size_t)i * a.Bp + b) * HP + tid] * __builtin_amdgcn_exp2f(pm - M);
+        }
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float s_lab = red[0];
+    if (tid < H) drep[(size_t)b * H + tid] = w * (oh / L - et);
+    if (tid == 0) {
+        const float z = lse2 / LOG2E;
+        lse[b] = z;
+        rowloss[b] = (t >= 0) ? w * (z - s_lab) : 0.0f;
+        off[b] = (w > 0.0f) ? log2f(w) - lse2 : -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// dE tile (128 items per workgroup, 32 per wave); loops over all batch rows in chunks of 64 staged through LDS.
+__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]
+    float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int H = a.H, N = a.N;
+    const int it0 = blockIdx.x * 128 + wave * 32;
+    // table fragments of this wave's 32 items: lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
+    bf16x8 efrag[10];
+    {
+        const int it = it0 + r;
+        const float* row = a.emb1 + (size_t)it * H;
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) {
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const int k = 16 * ks + 8 * hh + 2 * j2;
+                float2 v = make_float2(0.f, 0.f);
+                if (it < N && k < H) v = *(const float2*)(row + k);
+                efrag[ks][2 * j2] = (bf16)v.x;
+                efrag[ks][2 * j2 + 1] = (bf16)v.y;
+            }
+        }
+    }
+    for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+    f32x16 dE[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dE[nb][j] = 0.0f;
+    const int nch = a.Bp >> 6;
+    const int n16 = 64 * LDR * 2 / 16;                  // 16-byte pieces per 64-row chunk (1344)
+    uint4 pf[6];
+#define LBF_RPREFETCH(c_)                                                                               \
+    {                                                                                                   \
+        const uint4* src_ = (const uint4*)(a.rep_bf + (size_t)(c_) * 64 * LDR);                          \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                 \
+            const int idx = tid + 256 * j;                                                              \
+            pf[j] = (idx < n16) ? src_[idx] : make_uint4(0u, 0u, 0u, 0u);                               \
+        }                                                                                               \
+    }
+#define LBF_RSTAGE(buf_)                                                                                \
+    {                                                                                                   \
+        uint4* dst_ = (uint4*)(R_l + (buf_) * 64 * LDR);                                                 \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                 \
+            const int idx = tid + 256 * j;                                                              \
+            if (idx < n16) dst_[idx] = pf[j];                                                           \
+        }                                                                                               \
+    }
+    LBF_RPREFETCH(0); LBF_RSTAGE(0);
+    __syncthreads();
+    int cur = 0;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        if (more) LBF_RPREFETCH(c + 1);
+        const bf16* Rb = R_l + cur * 64 * LDR;
+#pragma unroll 1
+        for (int bb = 0; bb < 2; ++bb) {
+            const int b0 = c * 64 + bb * 32;
+            f32x16 S;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) S[j] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) {
+                const bf16x8 af = *(const bf16x8*)(Rb + (bb * 32 + r) * LDR + 16 * ks + 8 * hh);
+                S = mfma_bf16(af, efrag[ks], S);
+            }
+            // rows of S are batch rows: p = w_b * softmax = exp2(S*log2e + off_b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o4 = *(const float4*)(off_l + b0 + 8 * g + 4 * hh);
+                S[4 * g + 0] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 0], LOG2E, o4.x));
+                S[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 1], LOG2E, o4.y));
+                S[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 2], LOG2E, o4.z));
+                S[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 3], LOG2E, o4.w));
+            }
+            const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const bf16* base = Rb + (bb * 32 + 4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
+                const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
+                const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
+                bf16x8 b0v, b1v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
+                dE[nb] = mfma_bf16(pa0, b0v, dE[nb]);
+                dE[nb] = mfma_bf16(pa1, b1v, dE[nb]);
+            }
+        }
+        if (more) LBF_RSTAGE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // dE acc: rows = items, col = hidden channel
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb) {
+        const int h = 32 * nb + r;
+        if (h >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int it = it0 + acc_row(j, hh);
+            if (it < N) a.demb1[(size_t)it * H + h] = dE[nb][j];
+        }
+    }
+}
+
+// sparse one-hot term of dlogit: dE[label_b,:] -= w_b * rep_b  (one wave per batch row, float atomics)
+__global__ __launch_bounds__(256) void k_lbf_target_fix(const bf16* __restrict__ rep_bf, const int* __restrict__ lab,
+                                                        const float* __restrict__ wrow, float* __restrict__ demb1, int B, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int t = lab[b] - 1;
+    if (t < 0) return;
+    const float w = wrow[b];
+    for (int c = lane; c < H; c += 64) atomicAdd(demb1 + (size_t)t * H + c, -w * (float)rep_bf[(size_t)b * LDR + c]);
+}
+
+// ============================================================================================= C ABI
+static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
+static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float); }
+
+extern "C" {
+
+int ader_lbf_ranges(int N, int Bp) {
+    const int nblk = (N + FB - 1) / FB;
+    const int nchunk = Bp / 128;
+    int target = 512 / (nchunk < 1 ? 1 : nchunk);
+    int r = 8;
+    while (r * 2 <= target && r * 2 <= nblk) r *= 2;
+    return r;
+}
+
+// Forward of the one-hot softmax CE over items 1..N with bf16 MFMA.  Bp % 128 == 0, H even, H <= 160.
+// Scratch: rep_bf Bp*168 bf16; pm, pl: ranges*Bp floats; pO: ranges*Bp*160 floats (ranges = ader_lbf_ranges(N,Bp)).
+// Outputs: lse [Bp] (natural log), off [Bp] (backward exponent offsets), rowloss [Bp], loss [1], drep [B,H].
+int ader_lbf_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const float* wrow, void* rep_bf,
+                 float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+    if (B <= 0) return 0;
+    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2) return -2;
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LbfArgs a;
+    a.emb1 = emb + H; a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = ader_lbf_ranges(N, Bp);
+    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
+    hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
+    hipLaunchKernelGGL(k_lbf_combine, dim3(Bp), dim3(256), 0, st, a, lab, wrow, lse, off, rowloss, drep);
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Table gradient rows 1..N (overwritten), including the sparse one-hot term.
+int ader_lbf_bwd_demb(const void* rep_bf, const float* emb, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                      const float* off, float* demb, void* stream) {
+    if (B <= 0) return 0;
+    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2) return -2;
+    static bool f = false;
+    static int lds_set = 0;
+    const size_t lds = bwd_lds(Bp);
+    if (!f || (int)lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        f = true; lds_set = (int)lds;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LbfArgs a;
+    a.emb1 = emb + H; a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
+    a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = demb + H;
+    hipLaunchKernelGGL(k_lbf_bwd_de, dim3((N + 127) / 128), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_lbf_target_fix, dim3((B + 3) / 4), dim3(256), 0, st, (const bf16*)rep_bf, lab, wrow, demb + H, B, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -133,7 +133,8 @@ def param_layout(item_num, T, H, L, align=64):
 class Engine:
     MAX_ROWS = 1024   # padded batch rows per launch (logits kernels keep per-row state in LDS)
 
-    def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0"):
+    def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0",
+                 logits_dtype="f32"):
         if not torch.cuda.is_available():
             raise _lib.AderHipError("ader_amd.Engine needs an MI355X (no CPU fallback)")
         _lib.load()
@@ -141,6 +142,10 @@ class Engine:
         self.item_num, self.T, self.H, self.L, self.heads = item_num, maxlen, hidden_units, num_blocks, num_heads
         self.V = item_num + 1
         self.seed = seed
+        assert logits_dtype in ("f32", "bf16")
+        # "bf16": logits GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 master table, fp32 accumulate + softmax) for one-hot
+        # rows; distilled rows always take the float32 kernels
+        self.logits_dtype = logits_dtype
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.layout, self.P = param_layout(item_num, maxlen, hidden_units, num_blocks)
@@ -344,26 +349,43 @@ class Engine:
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         A = self._act
-        Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
-                               N, Np, w_train, w_ex, teacher)
-        emb = self.param("emb")
-        parts = call("ader_logits_parts", N)
-        part = self.buf("lg_part", (parts * Bp * 3,))
-        lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
-        with self._sec("logits_fwd"):
-            call("ader_logits_loss_fwd", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(part), ptr(lse), ptr(rowloss), ptr(self.loss), st)
-        # ---- backward
+        use_bf16 = self.logits_dtype == "bf16" and teacher is None and H % 2 == 0
+        emb = self._pp["emb"]
         demb = self.gradient("emb")
         if N < self._grad_hi:   # catalog shrank (never in the reference flow): clear stale rows
             demb[N + 1:self._grad_hi + 1].zero_()
         self._grad_hi = max(self._grad_hi, N)
-        ranges = call("ader_logits_ranges", N, Bp)
-        slab = self.buf("lg_slab", (ranges * Bp * 160,))
         drep = self.buf("drep", (B, H))
-        with self._sec("logits_bwd_drep"):
-            call("ader_logits_bwd_drep", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), st)
-        with self._sec("logits_bwd_demb"):
-            call("ader_logits_bwd_demb", ptr(rep), ptr(emb), B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
+        if use_bf16:
+            Bp = (B + 127) // 128 * 128
+            lab, ncol = self.buf("ri_lab", (Bp,), torch.int32), self.buf("ri_ncol", (Bp,), torch.int32)
+            wrow, trow = self.buf("ri_w", (Bp,)), self.buf("ri_trow", (Bp,), torch.int32)
+            call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos), None, n_ex, N, 0, float(w_train), float(w_ex), Bp,
+                 ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
+            R = call("ader_lbf_ranges", N, Bp)
+            rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
+            pm, pl = self.buf("lbf_pm", (R * Bp,)), self.buf("lbf_pl", (R * Bp,))
+            pO = self.buf("lbf_pO", (R * Bp * 160,))
+            lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
+            with self._sec("logits_fwd"):
+                call("ader_lbf_fwd", ptr(rep), emb, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO),
+                     ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
+            with self._sec("logits_bwd_demb"):
+                call("ader_lbf_bwd_demb", ptr(rep_bf), emb, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(off), ptr(demb), st)
+        else:
+            Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
+                                   N, Np, w_train, w_ex, teacher)
+            parts = call("ader_logits_parts", N)
+            part = self.buf("lg_part", (parts * Bp * 3,))
+            lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
+            with self._sec("logits_fwd"):
+                call("ader_logits_loss_fwd", ptr(rep), emb, B, Bp, H, N, *ri, ptr(part), ptr(lse), ptr(rowloss), ptr(self.loss), st)
+            ranges = call("ader_logits_ranges", N, Bp)
+            slab = self.buf("lg_slab", (ranges * Bp * 160,))
+            with self._sec("logits_bwd_drep"):
+                call("ader_logits_bwd_drep", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), st)
+            with self._sec("logits_bwd_demb"):
+                call("ader_logits_bwd_demb", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
         tb = self._sec("blocks_bwd")
         tb.__enter__()
         wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))

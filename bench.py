@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--logits", choices=["bf16", "f32"], default="bf16",
+                    help="operand type of the logit GEMMs (fp32 master table, fp32 accumulate/softmax either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -83,7 +85,7 @@ def main():
     torch.cuda.set_device(dev)
 
     N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, 0.3, 5e-4
-    eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev)
+    eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits)
     dp = adist.DataParallel(eng, rank, world)
     dp.set_rows(rank * B, N)
     nbatch = 4
@@ -119,24 +121,28 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         P = eng.P
-        work = {  # algorithmic work per launch (DESIGN.md "roofline accounting")
-            "logits_fwd": ("mfma", 2.0 * B * N * H),
-            "logits_bwd_drep": ("mfma", 2.0 * B * N * H),
-            "logits_bwd_demb": ("mfma", 2.0 * B * N * H),
-            "blocks_fwd": ("mfma", L * 2.0 * B * T * (5 * H * H + 2 * T * H)),
-            "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H)),
-            "adam": ("hbm", 7.0 * P * 4),
-            "grad_exchange": ("hbm", 0.0),
+        lpeak = BF16_MFMA_PEAK_TFLOPS if args.logits == "bf16" else F32_MFMA_PEAK_TFLOPS
+        # algorithmic work per launch (DESIGN.md "roofline accounting").  In bf16 mode the forward launch also
+        # produces dRep (flash-style readout), so it is credited both GEMMs; recomputation is never credited.
+        fwd_flops = 2.0 * B * N * H * (2 if args.logits == "bf16" else 1)
+        work = {
+            "logits_fwd": ("mfma", fwd_flops, lpeak),
+            "logits_bwd_drep": ("mfma", 2.0 * B * N * H, lpeak),
+            "logits_bwd_demb": ("mfma", 2.0 * B * N * H, lpeak),
+            "blocks_fwd": ("mfma", L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
+            "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
+            "adam": ("hbm", 7.0 * P * 4, HBM_PEAK_GBS),
+            "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
         }
         roof = None
         if sections:
             dom = max((k for k in sections if k != "grad_exchange"), key=lambda k: sections[k])
-            bound, amount = work[dom]
+            bound, amount, peak = work[dom]
             sec = sections[dom] * 1e-3
             if bound == "mfma":
-                ach, peak, unit = amount / sec / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+                ach, unit = amount / sec / 1e12, "TFLOP/s"
             else:
-                ach, peak, unit = amount / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+                ach, unit = amount / sec / 1e9, "GB/s"
             roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                     "traffic": None, "ms": sections[dom],
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
@@ -149,10 +155,13 @@ def main():
         out = {
             "metric": "train sessions/sec at batch=512 seq=50", "value": B * world * args.steps / dt, "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.logits == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, dense regime (BASELINE.json configs[4])",
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
-                       "dropout": rate, "optimizer": "dense TF-Adam", "parallelism": "dp%d" % world, "final_loss": loss},
+                       "dropout": rate, "optimizer": "dense TF-Adam",
+                       "precision": ("logit GEMMs bf16 operands / fp32 accumulate+softmax; blocks, optimizer, master weights fp32"
+                                     if args.logits == "bf16" else "fp32 throughout"), "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

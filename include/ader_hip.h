@@ -92,6 +92,17 @@ int ader_logits_store(const float* rep, const float* emb, int B, int Bp, int H, 
 int ader_rank_targets(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* target, const int* ncol,
                       float* tlogit, int* rank, void* stream);
 
+/* ---- bf16-MFMA variant of the one-hot softmax CE (fp32 master table, fp32 accumulate/softmax): ADER.py:88-93 ------ */
+/* Bp % 128 == 0, H even.  Scratch: rep_bf Bp*168 bf16; pm, pl: R*Bp floats; pO: R*Bp*160 floats, R = ader_lbf_ranges(N,Bp).
+ * Outputs: lse/off/rowloss [Bp], loss [1], drep [B,H] (complete: includes the one-hot target term). */
+int ader_lbf_ranges(int N, int Bp);
+int ader_lbf_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                 void* rep_bf, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
+                 float* drep, void* stream);
+/* demb rows 1..N overwritten (each row written once, then the sparse one-hot term is added with float atomics) */
+int ader_lbf_bwd_demb(const void* rep_bf, const float* emb, int B, int Bp, int H, int N, const int* lab,
+                      const float* wrow, const float* off, float* demb, void* stream);
+
 /* ---- optimiser: tf.train.AdamOptimizer (ADER.py:96), dense over one flat buffer ------------------------ */
 int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,
                    void* stream);

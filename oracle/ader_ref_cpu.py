@@ -177,20 +177,27 @@ def forward_rep(params, seq, L, num_heads, *, training=False, rate=0.0, seed=0, 
     return rep
 
 
-def logits_from_rep(params, rep, max_item):
+def _bf16_ste(x):
+    """Round to bfloat16 with a straight-through gradient (models the bf16-MFMA logits mode of the HIP path)."""
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+def logits_from_rep(params, rep, max_item, logits_bf16=False):
     item_emb = params["emb"][1:max_item + 1]                                 # ADER.py:91 (unscaled table)
+    if logits_bf16:
+        return _bf16_ste(rep) @ _bf16_ste(item_emb).t()
     return rep @ item_emb.t()                                                # ADER.py:92
 
 
 def loss_fn(params, seq, pos, max_item, L, num_heads, *, ex_logits=None, ex_pos=None, lambda_=0.0,
-            training=True, rate=0.0, seed=0, step=0, row0=0, n_train_global=None, n_ex_global=None):
+            training=True, rate=0.0, seed=0, step=0, row0=0, n_train_global=None, n_ex_global=None, logits_bf16=False):
     """Vanilla loss (ADER.py:93) or ADER loss (ADER.py:108-137).
 
     seq holds the train rows first, exemplar rows after (main.py:229); the split point is inferred
     from the exemplar feed (ADER.py:113-115).  n_*_global override the mean denominators for the
     data-parallel shards (each rank scales its local sums by the global counts)."""
     rep = forward_rep(params, seq, L, num_heads, training=training, rate=rate, seed=seed, step=step, row0=row0)
-    logits = logits_from_rep(params, rep, max_item)
+    logits = logits_from_rep(params, rep, max_item, logits_bf16)
     n_ex = 0 if (ex_logits is None and ex_pos is None) else (len(ex_logits) if ex_logits is not None else len(ex_pos))
     n_train = seq.shape[0] - n_ex
     pos = torch.as_tensor(pos).long()

@@ -17,9 +17,9 @@ from oracle import ader_ref_cpu as R  # noqa: E402
 from oracle import herding_ref  # noqa: E402
 
 
-def _engine(item_num, T, H, L, heads, seed=0):
+def _engine(item_num, T, H, L, heads, seed=0, **kw):
     from ader_amd.engine import Engine
-    eng = Engine(item_num, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=seed)
+    eng = Engine(item_num, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=seed, **kw)
     # non-trivial LN parameters / biases so masks and residual paths are exercised away from the init symmetry
     g = torch.Generator().manual_seed(seed + 11)
     for k in eng.layout:
@@ -129,6 +129,53 @@ def test_loss_and_gradients_match_oracle(cfg, mode):
         assert e < 3e-4, (k, e)       # float32 kernels (incl. float atomics in the table scatter) vs float64 oracle
     assert np.all(eng.gradient("emb")[0].cpu().numpy() == 0)        # row 0 never receives gradient (modules.py:124-126)
     assert np.all(eng.gradient("emb")[N + 1:].cpu().numpy() == 0)   # items beyond max_item are outside the softmax
+
+
+BF16_CFGS = [  # item_num, T, H, L, heads, B, N  (tail tiles, several ranges, B not a multiple of 128, empty ranges)
+    (700, 50, 150, 2, 1, 70, 650),
+    (5000, 50, 150, 1, 1, 300, 4321),
+    (300, 20, 64, 1, 2, 9, 300),
+]
+
+
+@pytest.mark.parametrize("cfg", BF16_CFGS)
+@pytest.mark.parametrize("mode", ["vanilla", "onehot_ex"])
+def test_bf16_logits_path_matches_bf16_aware_oracle(cfg, mode):
+    """bf16-MFMA logits mode.  Checked (a) tightly against the oracle evaluated with the same operand rounding
+    (rep and table rounded to bf16 inside the logits product, straight-through gradient): remaining differences are the
+    bf16 rounding of the probabilities fed to the second MFMA and summation order -> 3e-3 normalised; and
+    (b) loosely against the exact float64 oracle: 3e-2 normalised, loss within 5e-3 relative (bf16 operand rounding)."""
+    item_num, T, H, L, heads, B, N = cfg
+    eng = _engine(item_num, T, H, L, heads, seed=3, logits_dtype="bf16")
+    rs = np.random.RandomState(12)
+    seq = _seqs(rs, B, T, N)
+    n_ex = 0 if mode == "vanilla" else max(1, B // 4)
+    n_train = B - n_ex
+    pos = rs.randint(1, N + 1, size=n_train).astype(np.int32)
+    pos[0] = N                                    # a label in the tail tile
+    kw, okw = {}, {}
+    if mode == "onehot_ex":
+        ex_pos = rs.randint(1, N + 1, size=n_ex).astype(np.int32)
+        kw = dict(ex_pos=ex_pos, lambda_=0.6)
+        okw = dict(ex_pos=ex_pos, lambda_=0.6)
+    eng.global_step = 2
+    loss = eng.loss_and_grad(seq, pos, N, rate=0.3, **kw)
+    torch.cuda.synchronize()
+    eng.check_status()
+    p64 = _params(eng, torch.float64)
+    l_q, g_q = R.loss_and_grads(p64, seq, pos, N, L, heads, training=True, rate=0.3, seed=3, step=2, logits_bf16=True, **okw)
+    l_x, g_x = R.loss_and_grads(p64, seq, pos, N, L, heads, training=True, rate=0.3, seed=3, step=2, **okw)
+    got = float(loss.item())
+    assert abs(got - float(l_q)) < 3e-4 * max(1.0, abs(float(l_q)))
+    assert abs(got - float(l_x)) < 5e-3 * max(1.0, abs(float(l_x)))
+    for k in eng.layout:
+        g = eng.gradient(k).cpu().numpy()
+        eq = nerr(g, g_q[k].numpy(), floor=1e-4)
+        ex = nerr(g, g_x[k].numpy(), floor=1e-4)
+        assert eq < 3e-3, (k, "vs bf16-aware oracle", eq)
+        assert ex < 3e-2, (k, "vs exact oracle", ex)
+    assert np.all(eng.gradient("emb")[0].cpu().numpy() == 0)
+    assert np.all(eng.gradient("emb")[N + 1:].cpu().numpy() == 0)
 
 
 def test_adam_matches_tf_formula():
