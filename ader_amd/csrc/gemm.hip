@@ -147,7 +147,8 @@ static int launch_rows(const GemmArgs& g, hipStream_t st) {
         attr_set = true;
     }
     const int n_tiles = (g.M + TM - 1) / TM;
-    const int grid = n_tiles < 256 ? n_tiles : 256;
+    const int per = (n_tiles + 255) / 256;                 // tiles per workgroup, balanced over the 256 CUs
+    const int grid = (n_tiles + per - 1) / per;
     hipLaunchKernelGGL((k_gemm_rows<EPI, TB>), dim3(grid), dim3(512), kGemmRowsLds, st, g);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -178,7 +179,9 @@ int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, 
 
 int ader_gemm_atb_slabs(int M) {
     const int n_tiles = (M + TM - 1) / TM;
-    return n_tiles < 128 ? (n_tiles < 1 ? 1 : n_tiles) : 128;
+    if (n_tiles < 1) return 1;
+    const int per = (n_tiles + 255) / 256;                 // balanced over the 256 CUs
+    return (n_tiles + per - 1) / per;
 }
 
 // slab: ader_gemm_atb_slabs(M) * 160 * 160 floats of scratch.  dW [H,H] and db [H] (may be null) are overwritten.

@@ -78,13 +78,28 @@ __global__ __launch_bounds__(256) void k_embed_bwd_sorted(const int* __restrict_
     }
 }
 
-// dpos[t][c] = sum_b g[b*T + t][c]   (sequential over b: deterministic)
+// dpos[t][c] = sum_b g[b*T + t][c].  Each workgroup owns 32 consecutive (t,c) outputs; 8 b-slices accumulate
+// sequentially and are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ g, float* __restrict__ dpos, int B, int T, int H) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * H) return;
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    const int TH = T * H;
     float acc = 0.0f;
-    for (int b = 0; b < B; ++b) acc += g[(size_t)b * T * H + i];
-    dpos[i] = acc;
+    if (i < TH) {
+        const int per = (B + 7) / 8;
+        const int b0 = sl * per, b1 = min(B, b0 + per);
+#pragma unroll 4
+        for (int b = b0; b < b1; ++b) acc += g[(size_t)b * TH + i];
+    }
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < TH) {
+        float a = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) a += red[k][o];
+        dpos[i] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,20 +227,31 @@ __global__ __launch_bounds__(256) void k_mask_dropgrad(const float* __restrict__
     }
 }
 
-// dst[r][c] = sum_s src[s*slab_stride + r*ld + c]  (s ascending: deterministic).  Rows r < n_rows go to
-// dst, row n_rows (if dst_extra) goes to dst_extra -- the "ones row" of the weight-gradient GEMM = bias grad.
+// dst[r][c] = sum_s src[s*slab_stride + r*ld + c].  Rows r < n_rows go to dst, row n_rows (if dst_extra) goes to
+// dst_extra -- the "ones row" of the weight-gradient GEMM = bias gradient.  A workgroup owns 64 outputs; 4 thread
+// groups sum interleaved slab subsets (s = k mod 4, ascending) and are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ src, long slab_stride, int S, int ld,
                                                       int n_rows, int n_cols, float* __restrict__ dst,
                                                       float* __restrict__ dst_extra) {
+    __shared__ float red[4][64];
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int r = i / n_cols, c = i % n_cols;
-    const float* p = src + (size_t)r * ld + c;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
     float acc = 0.0f;
-    for (int s = 0; s < S; ++s) acc += p[(size_t)s * slab_stride];
-    if (r < n_rows) dst[(size_t)r * n_cols + c] = acc;
-    else dst_extra[c] = acc;
+    int r = 0, c = 0;
+    if (i < total) {
+        r = i / n_cols; c = i - r * n_cols;
+        const float* p = src + (size_t)r * ld + c;
+#pragma unroll 8
+        for (int s = sg; s < S; s += 4) acc += p[(size_t)s * slab_stride];
+    }
+    red[sg][o] = acc;
+    __syncthreads();
+    if (sg == 0 && i < total) {
+        const float a = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+        if (r < n_rows) dst[(size_t)r * n_cols + c] = a;
+        else dst_extra[c] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,7 +312,7 @@ int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, i
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
                        sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base));
-    hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
+    hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -313,7 +339,7 @@ int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const fl
     hipLaunchKernelGGL(k_ln_bwd, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, dy_rs, x, x_rs, gamma, mean_i, std_i, add, add_rs,
                        dx, dx_rs, slab, rows, H);
     // slab layout [G][2][H]: row 0 = dgamma partial, row 1 = dbeta partial
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
                        dgamma, dbeta);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -332,7 +358,7 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
                       void* stream) {
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
                        n_cols, dst, dst_extra);
     HIP_LAUNCH_CHECK();
     return 0;
