@@ -95,3 +95,27 @@ class ExemplarGenerator:
             self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
             p += c
         return int(len(keep))
+
+    def randomly_selection(self, sess, model):
+        """Random exemplars per label (util.py:497-522): np.random.choice without replacement, in group order."""
+        labels, offs, quota, rows = self._segments()
+        keep, counts = [], []
+        for g, label in enumerate(labels):
+            n = int(offs[g + 1] - offs[g])
+            m = int(self.item_count[label - 1])
+            c = 0
+            if m > 0:
+                ids = np.random.choice(n, min(m, n), replace=False)
+                keep.append(ids + offs[g])
+                c = len(ids)
+            counts.append(c)
+        keep = np.concatenate(keep) if keep else np.zeros(0, np.int64)
+        sel_rows = rows[keep]
+        logits = model.engine.teacher_logits(sel_rows[:, :self.maxlen], self.max_item)
+        self.store = ExemplarStore(sel_rows, logits, self.max_item)
+        p = 0
+        for label, c in zip(labels, counts):
+            if c:
+                self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
+            p += c
+        return int(len(keep))

@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Continual-learning driver with the reference's flags and log format (reference main.py:68-336), running the
+MI355X hot path.  `python -m ader_amd.main --dataset DIGINETICA [--finetune=True] ...`
+
+Differences from the reference that do not change results: booleans are parsed with str2bool (the reference's
+`type=bool` turns "--finetune=False" into True, main.py:83-91); `stop_counter` is initialised (main.py:272-273);
+batches and teacher logits stay on the GPU (the reference feeds Python float lists every step, util.py:254);
+the best-epoch checkpoint is kept in memory and written to disk only with --save_ckpt.
+Extra flags: --logits_dtype, --max_periods, --data_root, --device, --save_ckpt.
+"""
+import argparse
+import math
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from .data import DataLoader, Evaluator, Sampler, load_exemplars
+from .exemplar import ExemplarGenerator
+from .model import Ader, Saver, Session
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ('yes', 'true', 't', 'y', '1'):
+        return True
+    if v.lower() in ('no', 'false', 'f', 'n', '0'):
+        return False
+    raise argparse.ArgumentTypeError('Boolean value expected.')
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--dataset', default='DIGINETICA', type=str)
+    p.add_argument('--save_dir', default='ADER', type=str)
+    p.add_argument('--exemplar_size', default=30000, type=int)
+    p.add_argument('--lambda_', default=0.8, type=float)
+    p.add_argument('--finetune', default=False, type=str2bool)
+    p.add_argument('--dropout', default=False, type=str2bool)
+    p.add_argument('--joint', default=False, type=str2bool)
+    p.add_argument('--selection', default='herding', type=str)
+    p.add_argument('--disable_distillation', default=False, type=str2bool)
+    p.add_argument('--equal_exemplar', default=False, type=str2bool)
+    p.add_argument('--fix_lambda', default=False, type=str2bool)
+    p.add_argument('--num_epochs', default=100, type=int)
+    p.add_argument('--batch_size', default=256, type=int)
+    p.add_argument('--test_batch', default=64, type=int)
+    p.add_argument('--device_num', default=0, type=int)
+    p.add_argument('--lr', default=0.0005, type=float)
+    p.add_argument('--num_blocks', default=2, type=int)
+    p.add_argument('--num_heads', default=1, type=int)
+    p.add_argument('--stop', default=5, type=int)
+    p.add_argument('--random_seed', default=0, type=int)
+    p.add_argument('--hidden_units', default=150, type=int)
+    p.add_argument('--maxlen', default=50, type=int)
+    p.add_argument('--dropout_rate', default=0.3, type=float)
+    p.add_argument('--l2_emb', default=0.0, type=float)
+    # build-specific
+    p.add_argument('--logits_dtype', default='f32', choices=['f32', 'bf16'])
+    p.add_argument('--max_periods', default=0, type=int)
+    p.add_argument('--data_root', default=None, type=str)
+    p.add_argument('--results_root', default='results', type=str)
+    p.add_argument('--save_ckpt', default=False, type=str2bool)
+    p.add_argument('--eval_batch', default=1024, type=int, help="rows per evaluation launch (results do not depend on it)")
+    return p
+
+
+ITEM_NUM = {'DIGINETICA': 43136, 'YOOCHOOSE': 25958}     # main.py:133-138
+
+
+def run(args, log=print):
+    out_dir = os.path.join(args.results_root, args.dataset + '-' + args.save_dir)
+    os.makedirs(out_dir, exist_ok=True)
+    logs = open(os.path.join(out_dir, 'Training_logs.txt'), mode='w')
+    logs.write('\n'.join([str(k) + ',' + str(v) for k, v in sorted(vars(args).items(), key=lambda x: x[0])]))
+    np.random.seed(args.random_seed)
+    random.seed(args.random_seed)
+    torch.manual_seed(args.random_seed)
+    if args.dataset not in ITEM_NUM:
+        raise ValueError('Invalid dataset name')
+    item_num = ITEM_NUM[args.dataset]
+    args.dropout_rate = 0 if args.finetune else args.dropout_rate      # main.py:141
+    model = Ader(item_num, args, device="cuda:%d" % args.device_num)
+    baseline = args.finetune or args.dropout or args.joint
+    dataloader = DataLoader(args.dataset, root=args.data_root)
+    n_periods = dataloader.num_periods() - 1
+    periods = range(1, n_periods + 1)
+    if args.max_periods:
+        periods = range(1, min(n_periods, args.max_periods) + 1)
+    log('Continue Learning: number of periods is %d.' % len(periods))
+    logs.write('Continue Learning: number of periods is %d.\n' % len(periods))
+    item_num_prev = 0
+    t_start = time.time()
+    MRR_20, Recall_20, MRR_10, Recall_10 = [], [], [], []
+    best_state, store = None, None
+    fast_exemplar = {}
+    saver = Saver(model)
+    summary = []
+    for period in periods:
+        log('Period %d:' % period)
+        logs.write('Period %d:\n' % period)
+        best_performance, performance = 0, 0
+        train_sess, info = dataloader.train_loader(period - 1)
+        logs.write(info + '\n')
+        if args.joint and period > 1:
+            for p in range(1, period):
+                pre, info = dataloader.train_loader(p - 1)
+                logs.write(info + '\n')
+                train_sess.extend(pre)
+        train_sampler = Sampler(train_sess, args.maxlen, args.batch_size)
+        valid_subseq, train_subseq = train_sampler.split_data(valid_portion=0.1, return_train=True)
+        batch_num = train_sampler.batch_num()
+        test_sess, info = dataloader.evaluate_loader(period)
+        logs.write(info + '\n')
+        max_item = dataloader.max_item()
+        use_ex = period > 1 and not baseline
+        if use_ex:
+            exemplar_data_logits = load_exemplars(fast_exemplar)
+            exemplar_size = len(exemplar_data_logits)
+            exemplar_subseq = [e[0] for e in exemplar_data_logits]
+            exemplar_batch = int(exemplar_size / batch_num)             # main.py:187
+            exemplar_sampler = Sampler([], args.maxlen, exemplar_batch)
+            exemplar_sampler.add_exemplar(exemplar_data_logits)
+            if args.fix_lambda:
+                lambda_ = args.lambda_
+            else:                                                        # main.py:200
+                lambda_ = args.lambda_ * math.sqrt((item_num_prev / max_item) * (exemplar_size / train_sampler.data_size()))
+            model.update_loss(lambda_=lambda_)
+        else:
+            exemplar_subseq = []
+            model.set_vanilla_loss()
+        with Session(model) as sess:
+            if period > 1 and not args.joint:
+                model.engine.load_state_dict(best_state)                # saver.restore(prev best), main.py:211
+            else:
+                model.engine.init_params(args.random_seed)              # global_variables_initializer, main.py:213
+            best_epoch, stop_counter, period_best = 1, 0, None
+            for epoch in range(1, args.num_epochs + 1):
+                for _ in range(batch_num):
+                    seq, pos = train_sampler.next_batch()
+                    if use_ex:
+                        ex_seq, ex_pos, idx = exemplar_sampler.next_exemplar_batch()
+                        seq = np.concatenate([seq, ex_seq]) if len(ex_seq) else seq
+                        if args.disable_distillation:
+                            model.train_step(seq, pos, max_item, args.lr, args.dropout_rate, ex_pos=ex_pos)
+                        else:
+                            model.train_step(seq, pos, max_item, args.lr, args.dropout_rate, teacher=store.logits,
+                                             ex_trow=idx.astype(np.int32))
+                    else:
+                        model.train_step(seq, pos, max_item, args.lr, args.dropout_rate)
+                model.engine.check_status()
+                valid_evaluator = Evaluator(valid_subseq, True, args.maxlen, args.eval_batch, max_item, 'valid', model, sess)
+                info = valid_evaluator.evaluate(epoch)
+                logs.write(info + '\n')
+                performance = valid_evaluator.results()[1]
+                if best_performance >= performance:                      # early stop, main.py:271-280
+                    stop_counter += 1
+                    if stop_counter >= args.stop:
+                        break
+                else:
+                    stop_counter = 0
+                    best_epoch = epoch
+                    best_performance = performance
+                    period_best = best_state = model.engine.state_dict()
+                    if args.save_ckpt:
+                        d = os.path.join(out_dir, 'model', 'period%d' % period)
+                        os.makedirs(d, exist_ok=True)
+                        saver.save(sess, os.path.join(d, 'epoch=%d.ckpt' % epoch))
+            if period_best is None:                                      # no epoch improved on 0: keep the last state
+                best_state = model.engine.state_dict()
+            model.engine.load_state_dict(best_state)                    # saver.restore(best), main.py:283
+            test_evaluator = Evaluator(test_sess, False, args.maxlen, args.eval_batch, max_item, 'test', model, sess)
+            info = test_evaluator.evaluate(best_epoch)
+            logs.write(info + '\n')
+            r = test_evaluator.results()
+            MRR_20.append(r[0]); Recall_20.append(r[1]); MRR_10.append(r[2]); Recall_10.append(r[3])
+            summary.append({"period": period, "best_epoch": best_epoch, "mrr20": r[0], "recall20": r[1], "mrr10": r[2],
+                            "recall10": r[3], "max_item": max_item})
+            if not baseline:                                             # exemplar selection, main.py:294-313
+                exemplar_candidate = train_subseq
+                exemplar_candidate.extend(valid_subseq)
+                exemplar_candidate.extend(exemplar_subseq)
+                exemplar = ExemplarGenerator(exemplar_candidate, args.exemplar_size, args.equal_exemplar, args.batch_size,
+                                             args.maxlen, args.dropout_rate, max_item)
+                if args.selection == 'herding':
+                    saved_num = exemplar.herding_selection(sess, model)
+                elif args.selection == 'random':
+                    saved_num = exemplar.randomly_selection(sess, model)
+                else:
+                    raise ValueError("Invalid exemplar selection method (supported: herding, random)")
+                info = 'Total saved exemplar: %d' % saved_num
+                log(info)
+                logs.write(info + '\n')
+                fast_exemplar = exemplar.exemplars
+                store = exemplar.store
+                del exemplar
+            item_num_prev = max_item
+        logs.flush()
+    res = (np.array(MRR_20).mean(), np.array(Recall_20).mean(), np.array(MRR_10).mean(), np.array(Recall_10).mean())
+    info = 'Average: (MRR@20: %.4f, RECALL@20: %.4f, MRR@10: %.4f, RECALL@10: %.4f)' % res
+    log(info)
+    logs.write(info + '\n')
+    log('Total time: %.2f minutes.' % ((time.time() - t_start) / 60.0))
+    logs.write('Total time: %.2f minutes\nDone.' % ((time.time() - t_start) / 60.0))
+    logs.close()
+    log('Done.')
+    return {"average": dict(zip(("mrr20", "recall20", "mrr10", "recall10"), map(float, res))), "periods": summary}
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    return run(args)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,142 @@
+"""`Ader` with the reference's call surface (ADER.py:13-150) over the MI355X engine, plus `Session` / `Saver`
+shims so `main.py` / `util.py`-style code (``sess.run(model.train_op, feed_dict)``, ``model.predict(sess, ...)``,
+``saver.save/restore``) runs unchanged.
+
+The reference builds a TF1 graph once (main.py:143-144) and drives it with ``sess.run``.  Here the "graph handles"
+(`input_seq`, `pos`, `is_training`, `max_item`, `exemplar_logits`, `exemplar_pos`, `dropout_rate`, `lr`, `test_item`,
+`rep`, `logits`, `loss`, `train_op`, `pred_last`) are inert tokens; `Session.run` dispatches on the fetched token and
+reads the feeds by token.  Next to the shim are the fast paths that take device tensors and never leave the GPU:
+`train_step`, `encode`, `rank_targets`.
+"""
+import numpy as np
+import torch
+
+from .engine import Engine
+
+
+class _Handle:
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<ader handle %s>" % self.name
+
+
+class Ader:
+    def __init__(self, item_num, args, reuse=None, device="cuda:0", logits_dtype=None):
+        self.args = args
+        self.item_num = item_num
+        ld = logits_dtype or getattr(args, "logits_dtype", "f32")
+        self.engine = Engine(item_num, maxlen=args.maxlen, hidden_units=args.hidden_units, num_blocks=args.num_blocks,
+                             num_heads=args.num_heads, seed=args.random_seed, device=device, logits_dtype=ld)
+        for n in ("is_training", "input_seq", "pos", "exemplar_logits", "exemplar_pos", "max_item", "lr", "dropout_rate",
+                  "test_item", "rep", "logits", "loss", "train_op", "pred_last", "exemp_loss"):
+            setattr(self, n, _Handle(n))
+        self._loss_mode = "vanilla"
+        self._lambda = 0.0
+
+    # ---- loss selection (reference: re-issues optimizer.minimize on a different loss tensor, ADER.py:105-138)
+    def set_vanilla_loss(self):
+        self._loss_mode, self._lambda = "vanilla", 0.0
+
+    def update_loss(self, lambda_):
+        self._loss_mode = "onehot" if getattr(self.args, "disable_distillation", False) else "kd"
+        self._lambda = float(lambda_)
+
+    # ---- fast paths (device tensors / numpy in, no per-step host round trip)
+    def train_step(self, seq, pos, max_item, lr, dropout_rate, *, ex_pos=None, teacher=None, ex_trow=None, **kw):
+        """One optimisation step.  Exemplar rows (if any) are the last rows of `seq` (main.py:229)."""
+        e = self.engine
+        if self._loss_mode == "vanilla":
+            return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, **kw)
+        if self._loss_mode == "onehot":
+            return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, ex_pos=ex_pos, lambda_=self._lambda, **kw)
+        return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, teacher=teacher, ex_trow=ex_trow, lambda_=self._lambda, **kw)
+
+    def encode(self, seq):
+        return self.engine.encode(seq)
+
+    def rank_targets(self, seq, pos, max_item):
+        return self.engine.rank_targets(seq, pos, max_item)
+
+    def predict(self, sess, seq, item_idx):
+        """Rank of every candidate item (ADER.py:140-150).  Kept for API parity; the Evaluator uses rank_targets."""
+        return sess.run(self.pred_last, {self.input_seq: seq, self.test_item: item_idx, self.is_training: False,
+                                         self.dropout_rate: self.args.dropout_rate})
+
+
+class Session:
+    """Minimal `tf.Session` stand-in: context manager + run(fetches, feed_dict)."""
+
+    def __init__(self, model=None, config=None):
+        self.model = model
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    @staticmethod
+    def _model_of(fetches, feed):
+        raise RuntimeError("Session needs the model: construct Session(model)")
+
+    def run(self, fetches, feed_dict=None):
+        m = self.model or self._model_of(fetches, feed_dict)
+        feed = {k.name: v for k, v in (feed_dict or {}).items()}
+        single = not isinstance(fetches, (list, tuple))
+        names = [fetches.name] if single else [f.name for f in fetches]
+        e = m.engine
+        if names == ["train_op"]:
+            seq = np.asarray(feed["input_seq"], dtype=np.int32)
+            pos = np.asarray(feed["pos"], dtype=np.int32).reshape(-1)
+            kw = {}
+            if "exemplar_logits" in feed and m._loss_mode == "kd":
+                rows = feed["exemplar_logits"]
+                if len(rows) and isinstance(rows[0], torch.Tensor):
+                    kw["teacher"] = torch.stack([r.to(e.device) for r in rows]).float().contiguous()
+                else:
+                    kw["teacher"] = torch.as_tensor(np.asarray(rows, dtype=np.float32)).to(e.device)
+            elif "exemplar_pos" in feed and m._loss_mode == "onehot":
+                kw["ex_pos"] = np.asarray(feed["exemplar_pos"], dtype=np.int32).reshape(-1)
+            rate = float(feed.get("dropout_rate", 0.0)) if feed.get("is_training", True) else 0.0
+            m.train_step(seq, pos, int(feed["max_item"]), float(feed["lr"]), rate, **kw)
+            return None
+        seq = np.asarray(feed["input_seq"], dtype=np.int32)
+        out = []
+        rep = None
+        for n in names:
+            if n == "rep":
+                rep = e.encode(seq) if rep is None else rep
+                out.append(rep.cpu().numpy())
+            elif n == "logits":
+                rep = e.encode(seq) if rep is None else rep
+                out.append(e.logits_from_rep(rep, int(feed["max_item"])).cpu().numpy())
+            elif n == "pred_last":
+                items = np.asarray(feed["test_item"], dtype=np.int64)
+                N = int(items.max())
+                assert np.array_equal(items, np.arange(1, N + 1)), "predict() ranks the contiguous catalog 1..N (util.py:323)"
+                rep = e.encode(seq) if rep is None else rep
+                lg = e.logits_from_rep(rep, N)
+                order = torch.argsort(-lg, dim=-1, stable=True)           # ties -> lower index first
+                out.append(torch.argsort(order, dim=-1, stable=True).to(torch.int32).cpu().numpy())
+            else:
+                raise KeyError("unsupported fetch %r" % n)
+        return out[0] if single else out
+
+
+class Saver:
+    """`tf.train.Saver(max_to_keep=1)` stand-in: parameters + Adam slots + beta powers + global_step (main.py:209-213,
+    280, 283 save/restore ALL global variables, so optimiser state carries across periods)."""
+
+    def __init__(self, model=None, max_to_keep=1):
+        self.model = model
+
+    def save(self, sess, path):
+        torch.save((self.model or sess.model).engine.state_dict(), path)
+        return path
+
+    def restore(self, sess, path):
+        (self.model or sess.model).engine.load_state_dict(torch.load(path))
