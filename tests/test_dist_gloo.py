@@ -1,0 +1,112 @@
+"""Data-parallel path on CPU: world_size-2 gloo processes.  Each rank takes a contiguous slice of the train rows and of
+the exemplar rows, scales its loss terms by the GLOBAL sub-batch sizes, and the flat gradient buffer is SUM-reduced with
+ader_amd.dist.allreduce_flat; the result must equal the single-process full-batch gradient (ADER.py:120-121,136-137 are
+means over rows).  The oracle provides the local gradients here (no GPU in this container)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ader_amd import dist as adist
+from ader_amd.engine import param_layout
+from oracle import ader_ref_cpu as R
+
+ITEMS, T, H, L, HEADS, N, NP = 120, 12, 16, 2, 2, 100, 80
+N_TRAIN, N_EX, LAM = 11, 5, 0.7
+
+
+def _problem():
+    rs = np.random.RandomState(0)
+    params = R.init_params(ITEMS, T, H, L, seed=1, dtype=torch.float64)
+    g = torch.Generator().manual_seed(2)
+    for k in params:
+        if k.endswith("_b"):
+            params[k] = torch.randn(params[k].shape, generator=g, dtype=torch.float64) * 0.1
+    seq = np.zeros((N_TRAIN + N_EX, T), dtype=np.int64)
+    for b in range(len(seq)):
+        ln = rs.randint(1, T + 1)
+        seq[b, T - ln:] = rs.randint(1, N + 1, size=ln)
+    pos = rs.randint(1, N + 1, size=N_TRAIN)
+    teacher = torch.from_numpy(rs.standard_normal((N_EX, NP)))
+    return params, seq, pos, teacher
+
+
+def _flat(grads, layout, total):
+    buf = torch.zeros(total, dtype=torch.float64)
+    for k, (off, shp) in layout.items():
+        buf[off:off + grads[k].numel()] = grads[k].reshape(-1)
+    return buf
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params, seq, pos, teacher = _problem()
+    layout, total = param_layout(ITEMS, T, H, L)
+    lo, hi = adist.shard_bounds(N_TRAIN, world, rank)
+    elo, ehi = adist.shard_bounds(N_EX, world, rank)
+    local_seq = np.concatenate([seq[lo:hi], seq[N_TRAIN + elo:N_TRAIN + ehi]])
+    _, grads = R.loss_and_grads(params, local_seq, pos[lo:hi], N, L, HEADS, ex_logits=teacher[elo:ehi], lambda_=LAM,
+                                training=True, rate=0.0, n_train_global=N_TRAIN, n_ex_global=N_EX)
+    buf = _flat(grads, layout, total)
+    adist.allreduce_flat(buf, (N + 1) * H, layout["pos"][0], bucket_elems=257)    # several ragged buckets
+    if rank == 0:
+        torch.save(buf, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gradient_equals_full_batch():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "g.pt")
+        mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+        got = torch.load(out)
+    params, seq, pos, teacher = _problem()
+    layout, total = param_layout(ITEMS, T, H, L)
+    _, grads = R.loss_and_grads(params, seq, pos, N, L, HEADS, ex_logits=teacher, lambda_=LAM, training=True, rate=0.0)
+    ref = _flat(grads, layout, total)
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-12)
+    # rows above max_item are skipped by the exchange and must be zero anyway
+    emb_off = layout["emb"][0]
+    assert torch.all(got[emb_off + (N + 1) * H: layout["pos"][0]] == 0)
+
+
+def test_shard_bounds_and_buckets():
+    for n in (0, 1, 7, 512, 513):
+        for w in (1, 2, 3, 8):
+            spans = [adist.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    r = adist.bucket_ranges(10_000, 1000, 300)
+    assert r == [(0, 300), (300, 600), (600, 900), (900, 1000)]
+
+
+def test_dropout_counter_is_keyed_by_global_row():
+    """A shard that starts at global row r0 draws the masks of rows r0.. of the full batch (Engine.row0 / oracle row0)."""
+    params, seq, pos, teacher = _problem()
+    p32 = {k: v.float() for k, v in params.items()}
+    full = R.forward_rep(p32, seq, L, HEADS, training=True, rate=0.4, seed=5, step=3)
+    part = R.forward_rep(p32, seq[6:11], L, HEADS, training=True, rate=0.4, seed=5, step=3, row0=6)
+    assert torch.equal(full[6:11], part)
+
+
+def test_parameter_layout_is_aligned_and_disjoint():
+    layout, total = param_layout(1000, 50, 150, 2)
+    spans = sorted((off, off + int(np.prod(shp))) for off, shp in layout.values())
+    assert all(off % 64 == 0 for off, _ in spans)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    assert spans[-1][1] <= total and total % 64 == 0
