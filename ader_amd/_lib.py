@@ -18,10 +18,13 @@ _SIGS = {
     "ader_ln_fwd": [P, L, P, L, P, P, P, P, P, P, I, I, P],
     "ader_ln_bwd_slabs": [I],
     "ader_ln_bwd": [P, L, P, L, P, P, P, P, L, P, L, P, P, P, I, I, P],
-    "ader_gemm_rows": [P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_gemm_rows": [P, P, P, P, P, P, I, I, I, I, I, I] + _DROP + [P],
     "ader_gemm_atb_slabs": [I],
     "ader_gemm_atb": [P, P, P, P, P, I, I, P],
-    "ader_mask_dropgrad": [P, P, P, P, I, I] + _DROP + [P],
+    "ader_mask_dropgrad": [P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_add_rows": [P, P, I, I, I, I, P],
+    "ader_attn_last_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_attn_last_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_attn_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_attn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_logits_sub": [I],

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int col = sub * 16 + i;
-            v[i] = (col < T) ? __expf(v[i] - mx) : 0.0f;
+            v[i] = (col < T) ? expf(v[i] - mx) : 0.0f;
             sum += v[i];
         }
         sum += __shfl_xor(sum, 1, 64);
@@ -244,6 +244,121 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Last-query attention.  Only position T-1 of the final block feeds the representation (ADER.py:85), and rows of a
+// block are independent except through K/V, so the final block needs ONE query row per sequence (exact, not an
+// approximation; the reference computes all T rows and discards T-1 of them).  Tiny: no MFMA.
+// One workgroup per (sequence, head); K and V tiles staged in LDS.
+struct AttnLastArgs {
+    const float* Ql;            // [B,H]  query projection of row T-1
+    const float* K; const float* V;       // [B,T,H]
+    const float* res;           // fwd: LN'd query row [B,H];  bwd: dO [B,H]
+    const float* kmask;         // [B,T]
+    const float* qmask;         // [B]
+    float* out;                 // fwd: x1 row T-1 [B,H]
+    float* P;                   // [B,heads,T] softmax output of the last query row
+    float* dQl; float* dK; float* dV;     // bwd: [B,H], [B,T,H], [B,T,H]
+    int B, T, H, heads;
+    float sqrt_dh;
+    DropArgs drop;
+};
+
+#define LAST_LD 161             // odd row stride: per-row dot products read LDS conflict-free
+
+__global__ __launch_bounds__(256) void k_attn_last_fwd(AttnLastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* K_l = smem;                       // [TR][LAST_LD]
+    float* V_l = K_l + TR * LAST_LD;
+    float* q_l = V_l + TR * LAST_LD;         // [160]
+    float* p_l = q_l + 160;                  // [TR]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
+    const int T = a.T, H = a.H, dh = H / a.heads, c0 = head * dh;
+    const size_t base = (size_t)b * T * H;
+    for (int i = tid; i < T * dh; i += 256) {
+        const int t = i / dh, c = i - t * dh;
+        K_l[t * LAST_LD + c] = a.K[base + (size_t)t * H + c0 + c];
+        V_l[t * LAST_LD + c] = a.V[base + (size_t)t * H + c0 + c];
+    }
+    for (int c = tid; c < dh; c += 256) q_l[c] = a.Ql[(size_t)b * H + c0 + c];
+    __syncthreads();
+    if (tid < 64) {                           // wave 0: scores + softmax of the single query row
+        float s = -INFINITY;
+        if (lane < T) {
+            float acc = 0.0f;
+            for (int c = 0; c < dh; ++c) acc = fmaf(q_l[c], K_l[lane * LAST_LD + c], acc);
+            s = acc / a.sqrt_dh;
+            if (a.kmask[(size_t)b * T + lane] == 0.0f) s = NEG_PAD;      // causal mask admits every key for row T-1
+        }
+        const float mx = wave_max(s);
+        const float e = (lane < T) ? expf(s - mx) : 0.0f;
+        const float sum = wave_sum(e);
+        if (lane < T) {
+            const float p = e / sum;
+            a.P[((size_t)b * a.heads + head) * T + lane] = p;
+            const uint32_t didx = (uint32_t)(((size_t)b * a.heads + head) * T + (T - 1)) * (uint32_t)T + (uint32_t)lane;
+            p_l[lane] = drop_apply(a.drop, didx, p * a.qmask[b]);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < dh; c += 256) {
+        float acc = 0.0f;
+        for (int t = 0; t < T; ++t) acc = fmaf(p_l[t], V_l[t * LAST_LD + c], acc);
+        const size_t idx = (size_t)b * H + c0 + c;
+        a.out[idx] = acc + a.res[idx];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_attn_last_bwd(AttnLastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* K_l = smem;
+    float* V_l = K_l + TR * LAST_LD;
+    float* q_l = V_l + TR * LAST_LD;         // Q row
+    float* g_l = q_l + 160;                  // dO row
+    float* pd_l = g_l + 160;                 // [TR] P_drop
+    float* ds_l = pd_l + TR;                 // [TR] dS
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
+    const int T = a.T, H = a.H, dh = H / a.heads, c0 = head * dh;
+    const size_t base = (size_t)b * T * H;
+    for (int i = tid; i < T * dh; i += 256) {
+        const int t = i / dh, c = i - t * dh;
+        K_l[t * LAST_LD + c] = a.K[base + (size_t)t * H + c0 + c];
+        V_l[t * LAST_LD + c] = a.V[base + (size_t)t * H + c0 + c];
+    }
+    for (int c = tid; c < dh; c += 256) { q_l[c] = a.Ql[(size_t)b * H + c0 + c]; g_l[c] = a.res[(size_t)b * H + c0 + c]; }
+    __syncthreads();
+    if (tid < 64) {
+        float p = 0.0f, dp = 0.0f, pd = 0.0f;
+        if (lane < T) {
+            float acc = 0.0f;
+            for (int c = 0; c < dh; ++c) acc = fmaf(g_l[c], V_l[lane * LAST_LD + c], acc);
+            p = a.P[((size_t)b * a.heads + head) * T + lane];
+            float f = a.qmask[b];
+            const uint32_t didx = (uint32_t)(((size_t)b * a.heads + head) * T + (T - 1)) * (uint32_t)T + (uint32_t)lane;
+            if (a.drop.thr != 0) f = drop_keep(a.drop, didx) ? f * a.drop.scale : 0.0f;
+            dp = acc * f;
+            pd = p * f;
+        }
+        const float dot = wave_sum(dp * p);
+        if (lane < T) {
+            pd_l[lane] = pd;
+            ds_l[lane] = (a.kmask[(size_t)b * T + lane] != 0.0f) ? (p * (dp - dot)) / a.sqrt_dh : 0.0f;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * dh; i += 256) {
+        const int t = i / dh, c = i - t * dh;
+        a.dV[base + (size_t)t * H + c0 + c] = pd_l[t] * g_l[c];
+        a.dK[base + (size_t)t * H + c0 + c] = ds_l[t] * q_l[c];
+    }
+    for (int c = tid; c < dh; c += 256) {
+        float acc = 0.0f;
+        for (int t = 0; t < T; ++t) acc = fmaf(ds_l[t], K_l[t * LAST_LD + c], acc);
+        a.dQl[(size_t)b * H + c0 + c] = acc;
+    }
+}
+
 // ============================================================================================= C ABI
 static const size_t kAttnFwdLds = (size_t)(2 * TR * LDQ + TR * LDV + TR * LDS_) * sizeof(float);
 static const size_t kAttnBwdLds = (size_t)(2 * TR * LDQ + 2 * TR * LDS_) * sizeof(float);
@@ -288,6 +403,55 @@ int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
     a.B = B; a.T = T; a.H = H; a.heads = heads; a.sqrt_dh = sqrtf((float)(H / heads));
     a.drop.key = drop_key; a.drop.thr = drop_thr; a.drop.scale = drop_scale; a.drop.base = drop_base;
     hipLaunchKernelGGL(k_attn_bwd, dim3(B * heads), dim3(256), kAttnBwdLds, (hipStream_t)stream, a);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+static const size_t kAttnLastLds = (size_t)(2 * TR * LAST_LD + 2 * 160 + 2 * TR) * sizeof(float);
+
+static int attn_last_args(AttnLastArgs& a, int B, int T, int H, int heads, unsigned k, unsigned thr, float sc, unsigned base) {
+    if (T > TR || heads < 1 || H % heads != 0 || H / heads > 160) return -2;
+    a.B = B; a.T = T; a.H = H; a.heads = heads; a.sqrt_dh = sqrtf((float)(H / heads));
+    a.drop.key = k; a.drop.thr = thr; a.drop.scale = sc; a.drop.base = base;
+    return 0;
+}
+
+int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, const float* q_in_last, const float* kmask,
+                       const float* qmask_last, float* out_last, float* P_last, int B, int T, int H, int heads, unsigned drop_key,
+                       unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+    if (B <= 0) return 0;
+    AttnLastArgs a;
+    int rc = attn_last_args(a, B, T, H, heads, drop_key, drop_thr, drop_scale, drop_base);
+    if (rc) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_last_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLastLds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.Ql = Q_last; a.K = K; a.V = V; a.res = q_in_last; a.kmask = kmask; a.qmask = qmask_last; a.out = out_last; a.P = P_last;
+    a.dQl = a.dK = a.dV = nullptr;
+    hipLaunchKernelGGL(k_attn_last_fwd, dim3(B * heads), dim3(256), kAttnLastLds, (hipStream_t)stream, a);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_attn_last_bwd(const float* dO_last, const float* Q_last, const float* K, const float* V, const float* P_last,
+                       const float* kmask, const float* qmask_last, float* dQ_last, float* dK, float* dV, int B, int T, int H,
+                       int heads, unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+    if (B <= 0) return 0;
+    AttnLastArgs a;
+    int rc = attn_last_args(a, B, T, H, heads, drop_key, drop_thr, drop_scale, drop_base);
+    if (rc) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_last_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLastLds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.Ql = Q_last; a.K = K; a.V = V; a.res = dO_last; a.kmask = kmask; a.qmask = qmask_last; a.out = nullptr; a.P = (float*)P_last;
+    a.dQl = dQ_last; a.dK = dK; a.dV = dV;
+    hipLaunchKernelGGL(k_attn_last_bwd, dim3(B * heads), dim3(256), kAttnLastLds, (hipStream_t)stream, a);
     HIP_LAUNCH_CHECK();
     return 0;
 }

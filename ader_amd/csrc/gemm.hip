@@ -20,6 +20,7 @@ struct GemmArgs {
     const float* aux;      // EPI 2: residual; EPI 3: saved post-dropout activation; EPI 4: addend (may alias C)
     const int* seq;        // EPI 2: row mask source (seq != 0)
     int M, H;
+    int row_mul, row_add;  // full-tensor row of local row m = m*row_mul + row_add (dropout counter / seq mask of a row subset)
     DropArgs drop;
 };
 
@@ -64,13 +65,15 @@ __global__ __launch_bounds__(512) void k_gemm_rows(GemmArgs g) {
                 const int m = m0 + mw * 16 + (lane >> 4) * 4 + r;
                 if (m >= g.M) continue;
                 const size_t idx = (size_t)m * H + n;
+                const int mf = m * g.row_mul + g.row_add;
+                const uint32_t didx = (uint32_t)mf * (uint32_t)H + (uint32_t)n;
                 float v = acc[j][r] + bv;
                 if (EPI == EPI_BIAS_RELU_DROP) {
                     v = fmaxf(v, 0.0f);
-                    v = drop_apply(g.drop, (uint32_t)idx, v);
+                    v = drop_apply(g.drop, didx, v);
                 } else if (EPI == EPI_BIAS_DROP_RES_MASK) {
-                    v = drop_apply(g.drop, (uint32_t)idx, v);
-                    v = (g.seq[m] != 0) ? (v + g.aux[idx]) : 0.0f;
+                    v = drop_apply(g.drop, didx, v);
+                    v = (g.seq[mf] != 0) ? (v + g.aux[idx]) : 0.0f;
                 } else if (EPI == EPI_RELUDROPGRAD) {
                     v = (g.aux[idx] != 0.0f) ? v * g.drop.scale : 0.0f;
                 } else if (EPI == EPI_ADD) {
@@ -157,17 +160,18 @@ static int launch_rows(const GemmArgs& g, hipStream_t st) {
 extern "C" {
 
 int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, const float* aux, const int* seq, int M, int H,
-                   int epilogue, int trans_b, unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base,
-                   void* stream) {
+                   int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                   unsigned drop_base, void* stream) {
     if (M <= 0) return 0;
     if (H > HP || H < 1) return -2;
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.C = C; g.aux = aux; g.seq = seq; g.M = M; g.H = H;
+    g.row_mul = row_mul; g.row_add = row_add;
     g.drop.key = drop_key; g.drop.thr = drop_thr; g.drop.scale = drop_scale; g.drop.base = drop_base;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue * 2 + (trans_b ? 1 : 0)) {
         case EPI_BIAS * 2 + 0: return launch_rows<EPI_BIAS, false>(g, st);
-        case EPI_BIAS * 2 + 1: return launch_rows<EPI_BIAS, true>(g, st);
+        case EPI_BIAS * 2 + 1: return launch_rows<EPI_BIAS, true>(g, st);   // plain dX = dY . W^T (bias NULL)
         case EPI_BIAS_RELU_DROP * 2 + 0: return launch_rows<EPI_BIAS_RELU_DROP, false>(g, st);
         case EPI_BIAS_DROP_RES_MASK * 2 + 0: return launch_rows<EPI_BIAS_DROP_RES_MASK, false>(g, st);
         case EPI_RELUDROPGRAD * 2 + 1: return launch_rows<EPI_RELUDROPGRAD, true>(g, st);

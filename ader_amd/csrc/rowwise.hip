@@ -216,14 +216,28 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, lo
 // Backward entry of the FFN tail  x2 = (dropout(h2) + y) * mask   (modules.py:262-266, ADER.py:80):
 //   g = dx2 * mask (gradient of the residual y);  dh2 = g * keep * scale.
 __global__ __launch_bounds__(256) void k_mask_dropgrad(const float* __restrict__ dx2, const int* __restrict__ seq,
-                                                       float* __restrict__ g, float* __restrict__ dh2, int rows, int H, DropArgs d) {
+                                                       float* __restrict__ g, float* __restrict__ dh2, int rows, int H,
+                                                       int row_mul, int row_add, DropArgs d) {
     const size_t n = (size_t)rows * H;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / H);
-        float v = (seq[row] != 0) ? dx2[i] : 0.0f;
+        const int c = (int)(i - (size_t)row * H);
+        const int rf = row * row_mul + row_add;               // row of the full [B*T,H] tensor
+        float v = (seq[rf] != 0) ? dx2[i] : 0.0f;
         g[i] = v;
-        if (d.thr != 0) v = drop_keep(d, (uint32_t)i) ? v * d.scale : 0.0f;
+        if (d.thr != 0) v = drop_keep(d, (uint32_t)rf * (uint32_t)H + (uint32_t)c) ? v * d.scale : 0.0f;
         dh2[i] = v;
+    }
+}
+
+// dst[(r*row_mul + row_add), :] += src[r, :]
+__global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ src, float* __restrict__ dst, int rows, int H,
+                                                  int row_mul, int row_add) {
+    const size_t n = (size_t)rows * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / H);
+        const int c = (int)(i - (size_t)row * H);
+        dst[((size_t)row * row_mul + row_add) * H + c] += src[i];
     }
 }
 
@@ -345,11 +359,19 @@ int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const fl
     return 0;
 }
 
-int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, unsigned drop_key,
-                       unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
+                       unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_mask_dropgrad, dim3(cap_grid((size_t)rows * H, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx2, seq, g,
-                       dh2, rows, H, mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+                       dh2, rows, H, row_mul, row_add, mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_add_rows(const float* src, float* dst, int rows, int H, int row_mul, int row_add, void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_add_rows, dim3(cap_grid((size_t)rows * H, 256, 2048)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, H,
+                       row_mul, row_add);
     HIP_LAUNCH_CHECK();
     return 0;
 }

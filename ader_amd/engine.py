@@ -164,6 +164,7 @@ class Engine:
         self._ws = {}
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
         self.timer = None        # optional SectionTimer
+        self.prune_last = True   # final block: query/FFN path only for position T-1 (exact; see forward())
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -238,60 +239,94 @@ class Engine:
         return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32)).to(self.device)
 
     # ---------------------------------------------------------------------------------------- forward
+    _ND = (0, 0, 1.0, 0)
+
+    def _gemm(self, A, W, bias, C, aux, seq, M, epi, trans=0, drop=None, rmap=(1, 0)):
+        d = drop.args() if drop is not None else self._ND
+        call("ader_gemm_rows", ptr(A), W, bias, ptr(C), ptr(aux), ptr(seq), M, self.H, epi, trans, rmap[0], rmap[1], *d,
+             self._stream())
+
     def forward(self, seq, training=False, rate=0.0, step=0, save=False):
-        """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward."""
+        """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward.
+        The final block computes only position T-1 of its query / FFN path (Engine.prune_last): the representation is
+        x[:, -1, :] (ADER.py:85) and rows interact only through K/V, so the other T-1 rows of that block are dead work."""
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
         rows = B * T
         st = self._stream()
         tag = "t" if save else "e"
         A = {"B": B, "seq": seq, "rate": rate, "training": training, "step": step}
         per_row = T * H
+        pp = self._pp
         d0 = _Drop(self.seed, step, SITE_EMB, rate, training, self.row0 * per_row)
         x = self.buf(tag + "x0", (rows, H))
-        call("ader_embed_fwd", ptr(seq), self._pp["emb"], self._pp["pos"], ptr(x), rows, T, H, self.V,
-             *d0.args(), ptr(self.status), st)
+        call("ader_embed_fwd", ptr(seq), pp["emb"], pp["pos"], ptr(x), rows, T, H, self.V, *d0.args(), ptr(self.status), st)
         A["d_emb"] = d0
+        last_map = (T, T - 1)
         for l in range(L):
             p = "b%d." % l
             n = lambda s: "%s%d%s" % (tag, l, s)   # noqa: E731
+            pruned = self.prune_last and l == L - 1
+            da = _Drop(self.seed, step, site_attn(l), rate, training, self.row0 * self.heads * T * T)
+            d1 = _Drop(self.seed, step, site_ffn1(l), rate, training, self.row0 * per_row)
+            d2 = _Drop(self.seed, step, site_ffn2(l), rate, training, self.row0 * per_row)
             q_in = self.buf(n("qin"), (rows, H))
             mean1, std1 = self.buf(n("m1"), (rows,)), self.buf(n("s1"), (rows,))
             kmask, qmask = self.buf(n("km"), (rows,)), self.buf(n("qm"), (rows,))
-            call("ader_ln_fwd", ptr(x), H, ptr(q_in), H, self._pp[p + "ln1_g"], self._pp[p + "ln1_b"],
-                 ptr(mean1), ptr(std1), ptr(kmask), ptr(qmask), rows, H, st)
-            Q, K, Vv = self.buf(n("Q"), (rows, H)), self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
-            nd = (0, 0, 1.0, 0)
-            call("ader_gemm_rows", ptr(q_in), self._pp[p + "wq"], self._pp[p + "bq"], ptr(Q), None, None,
-                 rows, H, EPI_BIAS, 0, *nd, st)
-            call("ader_gemm_rows", ptr(x), self._pp[p + "wk"], self._pp[p + "bk"], ptr(K), None, None,
-                 rows, H, EPI_BIAS, 0, *nd, st)
-            call("ader_gemm_rows", ptr(x), self._pp[p + "wv"], self._pp[p + "bv"], ptr(Vv), None, None,
-                 rows, H, EPI_BIAS, 0, *nd, st)
-            x1 = self.buf(n("x1"), (rows, H))
-            Pm = self.buf(n("P"), (B * self.heads * T * T,))
-            da = _Drop(self.seed, step, site_attn(l), rate, training, self.row0 * self.heads * T * T)
-            call("ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask), ptr(qmask), ptr(x1), ptr(Pm), B, T, H,
-                 self.heads, *da.args(), st)
-            y = self.buf(n("y"), (rows, H))
-            mean2, std2 = self.buf(n("m2"), (rows,)), self.buf(n("s2"), (rows,))
-            call("ader_ln_fwd", ptr(x1), H, ptr(y), H, self._pp[p + "ln2_g"], self._pp[p + "ln2_b"],
-                 ptr(mean2), ptr(std2), None, None, rows, H, st)
-            h1d = self.buf(n("h1"), (rows, H))
-            d1 = _Drop(self.seed, step, site_ffn1(l), rate, training, self.row0 * per_row)
-            call("ader_gemm_rows", ptr(y), self._pp[p + "w1"], self._pp[p + "b1"], ptr(h1d), None, None,
-                 rows, H, EPI_BIAS_RELU_DROP, 0, *d1.args(), st)
-            x2 = self.buf(n("x2"), (rows, H))
-            d2 = _Drop(self.seed, step, site_ffn2(l), rate, training, self.row0 * per_row)
-            call("ader_gemm_rows", ptr(h1d), self._pp[p + "w2"], self._pp[p + "b2"], ptr(x2), ptr(y), ptr(seq),
-                 rows, H, EPI_BIAS_DROP_RES_MASK, 0, *d2.args(), st)
-            A[l] = dict(x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv, P=Pm, x1=x1,
-                        y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
-            x = x2
+            call("ader_ln_fwd", ptr(x), H, ptr(q_in), H, pp[p + "ln1_g"], pp[p + "ln1_b"], ptr(mean1), ptr(std1), ptr(kmask),
+                 ptr(qmask), rows, H, st)
+            K, Vv = self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
+            self._gemm(x, pp[p + "wk"], pp[p + "bk"], K, None, None, rows, EPI_BIAS)
+            self._gemm(x, pp[p + "wv"], pp[p + "bv"], Vv, None, None, rows, EPI_BIAS)
+            if not pruned:
+                Q = self.buf(n("Q"), (rows, H))
+                self._gemm(q_in, pp[p + "wq"], pp[p + "bq"], Q, None, None, rows, EPI_BIAS)
+                x1 = self.buf(n("x1"), (rows, H))
+                Pm = self.buf(n("P"), (B * self.heads * T * T,))
+                call("ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask), ptr(qmask), ptr(x1), ptr(Pm), B, T, H,
+                     self.heads, *da.args(), st)
+                y = self.buf(n("y"), (rows, H))
+                mean2, std2 = self.buf(n("m2"), (rows,)), self.buf(n("s2"), (rows,))
+                call("ader_ln_fwd", ptr(x1), H, ptr(y), H, pp[p + "ln2_g"], pp[p + "ln2_b"], ptr(mean2), ptr(std2), None, None,
+                     rows, H, st)
+                h1d = self.buf(n("h1"), (rows, H))
+                self._gemm(y, pp[p + "w1"], pp[p + "b1"], h1d, None, None, rows, EPI_BIAS_RELU_DROP, drop=d1)
+                x2 = self.buf(n("x2"), (rows, H))
+                self._gemm(h1d, pp[p + "w2"], pp[p + "b2"], x2, y, seq, rows, EPI_BIAS_DROP_RES_MASK, drop=d2)
+                A[l] = dict(pruned=False, x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv,
+                            P=Pm, x1=x1, y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
+                x = x2
+            else:
+                # compact [B,H] tensors of row T-1
+                x_last = x.view(B, T, H)[:, T - 1, :]
+                qin_l = self.buf(n("qinL"), (B, H))
+                m1l, s1l, qml = self.buf(n("m1L"), (B,)), self.buf(n("s1L"), (B,)), self.buf(n("qmL"), (B,))
+                call("ader_ln_fwd", ptr(x_last), T * H, ptr(qin_l), H, pp[p + "ln1_g"], pp[p + "ln1_b"], ptr(m1l), ptr(s1l),
+                     None, ptr(qml), B, H, st)
+                Ql = self.buf(n("QL"), (B, H))
+                self._gemm(qin_l, pp[p + "wq"], pp[p + "bq"], Ql, None, None, B, EPI_BIAS)
+                x1l = self.buf(n("x1L"), (B, H))
+                Pl = self.buf(n("PL"), (B * self.heads * T,))
+                call("ader_attn_last_fwd", ptr(Ql), ptr(K), ptr(Vv), ptr(qin_l), ptr(kmask), ptr(qml), ptr(x1l), ptr(Pl), B, T, H,
+                     self.heads, *da.args(), st)
+                yl = self.buf(n("yL"), (B, H))
+                m2l, s2l = self.buf(n("m2L"), (B,)), self.buf(n("s2L"), (B,))
+                call("ader_ln_fwd", ptr(x1l), H, ptr(yl), H, pp[p + "ln2_g"], pp[p + "ln2_b"], ptr(m2l), ptr(s2l), None, None,
+                     B, H, st)
+                h1l = self.buf(n("h1L"), (B, H))
+                self._gemm(yl, pp[p + "w1"], pp[p + "b1"], h1l, None, None, B, EPI_BIAS_RELU_DROP, drop=d1, rmap=last_map)
+                x2l = self.buf(n("x2L"), (B, H))
+                self._gemm(h1l, pp[p + "w2"], pp[p + "b2"], x2l, yl, seq, B, EPI_BIAS_DROP_RES_MASK, drop=d2, rmap=last_map)
+                A[l] = dict(pruned=True, x=x, q_in=qin_l, mean1=m1l, std1=s1l, kmask=kmask, qmask=qml, Q=Ql, K=K, V=Vv, P=Pl,
+                            x1=x1l, y=yl, mean2=m2l, std2=s2l, h1d=h1l, da=da, d1=d1, d2=d2)
+                x = x2l
         rep = self.buf(tag + "rep", (B, H))
         meanf, stdf = self.buf(tag + "mf", (B,)), self.buf(tag + "sf", (B,))
-        x_last = x.view(B, T, H)[:, T - 1, :]
-        call("ader_ln_fwd", ptr(x_last), T * H, ptr(rep), H, self._pp["lnf_g"], self._pp["lnf_b"],
-             ptr(meanf), ptr(stdf), None, None, B, H, st)
+        if self.prune_last:
+            call("ader_ln_fwd", ptr(x), H, ptr(rep), H, pp["lnf_g"], pp["lnf_b"], ptr(meanf), ptr(stdf), None, None, B, H, st)
+        else:
+            x_last = x.view(B, T, H)[:, T - 1, :]
+            call("ader_ln_fwd", ptr(x_last), T * H, ptr(rep), H, pp["lnf_g"], pp["lnf_b"], ptr(meanf), ptr(stdf), None, None,
+                 B, H, st)
         A.update(xL=x, rep=rep, meanf=meanf, stdf=stdf)
         if save:
             self._act = A
@@ -389,46 +424,69 @@ class Engine:
         tb = self._sec("blocks_bwd")
         tb.__enter__()
         wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))
-        dx = self.buf("dx_a", (rows, H))
-        dx.zero_()
+        pp, gp = self._pp, self._gp
         xL = A["xL"]
-        call("ader_ln_bwd", ptr(drep), H, ptr(xL.view(B, T, H)[:, T - 1, :]), T * H, self._pp["lnf_g"],
-             ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab),
-             self._gp["lnf_g"], self._gp["lnf_b"], B, H, st)
-        g = self.buf("bw_g", (rows, H))
-        dh2 = self.buf("bw_dh2", (rows, H))
-        da_ = self.buf("bw_da", (rows, H))
-        dy = self.buf("bw_dy", (rows, H))
-        dx1 = self.buf("bw_dx1", (rows, H))
-        dQ, dK, dV = self.buf("bw_dQ", (rows, H)), self.buf("bw_dK", (rows, H)), self.buf("bw_dV", (rows, H))
-        dqin = self.buf("bw_dqin", (rows, H))
+        dx = self.buf("dx_a", (rows, H))
         dxn = self.buf("dx_b", (rows, H))
-        nd = (0, 0, 1.0, 0)
+        if self.prune_last:
+            dxl = self.buf("dx_L", (B, H))        # gradient of the final block's output row T-1 (compact)
+            call("ader_ln_bwd", ptr(drep), H, ptr(xL), H, pp["lnf_g"], ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dxl), H,
+                 ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
+        else:
+            dx.zero_()
+            call("ader_ln_bwd", ptr(drep), H, ptr(xL.view(B, T, H)[:, T - 1, :]), T * H, pp["lnf_g"], ptr(A["meanf"]),
+                 ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
+        last_map = (T, T - 1)
         for l in reversed(range(L)):
             p = "b%d." % l
             S = A[l]
-            W = lambda s: self._pp[p + s]      # noqa: E731
-            G = lambda s: self._gp[p + s]   # noqa: E731
-            call("ader_mask_dropgrad", ptr(dx), ptr(seq), ptr(g), ptr(dh2), rows, H, *S["d2"].args(), st)
-            call("ader_gemm_rows", ptr(dh2), W("w2"), None, ptr(da_), ptr(S["h1d"]), None, rows, H, EPI_RELUDROPGRAD, 1,
-                 *S["d1"].args(), st)
-            call("ader_gemm_rows", ptr(da_), W("w1"), None, ptr(dy), ptr(g), None, rows, H, EPI_ADD, 1, *nd, st)
-            call("ader_gemm_atb", ptr(S["h1d"]), ptr(dh2), ptr(wslab), G("w2"), G("b2"), rows, H, st)
-            call("ader_gemm_atb", ptr(S["y"]), ptr(da_), ptr(wslab), G("w1"), G("b1"), rows, H, st)
+            W = lambda s: pp[p + s]      # noqa: E731
+            G = lambda s: gp[p + s]      # noqa: E731
+            if S["pruned"]:
+                M, rmap, dxo = B, last_map, dxl
+            else:
+                M, rmap, dxo = rows, (1, 0), dx
+            tg = "L" if S["pruned"] else ""
+            g = self.buf("bw_g" + tg, (M, H))
+            dh2 = self.buf("bw_dh2" + tg, (M, H))
+            da_ = self.buf("bw_da" + tg, (M, H))
+            dy = self.buf("bw_dy" + tg, (M, H))
+            dx1 = self.buf("bw_dx1" + tg, (M, H))
+            dQ = self.buf("bw_dQ" + tg, (M, H))
+            dqin = self.buf("bw_dqin" + tg, (M, H))
+            dK, dV = self.buf("bw_dK", (rows, H)), self.buf("bw_dV", (rows, H))
+            call("ader_mask_dropgrad", ptr(dxo), ptr(seq), ptr(g), ptr(dh2), M, H, rmap[0], rmap[1], *S["d2"].args(), st)
+            self._gemm(dh2, W("w2"), None, da_, S["h1d"], None, M, EPI_RELUDROPGRAD, trans=1, drop=S["d1"])
+            self._gemm(da_, W("w1"), None, dy, g, None, M, EPI_ADD, trans=1)
+            call("ader_gemm_atb", ptr(S["h1d"]), ptr(dh2), ptr(wslab), G("w2"), G("b2"), M, H, st)
+            call("ader_gemm_atb", ptr(S["y"]), ptr(da_), ptr(wslab), G("w1"), G("b1"), M, H, st)
             call("ader_ln_bwd", ptr(dy), H, ptr(S["x1"]), H, W("ln2_g"), ptr(S["mean2"]), ptr(S["std2"]), None, 0, ptr(dx1), H,
-                 ptr(wslab), G("ln2_g"), G("ln2_b"), rows, H, st)
-            call("ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]),
-                 ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
-            call("ader_gemm_rows", ptr(dQ), W("wq"), None, ptr(dqin), ptr(dx1), None, rows, H, EPI_ADD, 1, *nd, st)
-            call("ader_ln_bwd", ptr(dqin), H, ptr(S["x"]), H, W("ln1_g"), ptr(S["mean1"]), ptr(S["std1"]), None, 0, ptr(dxn), H,
-                 ptr(wslab), G("ln1_g"), G("ln1_b"), rows, H, st)
-            call("ader_gemm_rows", ptr(dK), W("wk"), None, ptr(dxn), ptr(dxn), None, rows, H, EPI_ADD, 1, *nd, st)
-            call("ader_gemm_rows", ptr(dV), W("wv"), None, ptr(dxn), ptr(dxn), None, rows, H, EPI_ADD, 1, *nd, st)
-            call("ader_gemm_atb", ptr(S["q_in"]), ptr(dQ), ptr(wslab), G("wq"), G("bq"), rows, H, st)
+                 ptr(wslab), G("ln2_g"), G("ln2_b"), M, H, st)
+            if S["pruned"]:
+                call("ader_attn_last_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
+                     ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
+            else:
+                call("ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
+                     ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
+            self._gemm(dQ, W("wq"), None, dqin, dx1, None, M, EPI_ADD, trans=1)
+            if S["pruned"]:
+                # LN1 backward on row T-1 only; dK/dV reach every row through the K/V projections
+                dql = self.buf("bw_dxq", (B, H))
+                call("ader_ln_bwd", ptr(dqin), H, ptr(S["x"].view(B, T, H)[:, T - 1, :]), T * H, W("ln1_g"), ptr(S["mean1"]),
+                     ptr(S["std1"]), None, 0, ptr(dql), H, ptr(wslab), G("ln1_g"), G("ln1_b"), B, H, st)
+                self._gemm(dK, W("wk"), None, dxn, None, None, rows, EPI_BIAS, trans=1)
+                self._gemm(dV, W("wv"), None, dxn, dxn, None, rows, EPI_ADD, trans=1)
+                call("ader_add_rows", ptr(dql), ptr(dxn), B, H, T, T - 1, st)
+            else:
+                call("ader_ln_bwd", ptr(dqin), H, ptr(S["x"]), H, W("ln1_g"), ptr(S["mean1"]), ptr(S["std1"]), None, 0, ptr(dxn), H,
+                     ptr(wslab), G("ln1_g"), G("ln1_b"), rows, H, st)
+                self._gemm(dK, W("wk"), None, dxn, dxn, None, rows, EPI_ADD, trans=1)
+                self._gemm(dV, W("wv"), None, dxn, dxn, None, rows, EPI_ADD, trans=1)
+            call("ader_gemm_atb", ptr(S["q_in"]), ptr(dQ), ptr(wslab), G("wq"), G("bq"), M, H, st)
             call("ader_gemm_atb", ptr(S["x"]), ptr(dK), ptr(wslab), G("wk"), G("bk"), rows, H, st)
             call("ader_gemm_atb", ptr(S["x"]), ptr(dV), ptr(wslab), G("wv"), G("bv"), rows, H, st)
             dx, dxn = dxn, dx
-        call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), self._gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+        call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)
         return self.loss
 

@@ -45,15 +45,19 @@ int ader_ln_bwd(const float* dy, long dy_row_stride, const float* x, long x_row_
 enum { ADER_EPI_BIAS = 0, ADER_EPI_BIAS_RELU_DROP = 1, ADER_EPI_BIAS_DROP_RES_MASK = 2, ADER_EPI_RELUDROPGRAD = 3,
        ADER_EPI_ADD = 4 };
 /* C[M,H] = epilogue(A[M,H] . (trans_b ? W^T : W) + bias).  aux/seq per epilogue, see csrc/gemm.hip. */
+/* row_mul/row_add: local row m is row m*row_mul+row_add of the full [B*T,H] tensor (dropout counter and seq mask of a row
+ * subset, e.g. only position T-1 of every sequence: row_mul = T, row_add = T-1); 1, 0 for full tensors. */
 int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, const float* aux, const int* seq, int M,
-                   int H, int epilogue, int trans_b, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                   unsigned drop_base, void* stream);
+                   int H, int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr,
+                   float drop_scale, unsigned drop_base, void* stream);
 int ader_gemm_atb_slabs(int M);
 /* dW[H,H] = A^T . G, db[H] = column sums of G (db may be NULL).  slab: ader_gemm_atb_slabs(M)*160*160 floats. */
 int ader_gemm_atb(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
-int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, unsigned drop_key,
-                       unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
+                       unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+/* dst[(r*row_mul+row_add), :] += src[r, :] */
+int ader_add_rows(const float* src, float* dst, int rows, int H, int row_mul, int row_add, void* stream);
 
 /* ---- attention core: modules.py:177-223 --------------------------------------------------------------- */
 int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask,
@@ -62,6 +66,16 @@ int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q
 int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* P, const float* kmask,
                   const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads,
                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+
+/* Last block: only position T-1 feeds the representation (ADER.py:85), so its attention needs one query row per sequence
+ * (exact).  Q_last, q_in_last, out_last, dQ_last: [B,H]; K, V, dK, dV: [B,T,H]; P_last: [B,heads,T]; qmask_last: [B]. */
+int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, const float* q_in_last, const float* kmask,
+                       const float* qmask_last, float* out_last, float* P_last, int B, int T, int H, int heads,
+                       unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+int ader_attn_last_bwd(const float* dO_last, const float* Q_last, const float* K, const float* V, const float* P_last,
+                       const float* kmask, const float* qmask_last, float* dQ_last, float* dK, float* dV, int B, int T,
+                       int H, int heads, unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base,
+                       void* stream);
 
 /* ---- full-catalog logits + loss: ADER.py:88-93, 108-137 ------------------------------------------------ */
 /* Row descriptors, all [Bp]: lab (1-based target item or 0), ncol (valid columns: N, or Np for distilled rows, 0 for
