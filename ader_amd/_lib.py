@@ -36,11 +36,12 @@ _SIGS = {
     "ader_logits_bwd_drep": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P, P],
     "ader_logits_bwd_demb": [P, P, I, I, I, I, P, P, P, P, P, P, L, P, P, P],
     "ader_lbf_ranges": [I, I],
-    "ader_lbf_fwd": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
-    "ader_lbf_bwd_demb": [P, P, I, I, I, I, P, P, P, P, P],
+    "ader_lbf_shadow_refresh": [P, P, Z, I, P],
+    "ader_lbf_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
     "ader_rank_targets": [P, P, I, I, I, I, P, P, P, P, P],
-    "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P],
+    "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P, Z, I, P],
     "ader_fill": [P, Z, F, P],
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],

@@ -59,8 +59,20 @@ __global__ __launch_bounds__(256) void k_lbf_prep(const float* __restrict__ rep,
     rep_bf[i] = (bf16)((b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f);
 }
 
+// bf16 shadow of the fp32 master table: shadow[row][0:H] = bf16(emb[row][0:H]), row stride LDR (336 B), padding zero.
+// The logit GEMMs stream this copy (16-B pieces, LDS image == memory image); ader_adam_step keeps it in sync.
+__global__ __launch_bounds__(256) void k_lbf_shadow(const float* __restrict__ emb, bf16* __restrict__ shadow, size_t rows, int H) {
+    const size_t n = rows * LDR;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / LDR;
+        const int c = (int)(i - r * LDR);
+        shadow[i] = (bf16)((c < H) ? emb[r * H + c] : 0.0f);
+    }
+}
+
 struct LbfArgs {
-    const float* emb1;          // table row of item 1 (fp32)
+    const bf16* sh1;            // bf16 shadow of the table, row of item 1: rows of LDR elements (336 B), cols >= H zero
+    int vrows;                  // shadow rows available from sh1 (= item_num)
     const bf16* rep_bf;         // [Bp][LDR]
     int B, Bp, H, N, ranges;
     float* pm; float* pl; float* pO;    // [ranges][Bp], [ranges][Bp], [ranges][Bp][HP]
@@ -68,8 +80,11 @@ struct LbfArgs {
     float* demb1;               // gradient row of item 1
 };
 
-#define PF 10   // float2 prefetch registers per thread for a 32-item block (32*H/2/256 <= 10 for H <= 160)
-#define FB 32   // items per streamed block
+#define FB 32                      // items per streamed block
+#define PCS_ROW (LDR * 2 / 16)     // 16-byte pieces per shadow row (21)
+#define PCS_BLK (FB * PCS_ROW)     // pieces per block (672)
+#define PPT 3                      // pieces per thread per block (256*3 >= 672)
+#define RD 3                       // register ring depth: table blocks in flight per workgroup
 
 __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -80,12 +95,12 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int range = xcd + 8 * (slot / nchunk), bc = slot % nchunk;
     if (range >= a.ranges) return;
-    const int H = a.H, HH = H >> 1, N = a.N;
+    const int N = a.N;
     const int nblk = (N + FB - 1) / FB;
     const int per = (nblk + a.ranges - 1) / a.ranges;
     const int blk_begin = range * per, blk_end = min(nblk, blk_begin + per);
+    const int nb_blocks = max(0, blk_end - blk_begin);
     const int b0 = bc * 128 + wave * 32;
-    for (int i = tid; i < 2 * FB * LDR / 2; i += 256) ((uint32_t*)E_l)[i] = 0u;
     bf16x8 bfrag[10];
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) bfrag[ks] = *(const bf16x8*)(a.rep_bf + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
@@ -95,45 +110,38 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
-    float2 pf[PF];
-    // float2 #idx = tid + 256 j of a block <-> (item = idx / HH, pair = idx % HH), walked incrementally
-    const int it_first = tid / HH, c2_first = tid - it_first * HH;
-    const int it_step = 256 / HH, c2_step = 256 - it_step * HH;
-#define LBF_PREFETCH(blk_)                                                                               \
+    uint4 ring[RD][PPT];
+#define LBF_LOAD(slot_, blk_)                                                                            \
     {                                                                                                    \
-        const int i0_ = (blk_) * FB;                                                                     \
-        int it_ = it_first, c2_ = c2_first;                                                              \
-        _Pragma("unroll") for (int j = 0; j < PF; ++j) {                                                 \
-            float2 v = make_float2(0.f, 0.f);                                                            \
-            if (it_ < FB && i0_ + it_ < N) v = *(const float2*)(a.emb1 + (size_t)(i0_ + it_) * H + 2 * c2_); \
-            pf[j] = v;                                                                                   \
-            it_ += it_step; c2_ += c2_step;                                                              \
-            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        const uint4* src_ = (const uint4*)(a.sh1 + (size_t)(blk_) * FB * LDR);                           \
+        _Pragma("unroll") for (int j = 0; j < PPT; ++j) {                                                \
+            const int idx_ = tid + 256 * j;                                                              \
+            uint4 v_ = make_uint4(0u, 0u, 0u, 0u);                                                       \
+            if (idx_ < PCS_BLK && (blk_) * FB + idx_ / PCS_ROW < a.vrows) v_ = src_[idx_];               \
+            ring[slot_][j] = v_;                                                                         \
         }                                                                                                \
     }
-#define LBF_STAGE(buf_)                                                                                  \
+#define LBF_STORE(slot_, buf_)                                                                           \
     {                                                                                                    \
-        bf16* dst_ = E_l + (buf_) * FB * LDR;                                                            \
-        int it_ = it_first, c2_ = c2_first;                                                              \
-        _Pragma("unroll") for (int j = 0; j < PF; ++j) {                                                 \
-            if (it_ < FB) {                                                                              \
-                bf16x2 v; v[0] = (bf16)pf[j].x; v[1] = (bf16)pf[j].y;                                    \
-                *(bf16x2*)(dst_ + it_ * LDR + 2 * c2_) = v;                                              \
-            }                                                                                            \
-            it_ += it_step; c2_ += c2_step;                                                              \
-            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        uint4* dst_ = (uint4*)(E_l + (buf_) * FB * LDR);                                                 \
+        _Pragma("unroll") for (int j = 0; j < PPT; ++j) {                                                \
+            const int idx_ = tid + 256 * j;                                                              \
+            if (idx_ < PCS_BLK) dst_[idx_] = ring[slot_][j];                                             \
         }                                                                                                \
     }
-    __syncthreads();
-    if (blk_begin < blk_end) { LBF_PREFETCH(blk_begin); LBF_STAGE(0); }
-    __syncthreads();
-    int cur = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < RD; ++s_) if (s_ < nb_blocks) LBF_LOAD(s_, blk_begin + s_);
+    int cur = 0, i = 0;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    for (int blk = blk_begin; blk < blk_end; ++blk) {
-        const bool more = blk + 1 < blk_end;
-        if (more) LBF_PREFETCH(blk + 1);
-        const bf16* Eb = E_l + cur * FB * LDR;
-        {
+    while (i < nb_blocks) {
+#pragma unroll
+        for (int s_ = 0; s_ < RD; ++s_) {
+            if (i >= nb_blocks) break;                  // workgroup-uniform
+            const int blk = blk_begin + i;
+            LBF_STORE(s_, cur);
+            if (i + RD < nb_blocks) LBF_LOAD(s_, blk + RD);
+            __syncthreads();
+            const bf16* Eb = E_l + cur * FB * LDR;
             const int i0 = blk * FB;
             f32x16 S;
 #pragma unroll
@@ -181,10 +189,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
                 O[nb] = mfma_bf16(pa0, b0v, O[nb]);
                 O[nb] = mfma_bf16(pa1, b1v, O[nb]);
             }
+            cur ^= 1;
+            ++i;
         }
-        if (more) LBF_STAGE(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (hh == 0) {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void k_lbf_combine(LbfArgs a, const int* __res
     float et = 0.0f, oh = 0.0f;
     if (tid < H) {
         if (t >= 0) {
-            et = (float)(bf16)a.emb1[(size_t)t * H + tid];
+            et = (float)a.sh1[(size_t)t * LDR + tid];
             part = (float)a.rep_bf[(size_t)b * LDR + tid] * et;
         }
         for (int i = 0; i < R; ++i) {
@@ -269,32 +276,32 @@ __global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, in
 }
 
 // dE tile (128 items per workgroup, 32 per wave); loops over all batch rows in chunks of 64 staged through LDS.
+#define FLD 152                    // fp32 row stride of the dE staging tile
+
 __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]
+    bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
     float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int H = a.H, N = a.N;
-    const int it0 = blockIdx.x * 128 + wave * 32;
-    // table fragments of this wave's 32 items: lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
-    bf16x8 efrag[10];
-    {
-        const int it = it0 + r;
-        const float* row = a.emb1 + (size_t)it * H;
-#pragma unroll
-        for (int ks = 0; ks < 10; ++ks) {
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                const int k = 16 * ks + 8 * hh + 2 * j2;
-                float2 v = make_float2(0.f, 0.f);
-                if (it < N && k < H) v = *(const float2*)(row + k);
-                efrag[ks][2 * j2] = (bf16)v.x;
-                efrag[ks][2 * j2 + 1] = (bf16)v.y;
-            }
+    const int tile0 = blockIdx.x * 128;
+    const int it0 = tile0 + wave * 32;
+    {   // table tile: 128 shadow rows, contiguous -> LDS (coalesced 16-B pieces) -> operand fragments in registers
+        const uint4* src = (const uint4*)(a.sh1 + (size_t)tile0 * LDR);
+        uint4* dst = (uint4*)R_l;
+        for (int idx = tid; idx < 128 * PCS_ROW; idx += 256) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (tile0 + idx / PCS_ROW < a.vrows) v = src[idx];
+            dst[idx] = v;
         }
     }
     for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+    __syncthreads();
+    bf16x8 efrag[10];                                   // lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) efrag[ks] = *(const bf16x8*)(R_l + (wave * 32 + r) * LDR + 16 * ks + 8 * hh);
+    __syncthreads();
     f32x16 dE[5];
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
@@ -364,15 +371,28 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // dE acc: rows = items, col = hidden channel
+    // dE acc (rows = items, col = channel) -> LDS [64 items][FLD] -> coalesced 8-byte row stores, two halves of 64 items
+    float* F_l = (float*)smem_raw;
+    const int HH = H >> 1;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((wave >> 1) == half) {
 #pragma unroll
-    for (int nb = 0; nb < 5; ++nb) {
-        const int h = 32 * nb + r;
-        if (h >= H) continue;
+            for (int nb = 0; nb < 5; ++nb) {
+                const int h = 32 * nb + r;
+                if (h < FLD) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int it = it0 + acc_row(j, hh);
-            if (it < N) a.demb1[(size_t)it * H + h] = dE[nb][j];
+                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * FLD + h] = dE[nb][j];
+                }
+            }
+        }
+        __syncthreads();
+        const int base_it = tile0 + half * 64;
+        for (int idx = tid; idx < 64 * HH; idx += 256) {
+            const int row = idx / HH, c2 = idx - row * HH;
+            if (base_it + row < N)
+                *(float2*)(a.demb1 + (size_t)(base_it + row) * H + 2 * c2) = *(const float2*)(F_l + row * FLD + 2 * c2);
         }
     }
 }
@@ -395,6 +415,17 @@ static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (si
 
 extern "C" {
 
+// shadow [rows][168] bf16 <- emb [rows][H] fp32  (initialisation / checkpoint load; ader_adam_step keeps it in sync afterwards)
+int ader_lbf_shadow_refresh(const float* emb, void* shadow, size_t rows, int H, void* stream) {
+    if (rows == 0) return 0;
+    if (H > HP) return -2;
+    size_t g = (rows * LDR + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_lbf_shadow, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, emb, (bf16*)shadow, rows, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int ader_lbf_ranges(int N, int Bp) {
     const int nblk = (N + FB - 1) / FB;
     const int nchunk = Bp / 128;
@@ -407,8 +438,9 @@ int ader_lbf_ranges(int N, int Bp) {
 // Forward of the one-hot softmax CE over items 1..N with bf16 MFMA.  Bp % 128 == 0, H even, H <= 160.
 // Scratch: rep_bf Bp*168 bf16; pm, pl: ranges*Bp floats; pO: ranges*Bp*160 floats (ranges = ader_lbf_ranges(N,Bp)).
 // Outputs: lse [Bp] (natural log), off [Bp] (backward exponent offsets), rowloss [Bp], loss [1], drep [B,H].
-int ader_lbf_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const float* wrow, void* rep_bf,
-                 float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                 void* rep_bf, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss, float* drep,
+                 void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2) return -2;
     static bool f = false;
@@ -419,7 +451,9 @@ int ader_lbf_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N
     }
     hipStream_t st = (hipStream_t)stream;
     LbfArgs a;
-    a.emb1 = emb + H; a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = ader_lbf_ranges(N, Bp);
+    if (N > item_num) return -2;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
+    a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = ader_lbf_ranges(N, Bp);
     a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
@@ -430,8 +464,8 @@ int ader_lbf_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N
 }
 
 // Table gradient rows 1..N (overwritten), including the sparse one-hot term.
-int ader_lbf_bwd_demb(const void* rep_bf, const float* emb, int B, int Bp, int H, int N, const int* lab, const float* wrow,
-                      const float* off, float* demb, void* stream) {
+int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
+                      const float* wrow, const float* off, float* demb, void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2) return -2;
     static bool f = false;
@@ -444,7 +478,9 @@ int ader_lbf_bwd_demb(const void* rep_bf, const float* emb, int B, int Bp, int H
     }
     hipStream_t st = (hipStream_t)stream;
     LbfArgs a;
-    a.emb1 = emb + H; a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
+    if (N > item_num) return -2;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
+    a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
     a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = demb + H;
     hipLaunchKernelGGL(k_lbf_bwd_de, dim3((N + 127) / 128), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_lbf_target_fix, dim3((B + 3) / 4), dim3(256), 0, st, (const bf16*)rep_bf, lab, wrow, demb + H, B, H);

@@ -271,9 +271,13 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // Dense Adam over one flat parameter buffer, TF ApplyAdam semantics (ADER.py:96):
 //   m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= (m*lr_t)/(sqrt(v)+eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host).
-// HBM-bound: 4 streams in, 3 out, 16 B per lane per access.
+// HBM-bound: 4 streams in, 3 out, 16 B per lane per access.  Optionally refreshes the bf16 shadow of the item table
+// (first `table_elems` parameters, rows of H elements -> shadow rows of 168 bf16) that the bf16 logit GEMMs stream.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                              const float* __restrict__ g, size_t n, float lr_t, float omb1, float omb2, float eps) {
+                                              const float* __restrict__ g, size_t n, float lr_t, float omb1, float omb2, float eps,
+                                              __bf16* __restrict__ shadow, size_t table_elems, int H) {
     const size_t n4 = n >> 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     float4* p4 = (float4*)p; float4* m4 = (float4*)m; float4* v4 = (float4*)v; const float4* g4 = (const float4*)g;
@@ -284,6 +288,14 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        const size_t e0 = i << 2;
+        if (shadow && e0 < table_elems) {           // H even: a pair of consecutive elements never straddles a table row
+            const size_t r0 = e0 / H, r1 = (e0 + 2) / H;
+            bf16x2_t a; a[0] = (__bf16)pp.x; a[1] = (__bf16)pp.y;
+            bf16x2_t b; b[0] = (__bf16)pp.z; b[1] = (__bf16)pp.w;
+            *(bf16x2_t*)(shadow + r0 * 168 + (e0 - r0 * H)) = a;
+            if (e0 + 2 < table_elems) *(bf16x2_t*)(shadow + r1 * 168 + (e0 + 2 - r1 * H)) = b;
+        }
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float mm = m[i], vv = v[i];
@@ -387,10 +399,11 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
 }
 
 int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,
-                   void* stream) {
+                   void* shadow, size_t table_elems, int H, void* stream) {
     if (n == 0) return 0;
+    if (shadow && ((H & 1) || (table_elems & 1))) return -2;
     hipLaunchKernelGGL(k_adam, dim3(cap_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n, lr_t,
-                       1.0f - beta1, 1.0f - beta2, eps);
+                       1.0f - beta1, 1.0f - beta2, eps, (__bf16*)shadow, table_elems, H);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -154,6 +154,9 @@ class Engine:
         self.adam_m = torch.zeros(self.P, **f32)
         self.adam_v = torch.zeros(self.P, **f32)
         self.grad = torch.zeros(self.P, **f32)
+        # bf16 shadow of the item table streamed by the bf16 logit GEMMs ([V][168], 336-B rows); Adam keeps it in sync
+        self.shadow = (torch.zeros(self.V * 168, dtype=torch.bfloat16, device=self.device)
+                       if logits_dtype == "bf16" and hidden_units % 2 == 0 else None)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, **f32)
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
@@ -198,10 +201,17 @@ class Engine:
         self.adam_v.zero_()
         self.b1p, self.b2p = np.float32(self.beta1), np.float32(self.beta2)
         self.global_step = 0
+        self.refresh_shadow()
+
+    def refresh_shadow(self):
+        """Rebuild the bf16 shadow table from the fp32 master (after init / load / any direct write to `emb`)."""
+        if self.shadow is not None:
+            call("ader_lbf_shadow_refresh", self._pp["emb"], ptr(self.shadow), self.V, self.H, self._stream())
 
     def load_params(self, params):
         for k, v in params.items():
             self.param(k).copy_(torch.as_tensor(v, dtype=torch.float32))
+        self.refresh_shadow()
 
     def export_params(self):
         return {k: self.param(k).detach().cpu().clone() for k in self.layout}
@@ -217,6 +227,7 @@ class Engine:
         self.adam_v.copy_(sd["v"])
         self.b1p, self.b2p = np.float32(sd["b1p"]), np.float32(sd["b2p"])
         self.global_step = int(sd["global_step"])
+        self.refresh_shadow()
 
     # ---------------------------------------------------------------------------------------- workspaces
     def buf(self, name, shape, dtype=torch.float32):
@@ -384,7 +395,7 @@ class Engine:
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         A = self._act
-        use_bf16 = self.logits_dtype == "bf16" and teacher is None and H % 2 == 0
+        use_bf16 = self.shadow is not None and teacher is None
         emb = self._pp["emb"]
         demb = self.gradient("emb")
         if N < self._grad_hi:   # catalog shrank (never in the reference flow): clear stale rows
@@ -403,10 +414,11 @@ class Engine:
             pO = self.buf("lbf_pO", (R * Bp * 160,))
             lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
             with self._sec("logits_fwd"):
-                call("ader_lbf_fwd", ptr(rep), emb, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO),
-                     ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
+                call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
+                     ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
             with self._sec("logits_bwd_demb"):
-                call("ader_lbf_bwd_demb", ptr(rep_bf), emb, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(off), ptr(demb), st)
+                call("ader_lbf_bwd_demb", ptr(rep_bf), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(off),
+                     ptr(demb), st)
         else:
             Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
                                    N, Np, w_train, w_ex, teacher)
@@ -495,7 +507,7 @@ class Engine:
         lr_t = float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
         with self._sec("adam"):
             call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, lr_t, self.beta1,
-                 self.beta2, self.eps, self._stream())
+                 self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
         self.b1p = np.float32(self.b1p * np.float32(self.beta1))
         self.b2p = np.float32(self.b2p * np.float32(self.beta2))
         self.global_step += 1

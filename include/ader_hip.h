@@ -109,17 +109,21 @@ int ader_rank_targets(const float* rep, const float* emb, int B, int Bp, int H, 
 /* ---- bf16-MFMA variant of the one-hot softmax CE (fp32 master table, fp32 accumulate/softmax): ADER.py:88-93 ------ */
 /* Bp % 128 == 0, H even.  Scratch: rep_bf Bp*168 bf16; pm, pl: R*Bp floats; pO: R*Bp*160 floats, R = ader_lbf_ranges(N,Bp).
  * Outputs: lse/off/rowloss [Bp], loss [1], drep [B,H] (complete: includes the one-hot target term). */
+/* `shadow`: bf16 copy of the table, [item_num+1][168] (row stride 336 B, columns >= H zero), kept in sync by
+ * ader_adam_step and (re)built by ader_lbf_shadow_refresh after initialisation / checkpoint load. */
+int ader_lbf_shadow_refresh(const float* emb, void* shadow, size_t rows, int H, void* stream);
 int ader_lbf_ranges(int N, int Bp);
-int ader_lbf_fwd(const float* rep, const float* emb, int B, int Bp, int H, int N, const int* lab, const float* wrow,
-                 void* rep_bf, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
-                 float* drep, void* stream);
+int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
+                 const float* wrow, void* rep_bf, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss,
+                 float* loss, float* drep, void* stream);
 /* demb rows 1..N overwritten (each row written once, then the sparse one-hot term is added with float atomics) */
-int ader_lbf_bwd_demb(const void* rep_bf, const float* emb, int B, int Bp, int H, int N, const int* lab,
+int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
                       const float* wrow, const float* off, float* demb, void* stream);
 
 /* ---- optimiser: tf.train.AdamOptimizer (ADER.py:96), dense over one flat buffer ------------------------ */
+/* shadow (optional, may be NULL): bf16 shadow of the first table_elems parameters (the item table, rows of H), see above */
 int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,
-                   void* stream);
+                   void* shadow, size_t table_elems, int H, void* stream);
 int ader_fill(float* p, size_t n, float value, void* stream);
 int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_rows, int n_cols, float* dst,
                       float* dst_extra, void* stream);

@@ -33,6 +33,7 @@ def _engine(item_num, T, H, L, heads, seed=0, **kw):
             eng.param(k).copy_(torch.randn(shp, generator=g) * (1.0 / np.sqrt(shp[0])))
         elif base == "emb":
             eng.param(k).copy_(torch.randn(shp, generator=g) * 0.05)
+    eng.refresh_shadow()
     return eng
 
 
@@ -199,6 +200,19 @@ def test_full_last_block_equals_pruned_last_block():
     assert abs(out[0][0] - out[1][0]) < 1e-6
     for k in out[0][1]:
         assert nerr(out[0][1][k], out[1][1][k], floor=1e-4) < 2e-5, k
+
+
+def test_adam_keeps_bf16_shadow_in_sync():
+    eng = _engine(301, 20, 64, 1, 2, logits_dtype="bf16")          # odd row count: float4 groups straddle table rows
+    g = torch.Generator().manual_seed(9)
+    for it in range(2):
+        eng.grad.copy_(torch.randn(eng.P, generator=g) * 0.01)
+        eng.adam(5e-4)
+    torch.cuda.synchronize()
+    sh = eng.shadow.view(eng.V, 168).float().cpu()
+    emb = eng.param("emb").cpu()
+    assert torch.equal(sh[:, :64], emb.bfloat16().float())
+    assert torch.all(sh[:, 64:] == 0)
 
 
 def test_adam_matches_tf_formula():
