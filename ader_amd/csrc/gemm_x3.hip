@@ -1,0 +1,332 @@
+// Block GEMMs on the bf16 matrix cores at float32-grade accuracy ("bf16x3"): every fp32 operand x is split into
+// hi = bf16(x), lo = bf16(x - hi) and a product is evaluated as hi.hi + lo.hi + hi.lo with fp32 accumulation
+// (error ~2^-16 relative per product; the dropped lo.lo term is ~2^-18).  v_mfma_f32_32x32x16_bf16 runs 16x the rate
+// of the f32 MFMA, so three of them are still > 5x faster and the kernels become bound by moving the activations
+// through the Infinity Cache rather than by the matrix pipe.
+//
+// Same operations / epilogues as gemm.hip (reference modules.py:172-174 dense Q/K/V, modules.py:254-261 conv1d(k=1)
+// FFN, and their backward products):
+//   ader_wprep       : W [H,H] fp32 -> fragment-ready bf16 (hi, lo) copies of W^T and W, rows of 168 elements
+//   ader_gemm_x3     : C[M,H] = epilogue(A[M,H] . W (+bias))   (trans_b: A . W^T)
+//   ader_gemm_atb_x3 : dW = A^T . G, db = colsum(G)   (operands read k-major from row-major LDS tiles with
+//                      ds_read_b64_tr_b16; per-workgroup slabs, deterministic reduce)
+// H <= 159 (ones-column bias trick), H even.  gfx950 only.
+#include "common.h"
+#include "../../include/ader_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define HP 160
+#define LDR 168
+#define TM 64
+#define WSZ (HP * LDR)            // elements of one prepared weight plane
+
+enum { EPI_BIAS = 0, EPI_BIAS_RELU_DROP = 1, EPI_BIAS_DROP_RES_MASK = 2, EPI_RELUDROPGRAD = 3, EPI_ADD = 4 };
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ void split2(float x, float y, bf16x2& hi, bf16x2& lo) {
+    hi[0] = (bf16)x; hi[1] = (bf16)y;
+    lo[0] = (bf16)(x - (float)hi[0]); lo[1] = (bf16)(y - (float)hi[1]);
+}
+
+// planes per weight: [0] W^T hi, [1] W^T lo, [2] W hi, [3] W lo ; plane[n][k], row stride LDR, zero padded
+__global__ __launch_bounds__(256) void k_wprep(const float* __restrict__ theta, const long* __restrict__ offs, int nw, int H,
+                                               bf16* __restrict__ out) {
+    const int w = blockIdx.y;
+    if (w >= nw) return;
+    const float* W = theta + offs[w];
+    bf16* o = out + (size_t)w * 4 * WSZ;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < WSZ; i += gridDim.x * blockDim.x) {
+        const int n = i / LDR, k = i - n * LDR;
+        const float vt = (n < H && k < H) ? W[(size_t)k * H + n] : 0.0f;     // W^T[n][k]
+        const float vn = (n < H && k < H) ? W[(size_t)n * H + k] : 0.0f;     // W[n][k]
+        const bf16 th = (bf16)vt, nh = (bf16)vn;
+        o[i] = th; o[WSZ + i] = (bf16)(vt - (float)th);
+        o[2 * WSZ + i] = nh; o[3 * WSZ + i] = (bf16)(vn - (float)nh);
+    }
+}
+
+struct GemmX3Args {
+    const float* A; const bf16* Bhi; const bf16* Blo; const float* bias; float* C;
+    const float* aux; const int* seq;
+    int M, H, row_mul, row_add;
+    DropArgs drop;
+};
+
+#define PFG 8      // float2 prefetch registers per thread (64*80/640 = 8)
+
+// 10 waves: wave w -> output columns 32*(w%5).., rows 32*(w/5).. of the 64-row tile.  B fragments live in registers.
+template <int EPI>
+__global__ __launch_bounds__(640) void k_gemm_x3(GemmX3Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* A_l = (bf16*)smem_raw;                 // [2 buffers][2 (hi,lo)][TM][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nb = wave % 5, mh = wave / 5;
+    const int H = g.H, HH = H >> 1, M = g.M;
+    bf16x8 bh[10], bl[10];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+        bh[ks] = *(const bf16x8*)(g.Bhi + (size_t)(32 * nb + r) * LDR + 16 * ks + 8 * hh);
+        bl[ks] = *(const bf16x8*)(g.Blo + (size_t)(32 * nb + r) * LDR + 16 * ks + 8 * hh);
+    }
+    for (int i = tid; i < 2 * 2 * TM * LDR / 2; i += 640) ((uint32_t*)A_l)[i] = 0u;     // K padding columns stay zero
+    const int it_first = tid / HH, c2_first = tid - it_first * HH;
+    const int it_step = 640 / HH, c2_step = 640 - it_step * HH;
+    float2 pf[PFG];
+#define GX_PREFETCH(m0_)                                                                                 \
+    {                                                                                                    \
+        int it_ = it_first, c2_ = c2_first;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PFG; ++j) {                                                \
+            float2 v_ = make_float2(0.f, 0.f);                                                           \
+            if (it_ < TM && (m0_) + it_ < M) v_ = *(const float2*)(g.A + (size_t)((m0_) + it_) * H + 2 * c2_); \
+            pf[j] = v_;                                                                                  \
+            it_ += it_step; c2_ += c2_step;                                                              \
+            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        }                                                                                                \
+    }
+#define GX_STAGE(buf_)                                                                                   \
+    {                                                                                                    \
+        bf16* hi_ = A_l + (buf_) * 2 * TM * LDR;                                                         \
+        bf16* lo_ = hi_ + TM * LDR;                                                                      \
+        int it_ = it_first, c2_ = c2_first;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PFG; ++j) {                                                \
+            if (it_ < TM) {                                                                              \
+                bf16x2 h_, l_;                                                                           \
+                split2(pf[j].x, pf[j].y, h_, l_);                                                        \
+                *(bf16x2*)(hi_ + it_ * LDR + 2 * c2_) = h_;                                              \
+                *(bf16x2*)(lo_ + it_ * LDR + 2 * c2_) = l_;                                              \
+            }                                                                                            \
+            it_ += it_step; c2_ += c2_step;                                                              \
+            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        }                                                                                                \
+    }
+    const int n_tiles = (M + TM - 1) / TM;
+    __syncthreads();
+    int tile = blockIdx.x;
+    if (tile < n_tiles) { GX_PREFETCH(tile * TM); GX_STAGE(0); }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * TM;
+        const bool more = tile + gridDim.x < n_tiles;
+        if (more) GX_PREFETCH((tile + gridDim.x) * TM);
+        const bf16* Ah = A_l + cur * 2 * TM * LDR + (32 * mh + r) * LDR + 8 * hh;
+        const bf16* Al = Ah + TM * LDR;
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) {
+            const bf16x8 ah = *(const bf16x8*)(Ah + 16 * ks);
+            const bf16x8 al = *(const bf16x8*)(Al + 16 * ks);
+            acc = mfma_bf16(al, bh[ks], acc);
+            acc = mfma_bf16(ah, bl[ks], acc);
+            acc = mfma_bf16(ah, bh[ks], acc);
+        }
+        const int n = 32 * nb + r;
+        if (n < H) {
+            const float bv = (EPI <= EPI_BIAS_DROP_RES_MASK && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = m0 + 32 * mh + acc_row(j, hh);
+                if (m >= M) continue;
+                const size_t idx = (size_t)m * H + n;
+                const int mf = m * g.row_mul + g.row_add;
+                const uint32_t didx = (uint32_t)mf * (uint32_t)H + (uint32_t)n;
+                float v = acc[j] + bv;
+                if (EPI == EPI_BIAS_RELU_DROP) {
+                    v = fmaxf(v, 0.0f);
+                    v = drop_apply(g.drop, didx, v);
+                } else if (EPI == EPI_BIAS_DROP_RES_MASK) {
+                    v = drop_apply(g.drop, didx, v);
+                    v = (g.seq[mf] != 0) ? (v + g.aux[idx]) : 0.0f;
+                } else if (EPI == EPI_RELUDROPGRAD) {
+                    v = (g.aux[idx] != 0.0f) ? v * g.drop.scale : 0.0f;
+                } else if (EPI == EPI_ADD) {
+                    v = v + g.aux[idx];
+                }
+                g.C[idx] = v;
+            }
+        }
+        if (more) GX_STAGE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+#define PFA 15     // float2 prefetch registers per operand per thread (64*75/320 = 15) ... H <= 150 here
+
+// dW_aug slab [HP][HP] per workgroup: rows = input channel (row H = ones column -> bias gradient), cols = output channel.
+// 5 waves: wave w owns input channels 32w..32w+31 and all 5 output-channel blocks (80 accumulator registers).
+__global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ slab,
+                                                      int M, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* Ah = (bf16*)smem_raw;                  // [TM][LDR] each
+    bf16* Al = Ah + TM * LDR;
+    bf16* Gh = Al + TM * LDR;
+    bf16* Gl = Gh + TM * LDR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int HH = H >> 1;
+    f32x16 acc[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[nb][j] = 0.0f;
+    for (int i = tid; i < 4 * TM * LDR / 2; i += 320) ((uint32_t*)Ah)[i] = 0u;
+    const int it_first = tid / HH, c2_first = tid - it_first * HH;
+    const int it_step = 320 / HH, c2_step = 320 - it_step * HH;
+    float2 pa[PFA], pg[PFA];
+    const int n_tiles = (M + TM - 1) / TM;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    __syncthreads();
+    int tile = blockIdx.x;
+#define AT_PREFETCH(m0_)                                                                                 \
+    {                                                                                                    \
+        int it_ = it_first, c2_ = c2_first;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PFA; ++j) {                                                \
+            float2 va_ = make_float2(0.f, 0.f), vg_ = make_float2(0.f, 0.f);                             \
+            if (it_ < TM && (m0_) + it_ < M) {                                                           \
+                va_ = *(const float2*)(A + (size_t)((m0_) + it_) * H + 2 * c2_);                         \
+                vg_ = *(const float2*)(G + (size_t)((m0_) + it_) * H + 2 * c2_);                         \
+            }                                                                                            \
+            pa[j] = va_; pg[j] = vg_;                                                                    \
+            it_ += it_step; c2_ += c2_step;                                                              \
+            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        }                                                                                                \
+    }
+#define AT_STAGE(m0_)                                                                                    \
+    {                                                                                                    \
+        int it_ = it_first, c2_ = c2_first;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PFA; ++j) {                                                \
+            if (it_ < TM) {                                                                              \
+                bf16x2 h_, l_;                                                                           \
+                split2(pa[j].x, pa[j].y, h_, l_);                                                        \
+                *(bf16x2*)(Ah + it_ * LDR + 2 * c2_) = h_; *(bf16x2*)(Al + it_ * LDR + 2 * c2_) = l_;    \
+                split2(pg[j].x, pg[j].y, h_, l_);                                                        \
+                *(bf16x2*)(Gh + it_ * LDR + 2 * c2_) = h_; *(bf16x2*)(Gl + it_ * LDR + 2 * c2_) = l_;    \
+            }                                                                                            \
+            it_ += it_step; c2_ += c2_step;                                                              \
+            if (c2_ >= HH) { c2_ -= HH; ++it_; }                                                         \
+        }                                                                                                \
+        if (tid < TM) Ah[tid * LDR + H] = (bf16)(((m0_) + tid < M) ? 1.0f : 0.0f);   /* ones column -> db */ \
+    }
+    if (tile < n_tiles) AT_PREFETCH(tile * TM);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                    // previous tile's reads are done
+        AT_STAGE(tile * TM);
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) AT_PREFETCH((tile + gridDim.x) * TM);
+#pragma unroll
+        for (int ks = 0; ks < TM / 16; ++ks) {
+            const int ro = (16 * ks + 4 * hh + q4) * LDR + 16 * g1 + 4 * p4;
+            bf16x8 ah, al;
+            {
+                const bf16x4 x0 = tr_read(Ah + ro + 32 * wave), x1 = tr_read(Ah + ro + 32 * wave + 8 * LDR);
+                const bf16x4 y0 = tr_read(Al + ro + 32 * wave), y1 = tr_read(Al + ro + 32 * wave + 8 * LDR);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ah[j] = x0[j]; ah[4 + j] = x1[j]; al[j] = y0[j]; al[4 + j] = y1[j]; }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const bf16x4 x0 = tr_read(Gh + ro + 32 * nb), x1 = tr_read(Gh + ro + 32 * nb + 8 * LDR);
+                const bf16x4 y0 = tr_read(Gl + ro + 32 * nb), y1 = tr_read(Gl + ro + 32 * nb + 8 * LDR);
+                bf16x8 gh, gl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { gh[j] = x0[j]; gh[4 + j] = x1[j]; gl[j] = y0[j]; gl[4 + j] = y1[j]; }
+                acc[nb] = mfma_bf16(al, gh, acc[nb]);
+                acc[nb] = mfma_bf16(ah, gl, acc[nb]);
+                acc[nb] = mfma_bf16(ah, gh, acc[nb]);
+            }
+        }
+    }
+    float* out = slab + (size_t)blockIdx.x * HP * HP;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) out[(size_t)(32 * wave + acc_row(j, hh)) * HP + 32 * nb + r] = acc[nb][j];
+}
+
+// ============================================================================================= C ABI
+static const size_t kGemmX3Lds = (size_t)2 * 2 * TM * LDR * sizeof(bf16);
+static const size_t kAtbX3Lds = (size_t)4 * TM * LDR * sizeof(bf16);
+
+template <int EPI>
+static int launch_x3(const GemmX3Args& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_x3<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmX3Lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int n_tiles = (g.M + TM - 1) / TM;
+    const int per = (n_tiles + 255) / 256;
+    const int grid = (n_tiles + per - 1) / per;
+    hipLaunchKernelGGL((k_gemm_x3<EPI>), dim3(grid), dim3(640), kGemmX3Lds, st, g);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+// Elements (bf16) of the prepared-weight buffer for nw weights; planes per weight: W^T hi, W^T lo, W hi, W lo.
+size_t ader_wprep_elems(int nw) { return (size_t)nw * 4 * WSZ; }
+
+// offs[nw] (device, int64): offsets of the [H,H] fp32 weights inside theta.
+int ader_wprep(const float* theta, const long* offs, int nw, int H, void* out, void* stream) {
+    if (nw <= 0) return 0;
+    if (H > HP || (H & 1)) return -2;
+    hipLaunchKernelGGL(k_wprep, dim3(32, nw), dim3(256), 0, (hipStream_t)stream, theta, offs, nw, H, (bf16*)out);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// wplanes: the 4 prepared planes of this weight (from ader_wprep); trans_b selects W (A . W^T) instead of W^T (A . W).
+int ader_gemm_x3(const float* A, const void* wplanes, const float* bias, float* C, const float* aux, const int* seq, int M, int H,
+                 int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                 unsigned drop_base, void* stream) {
+    if (M <= 0) return 0;
+    if (H > HP || H < 2 || (H & 1)) return -2;
+    GemmX3Args g;
+    const bf16* wp = (const bf16*)wplanes + (trans_b ? 2 * WSZ : 0);
+    g.A = A; g.Bhi = wp; g.Blo = wp + WSZ; g.bias = bias; g.C = C; g.aux = aux; g.seq = seq; g.M = M; g.H = H;
+    g.row_mul = row_mul; g.row_add = row_add;
+    g.drop.key = drop_key; g.drop.thr = drop_thr; g.drop.scale = drop_scale; g.drop.base = drop_base;
+    hipStream_t st = (hipStream_t)stream;
+    switch (epilogue) {
+        case EPI_BIAS: return launch_x3<EPI_BIAS>(g, st);
+        case EPI_BIAS_RELU_DROP: return launch_x3<EPI_BIAS_RELU_DROP>(g, st);
+        case EPI_BIAS_DROP_RES_MASK: return launch_x3<EPI_BIAS_DROP_RES_MASK>(g, st);
+        case EPI_RELUDROPGRAD: return launch_x3<EPI_RELUDROPGRAD>(g, st);
+        case EPI_ADD: return launch_x3<EPI_ADD>(g, st);
+        default: return -3;
+    }
+}
+
+// slab: ader_gemm_atb_slabs(M)*160*160 floats.  dW [H,H] and db [H] (may be NULL) are overwritten.
+int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream) {
+    if (M <= 0) return 0;
+    if (H >= HP || H < 2 || (H & 1) || H > 2 * PFA * 5) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_atb_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAtbX3Lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int S = ader_gemm_atb_slabs(M);
+    hipLaunchKernelGGL(k_gemm_atb_x3, dim3(S), dim3(320), kAtbX3Lds, (hipStream_t)stream, A, G, slab, M, H);
+    HIP_LAUNCH_CHECK();
+    return ader_reduce_slabs(slab, (long)HP * HP, S, HP, H, H, dW, db, stream);
+}
+
+}  // extern "C"

@@ -275,28 +275,45 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
 // (first `table_elems` parameters, rows of H elements -> shadow rows of 168 bf16) that the bf16 logit GEMMs stream.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+#define ADAM_UNROLL 4
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                               const float* __restrict__ g, size_t n, float lr_t, float omb1, float omb2, float eps,
                                               __bf16* __restrict__ shadow, size_t table_elems, int H) {
     const size_t n4 = n >> 2;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
     float4* p4 = (float4*)p; float4* m4 = (float4*)m; float4* v4 = (float4*)v; const float4* g4 = (const float4*)g;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const float4 gg = g4[i];
-#define ADAM1(f) mm.f += (gg.f - mm.f) * omb1; vv.f += (gg.f * gg.f - vv.f) * omb2; pp.f -= (mm.f * lr_t) / (sqrtf(vv.f) + eps);
-        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+    // each workgroup walks contiguous spans of 256*ADAM_UNROLL float4; all loads of a span are issued before any math
+    const size_t span = (size_t)256 * ADAM_UNROLL;
+    for (size_t base = (size_t)blockIdx.x * span; base < n4; base += (size_t)gridDim.x * span) {
+        float4 pp[ADAM_UNROLL], mm[ADAM_UNROLL], vv[ADAM_UNROLL], gg[ADAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ADAM_UNROLL; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < n4) {
+                pp[u] = p4[i]; mm[u] = m4[i]; vv[u] = v4[i];
+                const f32x4 t_ = __builtin_nontemporal_load((const f32x4*)g4 + i);   // the gradient is dead after this read
+                gg[u] = make_float4(t_[0], t_[1], t_[2], t_[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ADAM_UNROLL; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i >= n4) continue;
+#define ADAM1(f) mm[u].f += (gg[u].f - mm[u].f) * omb1; vv[u].f += (gg[u].f * gg[u].f - vv[u].f) * omb2; \
+                 pp[u].f -= (mm[u].f * lr_t) / (sqrtf(vv[u].f) + eps);
+            ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
-        const size_t e0 = i << 2;
-        if (shadow && e0 < table_elems) {           // H even: a pair of consecutive elements never straddles a table row
-            const size_t r0 = e0 / H, r1 = (e0 + 2) / H;
-            bf16x2_t a; a[0] = (__bf16)pp.x; a[1] = (__bf16)pp.y;
-            bf16x2_t b; b[0] = (__bf16)pp.z; b[1] = (__bf16)pp.w;
-            *(bf16x2_t*)(shadow + r0 * 168 + (e0 - r0 * H)) = a;
-            if (e0 + 2 < table_elems) *(bf16x2_t*)(shadow + r1 * 168 + (e0 + 2 - r1 * H)) = b;
+            p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
+            const size_t e0 = i << 2;
+            if (shadow && e0 < table_elems) {           // H even: a pair of consecutive elements never straddles a table row
+                const size_t r0 = e0 / H, r1 = (e0 + 2) / H;
+                bf16x2_t a; a[0] = (__bf16)pp[u].x; a[1] = (__bf16)pp[u].y;
+                bf16x2_t b; b[0] = (__bf16)pp[u].z; b[1] = (__bf16)pp[u].w;
+                *(bf16x2_t*)(shadow + r0 * 168 + (e0 - r0 * H)) = a;
+                if (e0 + 2 < table_elems) *(bf16x2_t*)(shadow + r1 * 168 + (e0 + 2 - r1 * H)) = b;
+            }
         }
     }
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float mm = m[i], vv = v[i];
         const float gg = g[i];
@@ -402,7 +419,7 @@ int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float
                    void* shadow, size_t table_elems, int H, void* stream) {
     if (n == 0) return 0;
     if (shadow && ((H & 1) || (table_elems & 1))) return -2;
-    hipLaunchKernelGGL(k_adam, dim3(cap_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n, lr_t,
+    hipLaunchKernelGGL(k_adam, dim3(cap_grid(n / 4 + 1, 256 * ADAM_UNROLL, 2048)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n, lr_t,
                        1.0f - beta1, 1.0f - beta2, eps, (__bf16*)shadow, table_elems, H);
     HIP_LAUNCH_CHECK();
     return 0;

@@ -134,7 +134,7 @@ class Engine:
     MAX_ROWS = 1024   # padded batch rows per launch (logits kernels keep per-row state in LDS)
 
     def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0",
-                 logits_dtype="f32"):
+                 logits_dtype="f32", gemm="x3"):
         if not torch.cuda.is_available():
             raise _lib.AderHipError("ader_amd.Engine needs an MI355X (no CPU fallback)")
         _lib.load()
@@ -157,6 +157,16 @@ class Engine:
         # bf16 shadow of the item table streamed by the bf16 logit GEMMs ([V][168], 336-B rows); Adam keeps it in sync
         self.shadow = (torch.zeros(self.V * 168, dtype=torch.bfloat16, device=self.device)
                        if logits_dtype == "bf16" and hidden_units % 2 == 0 else None)
+        # block GEMMs: "x3" = bf16 hi/lo split on the bf16 matrix cores (float32-grade accuracy), "f32" = exact f32 MFMA
+        assert gemm in ("x3", "f32")
+        self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
+        self._wnames = ["b%d.%s" % (l, w) for l in range(num_blocks) for w in ("wq", "wk", "wv", "w1", "w2")]
+        self._widx = {k: i for i, k in enumerate(self._wnames)}
+        self.wbf = None
+        if self.gemm_x3:
+            self._woffs = torch.tensor([self.layout[k][0] for k in self._wnames], dtype=torch.int64, device=self.device)
+            self.wbf = torch.zeros(call("ader_wprep_elems", len(self._wnames)), dtype=torch.bfloat16, device=self.device)
+            self._wplane = 4 * 160 * 168 * 2   # bytes per weight
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, **f32)
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
@@ -204,9 +214,15 @@ class Engine:
         self.refresh_shadow()
 
     def refresh_shadow(self):
-        """Rebuild the bf16 shadow table from the fp32 master (after init / load / any direct write to `emb`)."""
+        """Rebuild the bf16 copies derived from the fp32 master parameters (after init / load / any direct write):
+        the shadow item table of the bf16 logit GEMMs and the hi/lo weight planes of the bf16x3 block GEMMs."""
         if self.shadow is not None:
             call("ader_lbf_shadow_refresh", self._pp["emb"], ptr(self.shadow), self.V, self.H, self._stream())
+        self.refresh_weights()
+
+    def refresh_weights(self):
+        if self.wbf is not None:
+            call("ader_wprep", ptr(self.theta), ptr(self._woffs), len(self._wnames), self.H, ptr(self.wbf), self._stream())
 
     def load_params(self, params):
         for k, v in params.items():
@@ -252,10 +268,19 @@ class Engine:
     # ---------------------------------------------------------------------------------------- forward
     _ND = (0, 0, 1.0, 0)
 
-    def _gemm(self, A, W, bias, C, aux, seq, M, epi, trans=0, drop=None, rmap=(1, 0)):
+    def _gemm(self, A, wname, bname, C, aux, seq, M, epi, trans=0, drop=None, rmap=(1, 0)):
         d = drop.args() if drop is not None else self._ND
-        call("ader_gemm_rows", ptr(A), W, bias, ptr(C), ptr(aux), ptr(seq), M, self.H, epi, trans, rmap[0], rmap[1], *d,
-             self._stream())
+        bias = self._pp[bname] if bname is not None else None
+        if self.gemm_x3:
+            call("ader_gemm_x3", ptr(A), self.wbf.data_ptr() + self._widx[wname] * self._wplane, bias, ptr(C), ptr(aux), ptr(seq),
+                 M, self.H, epi, trans, rmap[0], rmap[1], *d, self._stream())
+        else:
+            call("ader_gemm_rows", ptr(A), self._pp[wname], bias, ptr(C), ptr(aux), ptr(seq), M, self.H, epi, trans, rmap[0],
+                 rmap[1], *d, self._stream())
+
+    def _atb(self, A, G, wname, bname, slab, M):
+        fn = "ader_gemm_atb_x3" if self.gemm_x3 else "ader_gemm_atb"
+        call(fn, ptr(A), ptr(G), ptr(slab), self._gp[wname], self._gp[bname], M, self.H, self._stream())
 
     def forward(self, seq, training=False, rate=0.0, step=0, save=False):
         """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward.
@@ -286,11 +311,11 @@ class Engine:
             call("ader_ln_fwd", ptr(x), H, ptr(q_in), H, pp[p + "ln1_g"], pp[p + "ln1_b"], ptr(mean1), ptr(std1), ptr(kmask),
                  ptr(qmask), rows, H, st)
             K, Vv = self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
-            self._gemm(x, pp[p + "wk"], pp[p + "bk"], K, None, None, rows, EPI_BIAS)
-            self._gemm(x, pp[p + "wv"], pp[p + "bv"], Vv, None, None, rows, EPI_BIAS)
+            self._gemm(x, p + "wk", p + "bk", K, None, None, rows, EPI_BIAS)
+            self._gemm(x, p + "wv", p + "bv", Vv, None, None, rows, EPI_BIAS)
             if not pruned:
                 Q = self.buf(n("Q"), (rows, H))
-                self._gemm(q_in, pp[p + "wq"], pp[p + "bq"], Q, None, None, rows, EPI_BIAS)
+                self._gemm(q_in, p + "wq", p + "bq", Q, None, None, rows, EPI_BIAS)
                 x1 = self.buf(n("x1"), (rows, H))
                 Pm = self.buf(n("P"), (B * self.heads * T * T,))
                 call("ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask), ptr(qmask), ptr(x1), ptr(Pm), B, T, H,
@@ -300,9 +325,9 @@ class Engine:
                 call("ader_ln_fwd", ptr(x1), H, ptr(y), H, pp[p + "ln2_g"], pp[p + "ln2_b"], ptr(mean2), ptr(std2), None, None,
                      rows, H, st)
                 h1d = self.buf(n("h1"), (rows, H))
-                self._gemm(y, pp[p + "w1"], pp[p + "b1"], h1d, None, None, rows, EPI_BIAS_RELU_DROP, drop=d1)
+                self._gemm(y, p + "w1", p + "b1", h1d, None, None, rows, EPI_BIAS_RELU_DROP, drop=d1)
                 x2 = self.buf(n("x2"), (rows, H))
-                self._gemm(h1d, pp[p + "w2"], pp[p + "b2"], x2, y, seq, rows, EPI_BIAS_DROP_RES_MASK, drop=d2)
+                self._gemm(h1d, p + "w2", p + "b2", x2, y, seq, rows, EPI_BIAS_DROP_RES_MASK, drop=d2)
                 A[l] = dict(pruned=False, x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv,
                             P=Pm, x1=x1, y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
                 x = x2
@@ -314,7 +339,7 @@ class Engine:
                 call("ader_ln_fwd", ptr(x_last), T * H, ptr(qin_l), H, pp[p + "ln1_g"], pp[p + "ln1_b"], ptr(m1l), ptr(s1l),
                      None, ptr(qml), B, H, st)
                 Ql = self.buf(n("QL"), (B, H))
-                self._gemm(qin_l, pp[p + "wq"], pp[p + "bq"], Ql, None, None, B, EPI_BIAS)
+                self._gemm(qin_l, p + "wq", p + "bq", Ql, None, None, B, EPI_BIAS)
                 x1l = self.buf(n("x1L"), (B, H))
                 Pl = self.buf(n("PL"), (B * self.heads * T,))
                 call("ader_attn_last_fwd", ptr(Ql), ptr(K), ptr(Vv), ptr(qin_l), ptr(kmask), ptr(qml), ptr(x1l), ptr(Pl), B, T, H,
@@ -324,9 +349,9 @@ class Engine:
                 call("ader_ln_fwd", ptr(x1l), H, ptr(yl), H, pp[p + "ln2_g"], pp[p + "ln2_b"], ptr(m2l), ptr(s2l), None, None,
                      B, H, st)
                 h1l = self.buf(n("h1L"), (B, H))
-                self._gemm(yl, pp[p + "w1"], pp[p + "b1"], h1l, None, None, B, EPI_BIAS_RELU_DROP, drop=d1, rmap=last_map)
+                self._gemm(yl, p + "w1", p + "b1", h1l, None, None, B, EPI_BIAS_RELU_DROP, drop=d1, rmap=last_map)
                 x2l = self.buf(n("x2L"), (B, H))
-                self._gemm(h1l, pp[p + "w2"], pp[p + "b2"], x2l, yl, seq, B, EPI_BIAS_DROP_RES_MASK, drop=d2, rmap=last_map)
+                self._gemm(h1l, p + "w2", p + "b2", x2l, yl, seq, B, EPI_BIAS_DROP_RES_MASK, drop=d2, rmap=last_map)
                 A[l] = dict(pruned=True, x=x, q_in=qin_l, mean1=m1l, std1=s1l, kmask=kmask, qmask=qml, Q=Ql, K=K, V=Vv, P=Pl,
                             x1=x1l, y=yl, mean2=m2l, std2=s2l, h1d=h1l, da=da, d1=d1, d2=d2)
                 x = x2l
@@ -468,10 +493,10 @@ class Engine:
             dqin = self.buf("bw_dqin" + tg, (M, H))
             dK, dV = self.buf("bw_dK", (rows, H)), self.buf("bw_dV", (rows, H))
             call("ader_mask_dropgrad", ptr(dxo), ptr(seq), ptr(g), ptr(dh2), M, H, rmap[0], rmap[1], *S["d2"].args(), st)
-            self._gemm(dh2, W("w2"), None, da_, S["h1d"], None, M, EPI_RELUDROPGRAD, trans=1, drop=S["d1"])
-            self._gemm(da_, W("w1"), None, dy, g, None, M, EPI_ADD, trans=1)
-            call("ader_gemm_atb", ptr(S["h1d"]), ptr(dh2), ptr(wslab), G("w2"), G("b2"), M, H, st)
-            call("ader_gemm_atb", ptr(S["y"]), ptr(da_), ptr(wslab), G("w1"), G("b1"), M, H, st)
+            self._gemm(dh2, p + "w2", None, da_, S["h1d"], None, M, EPI_RELUDROPGRAD, trans=1, drop=S["d1"])
+            self._gemm(da_, p + "w1", None, dy, g, None, M, EPI_ADD, trans=1)
+            self._atb(S["h1d"], dh2, p + "w2", p + "b2", wslab, M)
+            self._atb(S["y"], da_, p + "w1", p + "b1", wslab, M)
             call("ader_ln_bwd", ptr(dy), H, ptr(S["x1"]), H, W("ln2_g"), ptr(S["mean2"]), ptr(S["std2"]), None, 0, ptr(dx1), H,
                  ptr(wslab), G("ln2_g"), G("ln2_b"), M, H, st)
             if S["pruned"]:
@@ -480,23 +505,23 @@ class Engine:
             else:
                 call("ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
                      ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
-            self._gemm(dQ, W("wq"), None, dqin, dx1, None, M, EPI_ADD, trans=1)
+            self._gemm(dQ, p + "wq", None, dqin, dx1, None, M, EPI_ADD, trans=1)
             if S["pruned"]:
                 # LN1 backward on row T-1 only; dK/dV reach every row through the K/V projections
                 dql = self.buf("bw_dxq", (B, H))
                 call("ader_ln_bwd", ptr(dqin), H, ptr(S["x"].view(B, T, H)[:, T - 1, :]), T * H, W("ln1_g"), ptr(S["mean1"]),
                      ptr(S["std1"]), None, 0, ptr(dql), H, ptr(wslab), G("ln1_g"), G("ln1_b"), B, H, st)
-                self._gemm(dK, W("wk"), None, dxn, None, None, rows, EPI_BIAS, trans=1)
-                self._gemm(dV, W("wv"), None, dxn, dxn, None, rows, EPI_ADD, trans=1)
+                self._gemm(dK, p + "wk", None, dxn, None, None, rows, EPI_BIAS, trans=1)
+                self._gemm(dV, p + "wv", None, dxn, dxn, None, rows, EPI_ADD, trans=1)
                 call("ader_add_rows", ptr(dql), ptr(dxn), B, H, T, T - 1, st)
             else:
                 call("ader_ln_bwd", ptr(dqin), H, ptr(S["x"]), H, W("ln1_g"), ptr(S["mean1"]), ptr(S["std1"]), None, 0, ptr(dxn), H,
                      ptr(wslab), G("ln1_g"), G("ln1_b"), rows, H, st)
-                self._gemm(dK, W("wk"), None, dxn, dxn, None, rows, EPI_ADD, trans=1)
-                self._gemm(dV, W("wv"), None, dxn, dxn, None, rows, EPI_ADD, trans=1)
-            call("ader_gemm_atb", ptr(S["q_in"]), ptr(dQ), ptr(wslab), G("wq"), G("bq"), M, H, st)
-            call("ader_gemm_atb", ptr(S["x"]), ptr(dK), ptr(wslab), G("wk"), G("bk"), rows, H, st)
-            call("ader_gemm_atb", ptr(S["x"]), ptr(dV), ptr(wslab), G("wv"), G("bv"), rows, H, st)
+                self._gemm(dK, p + "wk", None, dxn, dxn, None, rows, EPI_ADD, trans=1)
+                self._gemm(dV, p + "wv", None, dxn, dxn, None, rows, EPI_ADD, trans=1)
+            self._atb(S["q_in"], dQ, p + "wq", p + "bq", wslab, M)
+            self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
+            self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
             dx, dxn = dxn, dx
         call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)
@@ -508,6 +533,7 @@ class Engine:
         with self._sec("adam"):
             call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, lr_t, self.beta1,
                  self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
+        self.refresh_weights()
         self.b1p = np.float32(self.b1p * np.float32(self.beta1))
         self.b2p = np.float32(self.b2p * np.float32(self.beta2))
         self.global_step += 1

@@ -53,6 +53,15 @@ int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, 
 int ader_gemm_atb_slabs(int M);
 /* dW[H,H] = A^T . G, db[H] = column sums of G (db may be NULL).  slab: ader_gemm_atb_slabs(M)*160*160 floats. */
 int ader_gemm_atb(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
+/* "bf16x3" variants on v_mfma_f32_32x32x16_bf16: operands split into bf16 hi+lo, 3 MFMAs per product, fp32 accumulate
+ * (float32-grade accuracy, ~2^-16 relative per product).  Same semantics/epilogues as ader_gemm_rows / ader_gemm_atb.
+ * ader_wprep builds, for nw [H,H] weights at theta+offs[i], 4 planes each of [160][168] bf16: W^T hi, W^T lo, W hi, W lo. */
+size_t ader_wprep_elems(int nw);
+int ader_wprep(const float* theta, const long* offs, int nw, int H, void* out, void* stream);
+int ader_gemm_x3(const float* A, const void* wplanes, const float* bias, float* C, const float* aux, const int* seq, int M,
+                 int H, int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr,
+                 float drop_scale, unsigned drop_base, void* stream);
+int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
                        unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);

@@ -99,9 +99,12 @@ def test_forward_matches_oracle(cfg, rate):
 
 @pytest.mark.parametrize("cfg", CFGS)
 @pytest.mark.parametrize("mode", ["vanilla", "kd", "onehot_ex"])
-def test_loss_and_gradients_match_oracle(cfg, mode):
+@pytest.mark.parametrize("gemm", ["x3", "f32"])
+def test_loss_and_gradients_match_oracle(cfg, mode, gemm):
+    """gemm="f32": exact f32 MFMA kernels; gemm="x3": bf16 hi/lo split (3 bf16 MFMAs per product, fp32 accumulate).
+    Both must meet the same float32-level tolerance against the float64 oracle."""
     item_num, T, H, L, heads, B, N = cfg
-    eng = _engine(item_num, T, H, L, heads, seed=3)
+    eng = _engine(item_num, T, H, L, heads, seed=3, gemm=gemm)
     rs = np.random.RandomState(2)
     seq = _seqs(rs, B, T, N)
     n_ex = 0 if mode == "vanilla" else max(1, B // 4)
