@@ -125,8 +125,14 @@ def layernorm(x, g, b):
 
 
 def forward_rep(params, seq, L, num_heads, *, training=False, rate=0.0, seed=0, step=0, row0=0,
-                return_intermediates=False):
-    """seq: int64/int32 [B,T].  Returns rep [B,H] (ADER.py:85)."""
+                return_intermediates=False, relu_masks=None):
+    """seq: int64/int32 [B,T].  Returns rep [B,H] (ADER.py:85).
+
+    relu_masks (optional, test aid): {block: ("all", mask[B,T,H]) | ("last", mask[B,H])} replaces relu(a) by a*mask at
+    the given rows.  ReLU is discontinuous in its derivative: an implementation whose pre-activations differ from this
+    oracle's by rounding (e.g. the bf16x3 GEMMs, ~2^-16) takes the other branch for the handful of elements with
+    |a| below that rounding, which moves gradients by O(1e-3) without being an error.  Feeding the implementation's own
+    branch decisions makes the comparison exact again."""
     seq = torch.as_tensor(seq).long()
     B, T = seq.shape
     emb = params["emb"]
@@ -163,7 +169,15 @@ def forward_rep(params, seq, L, num_heads, *, training=False, rate=0.0, seed=0, 
         x = o + q_in                                                         # modules.py:223
         inter["attn%d" % l] = x
         y = layernorm(x, params[p + "ln2_g"], params[p + "ln2_b"])           # ADER.py:77
-        h1 = torch.relu(y @ params[p + "w1"] + params[p + "b1"])             # modules.py:254-256
+        pre = y @ params[p + "w1"] + params[p + "b1"]
+        h1 = torch.relu(pre)                                                 # modules.py:254-256
+        if relu_masks is not None and l in relu_masks:
+            kind, mk = relu_masks[l]
+            mk = torch.as_tensor(mk).to(dt)
+            if kind == "all":
+                h1 = pre * mk.view(B, T, H)
+            else:
+                h1 = torch.cat([h1[:, :-1], (pre[:, -1] * mk.view(B, H)).unsqueeze(1)], 1)
         h1 = _dropout(h1, rate, training, seed, step, site_ffn1(l), row0)    # modules.py:257
         h2 = h1 @ params[p + "w2"] + params[p + "b2"]                        # modules.py:259-261
         h2 = _dropout(h2, rate, training, seed, step, site_ffn2(l), row0)    # modules.py:262
@@ -190,13 +204,15 @@ def logits_from_rep(params, rep, max_item, logits_bf16=False):
 
 
 def loss_fn(params, seq, pos, max_item, L, num_heads, *, ex_logits=None, ex_pos=None, lambda_=0.0,
-            training=True, rate=0.0, seed=0, step=0, row0=0, n_train_global=None, n_ex_global=None, logits_bf16=False):
+            training=True, rate=0.0, seed=0, step=0, row0=0, n_train_global=None, n_ex_global=None, logits_bf16=False,
+            relu_masks=None):
     """Vanilla loss (ADER.py:93) or ADER loss (ADER.py:108-137).
 
     seq holds the train rows first, exemplar rows after (main.py:229); the split point is inferred
     from the exemplar feed (ADER.py:113-115).  n_*_global override the mean denominators for the
     data-parallel shards (each rank scales its local sums by the global counts)."""
-    rep = forward_rep(params, seq, L, num_heads, training=training, rate=rate, seed=seed, step=step, row0=row0)
+    rep = forward_rep(params, seq, L, num_heads, training=training, rate=rate, seed=seed, step=step, row0=row0,
+                      relu_masks=relu_masks)
     logits = logits_from_rep(params, rep, max_item, logits_bf16)
     n_ex = 0 if (ex_logits is None and ex_pos is None) else (len(ex_logits) if ex_logits is not None else len(ex_pos))
     n_train = seq.shape[0] - n_ex
