@@ -163,7 +163,8 @@ BF16_CFGS = [  # item_num, T, H, L, heads, B, N  (tail tiles, several ranges, B 
 def test_bf16_logits_path_matches_bf16_aware_oracle(cfg, mode):
     """bf16-MFMA logits mode.  Checked (a) tightly against the oracle evaluated with the same operand rounding
     (rep and table rounded to bf16 inside the logits product, straight-through gradient): remaining differences are the
-    bf16 rounding of the probabilities fed to the second MFMA and summation order -> 3e-3 normalised; and
+    bf16 rounding of the probabilities fed to the second MFMA (relative 2^-9 = 2e-3 per element) and summation
+    order -> 6e-3 normalised; and
     (b) loosely against the exact float64 oracle: 3e-2 normalised, loss within 5e-3 relative (bf16 operand rounding)."""
     item_num, T, H, L, heads, B, N = cfg
     eng = _engine(item_num, T, H, L, heads, seed=3, logits_dtype="bf16")
@@ -194,7 +195,7 @@ def test_bf16_logits_path_matches_bf16_aware_oracle(cfg, mode):
         g = eng.gradient(k).cpu().numpy()
         eq = nerr(g, g_q[k].numpy(), floor=1e-4)
         ex = nerr(g, g_x[k].numpy(), floor=1e-4)
-        assert eq < 3e-3, (k, "vs bf16-aware oracle", eq)
+        assert eq < 6e-3, (k, "vs bf16-aware oracle", eq)
         assert ex < 3e-2, (k, "vs exact oracle", ex)
     assert np.all(eng.gradient("emb")[0].cpu().numpy() == 0)
     assert np.all(eng.gradient("emb")[N + 1:].cpu().numpy() == 0)
