@@ -43,6 +43,8 @@ _SIGS = {
     "ader_lbf_shadow_refresh": [P, P, Z, I, P],
     "ader_lbf_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
+    "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, F, F, F, F, P],
+    "ader_embed_bwd_rows": [P, P, P, I, I, I, I] + _DROP + [P],
     "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
     "ader_rank_targets": [P, P, I, I, I, I, P, P, P, P, P],
     "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P, Z, I, P],

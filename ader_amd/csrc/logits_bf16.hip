@@ -275,10 +275,29 @@ __global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, in
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// Optional fused optimiser ("the table gradient is never materialised"): when the whole gradient of a table row is
+// available inside the workgroup that owns it -- the dense logits term from the MFMAs, plus the sparse input-embedding
+// rows and one-hot target rows looked up in id-sorted lists -- the TF-Adam update of that row (ADER.py:96) is applied in
+// place from the LDS staging tile: theta/m/v are read and written once, dE is neither written nor re-read, and the
+// bf16 shadow row is refreshed on the way out.  Sparse terms are added in list order (deterministic, no atomics).
+struct FuseArgs {
+    const int* sp_ids; const int* sp_rows; int n_sp; const float* sp_src; float sp_scale;   // input-embedding rows (sorted by id)
+    const int* tg_ids; const int* tg_rows; int n_tg; const float* wrow;                      // one-hot targets (sorted by id)
+    float* emb1; float* m1; float* v1; bf16* sh1w;                                           // row of item 1 of theta/m/v/shadow
+    float lr_t, omb1, omb2, eps;
+};
+
+__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // dE tile (128 items per workgroup, 32 per wave); loops over all batch rows in chunks of 64 staged through LDS.
 #define FLD 152                    // fp32 row stride of the dE staging tile
 
-__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a) {
+template <bool ADAM>
+__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
     float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
@@ -389,10 +408,42 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a) {
         }
         __syncthreads();
         const int base_it = tile0 + half * 64;
-        for (int idx = tid; idx < 64 * HH; idx += 256) {
-            const int row = idx / HH, c2 = idx - row * HH;
-            if (base_it + row < N)
-                *(float2*)(a.demb1 + (size_t)(base_it + row) * H + 2 * c2) = *(const float2*)(F_l + row * FLD + 2 * c2);
+        if (!ADAM) {
+            for (int idx = tid; idx < 64 * HH; idx += 256) {
+                const int row = idx / HH, c2 = idx - row * HH;
+                if (base_it + row < N)
+                    *(float2*)(a.demb1 + (size_t)(base_it + row) * H + 2 * c2) = *(const float2*)(F_l + row * FLD + 2 * c2);
+            }
+        } else {
+            // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
+            const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
+            if (tid < H) {
+                for (int k = lower_bound_i32(f.sp_ids, f.n_sp, id_lo); k < f.n_sp; ++k) {
+                    const int id = f.sp_ids[k];
+                    if (id >= id_hi) break;
+                    F_l[(id - id_lo) * FLD + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
+                }
+                for (int k = lower_bound_i32(f.tg_ids, f.n_tg, id_lo); k < f.n_tg; ++k) {
+                    const int id = f.tg_ids[k];
+                    if (id >= id_hi) break;
+                    const int b = f.tg_rows[k];
+                    F_l[(id - id_lo) * FLD + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 64 * HH; idx += 256) {
+                const int row = idx / HH, c2 = idx - row * HH;
+                const int it = base_it + row;
+                if (it >= N) continue;
+                const size_t e = (size_t)it * H + 2 * c2;
+                const float2 g2 = *(const float2*)(F_l + row * FLD + 2 * c2);
+                float2 p2 = *(const float2*)(f.emb1 + e), m2 = *(const float2*)(f.m1 + e), v2 = *(const float2*)(f.v1 + e);
+                m2.x += (g2.x - m2.x) * f.omb1; v2.x += (g2.x * g2.x - v2.x) * f.omb2; p2.x -= (m2.x * f.lr_t) / (sqrtf(v2.x) + f.eps);
+                m2.y += (g2.y - m2.y) * f.omb1; v2.y += (g2.y * g2.y - v2.y) * f.omb2; p2.y -= (m2.y * f.lr_t) / (sqrtf(v2.y) + f.eps);
+                *(float2*)(f.emb1 + e) = p2; *(float2*)(f.m1 + e) = m2; *(float2*)(f.v1 + e) = v2;
+                bf16x2 sb; sb[0] = (bf16)p2.x; sb[1] = (bf16)p2.y;
+                *(bf16x2*)(f.sh1w + (size_t)it * LDR + 2 * c2) = sb;
+            }
         }
     }
 }
@@ -472,7 +523,7 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
     static int lds_set = 0;
     const size_t lds = bwd_lds(Bp);
     if (!f || (int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         f = true; lds_set = (int)lds;
     }
@@ -482,8 +533,41 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
     a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
     a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
     a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = demb + H;
-    hipLaunchKernelGGL(k_lbf_bwd_de, dim3((N + 127) / 128), dim3(256), lds, st, a);
+    FuseArgs fa = {};
+    hipLaunchKernelGGL(k_lbf_bwd_de<false>, dim3((N + 127) / 128), dim3(256), lds, st, a, fa);
     hipLaunchKernelGGL(k_lbf_target_fix, dim3((B + 3) / 4), dim3(256), 0, st, (const bf16*)rep_bf, lab, wrow, demb + H, B, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Fused: table-gradient GEMM + sparse terms + TF-Adam on table rows 1..N + shadow refresh, in one pass (single GPU).
+// sp_ids/sp_rows: the B*T input positions sorted by item id (pads = id 0 first) and their row index into sp_src [B*T,H]
+// (the masked/dropout-scaled gradient rows left by ader_embed_bwd_rows); sp_scale = sqrt(H).
+// tg_ids/tg_rows: the B labels sorted by id and their batch row.  emb/adam_m/adam_v: fp32 [item_num+1, H].
+int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                      const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale, const int* tg_ids,
+                      const int* tg_rows, int n_tg, const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t,
+                      float beta1, float beta2, float eps, void* stream) {
+    if (B <= 0) return 0;
+    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num) return -2;
+    static bool f = false;
+    static int lds_set = 0;
+    const size_t lds = bwd_lds(Bp);
+    if (!f || (int)lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        f = true; lds_set = (int)lds;
+    }
+    LbfArgs a;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
+    a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
+    a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = nullptr;
+    FuseArgs fa;
+    fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
+    fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
+    fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = (bf16*)shadow + LDR;
+    fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
+    hipLaunchKernelGGL(k_lbf_bwd_de<true>, dim3((N + 127) / 128), dim3(256), lds, (hipStream_t)stream, a, fa);
     HIP_LAUNCH_CHECK();
     return 0;
 }

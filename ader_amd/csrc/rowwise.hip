@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ seq, 
     }
 }
 
+// Same as k_embed_bwd without the scatter: leaves g = dx0 * mask * keep * scale in place (consumed by the fused
+// table update of logits_bf16.hip through an id-sorted list) -- no atomics.
+__global__ __launch_bounds__(256) void k_embed_bwd_rows(const int* __restrict__ seq, float* __restrict__ dx, int rows, int H, int V,
+                                                        DropArgs d) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    int id = seq[row];
+    if (id < 0 || id >= V) id = 0;
+    float* g = dx + (size_t)row * H;
+    for (int c = lane; c < H; c += 64) {
+        float v = 0.0f;
+        if (id != 0) {
+            v = g[c];
+            if (d.thr != 0) v = drop_keep(d, (uint32_t)row * (uint32_t)H + (uint32_t)c) ? v * d.scale : 0.0f;
+        }
+        g[c] = v;
+    }
+}
+
 // Deterministic scatter: rows pre-sorted by id (order[] = argsort(seq) stable, computed by the caller);
 // one wave per distinct id run sums its rows in order and adds once (no atomics: each id is owned by one wave).
 __global__ __launch_bounds__(256) void k_embed_bwd_sorted(const int* __restrict__ seq, const int* __restrict__ order,
@@ -355,6 +375,17 @@ int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, i
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
                        sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+    hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, unsigned drop_key, unsigned drop_thr,
+                        float drop_scale, unsigned drop_base, void* stream) {
+    const int rows = B * T;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_embed_bwd_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, rows, H, V,
+                       mk_drop(drop_key, drop_thr, drop_scale, drop_base));
     hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
     HIP_LAUNCH_CHECK();
     return 0;

@@ -178,6 +178,9 @@ class Engine:
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
         self.timer = None        # optional SectionTimer
         self.prune_last = True   # final block: query/FFN path only for position T-1 (exact; see forward())
+        # single-GPU bf16-logits steps: apply Adam to the item table inside the table-gradient GEMM (the table gradient
+        # is never written to memory); needs the complete gradient locally, so it is off whenever a grad_hook is set
+        self.fuse_adam = True
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -390,7 +393,7 @@ class Engine:
 
     # ---------------------------------------------------------------------------------------- train step
     def loss_and_grad(self, seq, pos, max_item, *, ex_pos=None, teacher=None, ex_trow=None, lambda_=0.0, rate=0.0,
-                      n_train_global=None, n_ex_global=None):
+                      n_train_global=None, n_ex_global=None, _defer_table=False):
         """Forward + backward of one step (no optimiser).  seq [B,T] holds the train rows first and the exemplar rows
         after (main.py:229); pos [n_train]; exemplars are either distilled (teacher [*,Np] + ex_trow [n_ex] row indices,
         ADER.py:132-137) or one-hot (ex_pos [n_ex], ADER.py:126-131).  Leaves the loss in self.loss (device scalar) and
@@ -421,6 +424,8 @@ class Engine:
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         A = self._act
         use_bf16 = self.shadow is not None and teacher is None
+        defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
+        self._deferred = None
         emb = self._pp["emb"]
         demb = self.gradient("emb")
         if N < self._grad_hi:   # catalog shrank (never in the reference flow): clear stale rows
@@ -441,9 +446,10 @@ class Engine:
             with self._sec("logits_fwd"):
                 call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
                      ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
-            with self._sec("logits_bwd_demb"):
-                call("ader_lbf_bwd_demb", ptr(rep_bf), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(off),
-                     ptr(demb), st)
+            if not defer:
+                with self._sec("logits_bwd_demb"):
+                    call("ader_lbf_bwd_demb", ptr(rep_bf), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow),
+                         ptr(off), ptr(demb), st)
         else:
             Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
                                    N, Np, w_train, w_ex, teacher)
@@ -523,25 +529,63 @@ class Engine:
             self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
             self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
             dx, dxn = dxn, dx
-        call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+        if defer:
+            call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+            self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)
+        else:
+            call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)
         return self.loss
 
-    def adam(self, lr):
-        """tf.train.AdamOptimizer step on every variable (dense, incl. the whole table; ADER.py:96, SURVEY A10)."""
-        lr_t = float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
-        with self._sec("adam"):
-            call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, lr_t, self.beta1,
-                 self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
+    def _lr_t(self, lr):
+        return float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
+
+    def _advance_adam(self):
         self.refresh_weights()
         self.b1p = np.float32(self.b1p * np.float32(self.beta1))
         self.b2p = np.float32(self.b2p * np.float32(self.beta2))
         self.global_step += 1
 
+    def adam(self, lr):
+        """tf.train.AdamOptimizer step on every variable (dense, incl. the whole table; ADER.py:96, SURVEY A10)."""
+        with self._sec("adam"):
+            call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, self._lr_t(lr),
+                 self.beta1, self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
+        self._advance_adam()
+
+    def _fused_table_adam(self, lr):
+        """Table rows 1..N: gradient GEMM + sparse terms + Adam in one pass (ader_lbf_bwd_adam); all other parameters:
+        the flat Adam kernel on the tail of the buffer.  Rows 0 and > N have zero gradient and zero Adam state (the
+        catalog only grows), so leaving them untouched equals the dense update."""
+        D = self._deferred
+        st = self._stream()
+        H, T = self.H, self.T
+        lr_t = self._lr_t(lr)
+        ids, order = torch.sort(D["seq"].reshape(-1), stable=True)
+        tids, torder = torch.sort(D["lab"][:D["B"]], stable=True)
+        ids, order = ids.to(torch.int32), order.to(torch.int32)
+        tids, torder = tids.to(torch.int32), torder.to(torch.int32)
+        with self._sec("logits_bwd_adam"):
+            call("ader_lbf_bwd_adam", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
+                 ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids), ptr(torder),
+                 tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
+                 self.beta2, self.eps, st)
+        span = self.layout["pos"][0]
+        with self._sec("adam"):
+            call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
+                 self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
+                 self.eps, None, 0, H, st)
+        self._deferred = None
+        self._advance_adam()
+
     def train_step(self, seq, pos, max_item, lr, **kw):
         """One `sess.run(train_op)` (main.py:233-256): forward, loss, backward, [gradient exchange], Adam.
         Returns the loss as a 1-element device tensor (no host sync)."""
-        loss = self.loss_and_grad(seq, pos, max_item, **kw)
+        fuse = self.fuse_adam and self.grad_hook is None
+        loss = self.loss_and_grad(seq, pos, max_item, _defer_table=fuse, **kw)
+        if self._deferred is not None:
+            self._fused_table_adam(lr)
+            return loss
         if self.grad_hook is not None:
             with self._sec("grad_exchange"):
                 self.grad_hook(self)

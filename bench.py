@@ -132,10 +132,14 @@ def main():
             "blocks_fwd": ("mfma", L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
             "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
             "adam": ("hbm", 7.0 * P * 4, HBM_PEAK_GBS),
+            # fused table update: theta/m/v of rows 1..N in and out + bf16 shadow row in and out (dE never hits memory)
+            "logits_bwd_adam": ("hbm", 6.0 * N * H * 4 + 2.0 * N * 336, HBM_PEAK_GBS),
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
         }
         roof = None
         if sections:
+            if "logits_bwd_adam" in sections:     # the small-parameter Adam launch is not the 7*P*4-byte kernel any more
+                work["adam"] = ("hbm", 7.0 * (P - eng.layout["pos"][0]) * 4, HBM_PEAK_GBS)
             dom = max((k for k in sections if k != "grad_exchange"), key=lambda k: sections[k])
             bound, amount, peak = work[dom]
             sec = sections[dom] * 1e-3

@@ -31,6 +31,11 @@ int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x,
 int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
                    unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
 
+/* as ader_embed_bwd but without the scatter into demb: dx is left holding the per-position gradient rows (consumed by
+ * ader_lbf_bwd_adam through an id-sorted list); dpos is overwritten. */
+int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, unsigned drop_key,
+                        unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+
 /* ---- LayerNorm: modules.py:23-50 (`normalize`) ---------------------------------------------------------- */
 /* xnz/ynz (optional) = sign(|sum_c x|), sign(|sum_c y|): the key / query masks of modules.py:188,208. */
 int ader_ln_fwd(const float* x, long x_row_stride, float* y, long y_row_stride, const float* gamma, const float* beta,
@@ -128,6 +133,14 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
 /* demb rows 1..N overwritten (each row written once, then the sparse one-hot term is added with float atomics) */
 int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
                       const float* wrow, const float* off, float* demb, void* stream);
+
+/* Fused single-GPU table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both
+ * sorted by item id) + TF-Adam on table rows 1..N of emb/adam_m/adam_v + shadow refresh.  The table gradient is never
+ * written to memory.  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t). */
+int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                      const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                      const int* tg_ids, const int* tg_rows, int n_tg, const float* wrow, float* emb, float* adam_m,
+                      float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
 
 /* ---- optimiser: tf.train.AdamOptimizer (ADER.py:96), dense over one flat buffer ------------------------ */
 /* shadow (optional, may be NULL): bf16 shadow of the first table_elems parameters (the item table, rows of H), see above */

@@ -223,6 +223,35 @@ def test_full_last_block_equals_pruned_last_block():
         assert nerr(out[0][1][k], out[1][1][k], floor=1e-4) < 5e-4, k
 
 
+@pytest.mark.parametrize("cfg", [BF16_CFGS[0], BF16_CFGS[1]])
+def test_fused_table_adam_equals_unfused_step(cfg):
+    """Engine.fuse_adam applies Adam to the item table inside the table-gradient kernel (dE never written to memory,
+    sparse terms added from id-sorted lists).  Two steps must leave the same parameters, Adam slots and bf16 shadow as
+    the unfused path (dE materialised, float-atomic scatter, flat Adam): differences are summation order only."""
+    item_num, T, H, L, heads, B, N = cfg
+    rs = np.random.RandomState(33)
+    batches = []
+    for _ in range(2):
+        seq = _seqs(rs, B, T, N)
+        seq[1, -3:] = seq[0, -1]                       # repeated ids inside the batch (several sparse rows per item)
+        pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+        pos[2] = pos[3]                                # repeated labels
+        batches.append((seq, pos))
+    states = []
+    for fuse in (True, False):
+        eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
+        eng.fuse_adam = fuse
+        for seq, pos in batches:
+            eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+        torch.cuda.synchronize()
+        states.append((eng.theta.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(),
+                       eng.shadow.float().cpu().numpy().copy()))
+    a, b = states
+    assert np.abs(a[0] - b[0]).max() < 2e-6                      # parameters (updates are O(lr) = 5e-4 per step)
+    assert nerr(a[1], b[1]) < 1e-4 and nerr(a[2], b[2]) < 1e-4   # Adam m, v
+    assert np.mean(a[3] != b[3]) < 1e-3                          # bf16 shadow: only last-bit rounding flips
+
+
 def test_adam_keeps_bf16_shadow_in_sync():
     eng = _engine(301, 20, 64, 1, 2, logits_dtype="bf16")          # odd row count: float4 groups straddle table rows
     g = torch.Generator().manual_seed(9)
