@@ -247,7 +247,10 @@ def test_fused_table_adam_equals_unfused_step(cfg):
         states.append((eng.theta.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(),
                        eng.shadow.float().cpu().numpy().copy()))
     a, b = states
-    assert np.abs(a[0] - b[0]).max() < 2e-6                      # parameters (updates are O(lr) = 5e-4 per step)
+    # parameters: Adam divides by sqrt(v)+eps, so an element whose gradient is ~eps (1e-8) turns last-bit differences of
+    # the gradient sum into O(lr) differences of the update; everything else agrees to 2e-6
+    d = np.abs(a[0] - b[0])
+    assert np.mean(d < 2e-6) > 0.999 and d.max() < 2.5e-3
     assert nerr(a[1], b[1]) < 1e-4 and nerr(a[2], b[2]) < 1e-4   # Adam m, v
     assert np.mean(a[3] != b[3]) < 1e-3                          # bf16 shadow: only last-bit rounding flips
 
