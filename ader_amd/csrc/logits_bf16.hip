@@ -431,19 +431,37 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                 }
             }
             __syncthreads();
-            for (int idx = tid; idx < 64 * HH; idx += 256) {
-                const int row = idx / HH, c2 = idx - row * HH;
-                const int it = base_it + row;
-                if (it >= N) continue;
-                const size_t e = (size_t)it * H + 2 * c2;
-                const float2 g2 = *(const float2*)(F_l + row * FLD + 2 * c2);
-                float2 p2 = *(const float2*)(f.emb1 + e), m2 = *(const float2*)(f.m1 + e), v2 = *(const float2*)(f.v1 + e);
-                m2.x += (g2.x - m2.x) * f.omb1; v2.x += (g2.x * g2.x - v2.x) * f.omb2; p2.x -= (m2.x * f.lr_t) / (sqrtf(v2.x) + f.eps);
-                m2.y += (g2.y - m2.y) * f.omb1; v2.y += (g2.y * g2.y - v2.y) * f.omb2; p2.y -= (m2.y * f.lr_t) / (sqrtf(v2.y) + f.eps);
-                *(float2*)(f.emb1 + e) = p2; *(float2*)(f.m1 + e) = m2; *(float2*)(f.v1 + e) = v2;
-                bf16x2 sb; sb[0] = (bf16)p2.x; sb[1] = (bf16)p2.y;
-                *(bf16x2*)(f.sh1w + (size_t)it * LDR + 2 * c2) = sb;
+            // Adam on the half-tile: all theta/m/v loads of a chunk are issued before any math or store
+            float* __restrict__ pe = f.emb1; float* __restrict__ pm_ = f.m1; float* __restrict__ pv = f.v1;
+            bf16* __restrict__ psh = f.sh1w;
+#define AU 5
+            for (int i0 = 0; i0 < 64 * HH; i0 += 256 * AU) {
+                float2 p2[AU], m2[AU], v2[AU];
+                size_t e[AU]; int ok[AU], fo[AU], so[AU];
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    const int idx = i0 + tid + 256 * u;
+                    const int row = idx / HH, c2 = idx - row * HH;
+                    const int it = base_it + row;
+                    ok[u] = (idx < 64 * HH) && (it < N);
+                    e[u] = (size_t)it * H + 2 * c2;
+                    fo[u] = row * FLD + 2 * c2;
+                    so[u] = 2 * c2;
+                    if (ok[u]) { p2[u] = *(const float2*)(pe + e[u]); m2[u] = *(const float2*)(pm_ + e[u]); v2[u] = *(const float2*)(pv + e[u]); }
+                }
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    if (!ok[u]) continue;
+                    const float2 g2 = *(const float2*)(F_l + fo[u]);
+                    float2 p = p2[u], m = m2[u], v = v2[u];
+                    m.x += (g2.x - m.x) * f.omb1; v.x += (g2.x * g2.x - v.x) * f.omb2; p.x -= (m.x * f.lr_t) / (sqrtf(v.x) + f.eps);
+                    m.y += (g2.y - m.y) * f.omb1; v.y += (g2.y * g2.y - v.y) * f.omb2; p.y -= (m.y * f.lr_t) / (sqrtf(v.y) + f.eps);
+                    *(float2*)(pe + e[u]) = p; *(float2*)(pm_ + e[u]) = m; *(float2*)(pv + e[u]) = v;
+                    bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;
+                    *(bf16x2*)(psh + (e[u] / H) * LDR + so[u]) = sb;
+                }
             }
+#undef AU
         }
     }
 }
