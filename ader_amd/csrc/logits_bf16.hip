@@ -431,49 +431,36 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                 }
             }
             __syncthreads();
-            // Adam on the half-tile, software-pipelined: the theta/m/v loads of chunk k+1 are in flight while chunk k is
-            // updated and stored (the kernel is HBM-bound here: keep reads outstanding across the stores)
+            // Adam on the half-tile: all theta/m/v loads of a chunk are issued before any math or store
             float* __restrict__ pe = f.emb1; float* __restrict__ pm_ = f.m1; float* __restrict__ pv = f.v1;
             bf16* __restrict__ psh = f.sh1w;
 #define AU 5
-#define ADAM_LOAD(P2, M2, V2, OK, i0_)                                                                   \
-            _Pragma("unroll") for (int u = 0; u < AU; ++u) {                                             \
-                const int idx = (i0_) + tid + 256 * u;                                                   \
-                const int row = idx / HH, c2 = idx - row * HH;                                           \
-                OK[u] = (idx < 64 * HH) && (base_it + row < N);                                          \
-                if (OK[u]) {                                                                             \
-                    const size_t e_ = (size_t)(base_it + row) * H + 2 * c2;                              \
-                    P2[u] = *(const float2*)(pe + e_); M2[u] = *(const float2*)(pm_ + e_); V2[u] = *(const float2*)(pv + e_); \
-                }                                                                                        \
-            }
-#define ADAM_APPLY(P2, M2, V2, OK, i0_)                                                                  \
-            _Pragma("unroll") for (int u = 0; u < AU; ++u) {                                             \
-                if (!OK[u]) continue;                                                                    \
-                const int idx = (i0_) + tid + 256 * u;                                                   \
-                const int row = idx / HH, c2 = idx - row * HH;                                           \
-                const size_t e_ = (size_t)(base_it + row) * H + 2 * c2;                                  \
-                const float2 g2 = *(const float2*)(F_l + row * FLD + 2 * c2);                            \
-                float2 p = P2[u], m = M2[u], v = V2[u];                                                  \
-                m.x += (g2.x - m.x) * f.omb1; v.x += (g2.x * g2.x - v.x) * f.omb2; p.x -= (m.x * f.lr_t) / (sqrtf(v.x) + f.eps); \
-                m.y += (g2.y - m.y) * f.omb1; v.y += (g2.y * g2.y - v.y) * f.omb2; p.y -= (m.y * f.lr_t) / (sqrtf(v.y) + f.eps); \
-                *(float2*)(pe + e_) = p; *(float2*)(pm_ + e_) = m; *(float2*)(pv + e_) = v;               \
-                bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;                                         \
-                *(bf16x2*)(psh + (size_t)(base_it + row) * LDR + 2 * c2) = sb;                           \
-            }
-            {
-                float2 pA[AU], mA[AU], vA[AU], pB[AU], mB[AU], vB[AU];
-                int okA[AU], okB[AU];
-                const int total = 64 * HH, stepc = 256 * AU;
-                ADAM_LOAD(pA, mA, vA, okA, 0);
-                for (int i0 = 0; i0 < total; i0 += 2 * stepc) {
-                    ADAM_LOAD(pB, mB, vB, okB, i0 + stepc);          // (all-false beyond the tile)
-                    ADAM_APPLY(pA, mA, vA, okA, i0);
-                    ADAM_LOAD(pA, mA, vA, okA, i0 + 2 * stepc);
-                    ADAM_APPLY(pB, mB, vB, okB, i0 + stepc);
+            for (int i0 = 0; i0 < 64 * HH; i0 += 256 * AU) {
+                float2 p2[AU], m2[AU], v2[AU];
+                size_t e[AU]; int ok[AU], fo[AU], so[AU];
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    const int idx = i0 + tid + 256 * u;
+                    const int row = idx / HH, c2 = idx - row * HH;
+                    const int it = base_it + row;
+                    ok[u] = (idx < 64 * HH) && (it < N);
+                    e[u] = (size_t)it * H + 2 * c2;
+                    fo[u] = row * FLD + 2 * c2;
+                    so[u] = 2 * c2;
+                    if (ok[u]) { p2[u] = *(const float2*)(pe + e[u]); m2[u] = *(const float2*)(pm_ + e[u]); v2[u] = *(const float2*)(pv + e[u]); }
+                }
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    if (!ok[u]) continue;
+                    const float2 g2 = *(const float2*)(F_l + fo[u]);
+                    float2 p = p2[u], m = m2[u], v = v2[u];
+                    m.x += (g2.x - m.x) * f.omb1; v.x += (g2.x * g2.x - v.x) * f.omb2; p.x -= (m.x * f.lr_t) / (sqrtf(v.x) + f.eps);
+                    m.y += (g2.y - m.y) * f.omb1; v.y += (g2.y * g2.y - v.y) * f.omb2; p.y -= (m.y * f.lr_t) / (sqrtf(v.y) + f.eps);
+                    *(float2*)(pe + e[u]) = p; *(float2*)(pm_ + e[u]) = m; *(float2*)(pv + e[u]) = v;
+                    bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;
+                    *(bf16x2*)(psh + (e[u] / H) * LDR + so[u]) = sb;
                 }
             }
-#undef ADAM_LOAD
-#undef ADAM_APPLY
 #undef AU
         }
     }
