@@ -247,9 +247,11 @@ __global__ __launch_bounds__(256) void k_lbf_combine(LbfArgs a, const int* __res
             et = (float)a.sh1[(size_t)t * LDR + tid];
             part = (float)a.rep_bf[(size_t)b * LDR + tid] * et;
         }
-        for (int i = 0; i < R; ++i) {
+#pragma unroll 8
+        for (int i = 0; i < R; ++i) {                      // fixed order: deterministic
             const float pm = a.pm[(size_t)i * a.Bp + b];
-            if (pm != -INFINITY) oh += a.pO[((size_t)i * a.Bp + b) * HP + tid] * __builtin_amdgcn_exp2f(pm - M);
+            const float o_ = a.pO[((size_t)i * a.Bp + b) * HP + tid];
+            oh += (pm != -INFINITY) ? o_ * __builtin_amdgcn_exp2f(pm - M) : 0.0f;
         }
     }
     red[tid] = part;

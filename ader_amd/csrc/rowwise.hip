@@ -402,7 +402,7 @@ int ader_ln_fwd(const float* x, long x_rs, float* y, long y_rs, const float* gam
 }
 
 // slab must hold ader_ln_bwd_slabs(rows) * 2 * H floats; dgamma/dbeta receive the reduced sums.
-int ader_ln_bwd_slabs(int rows) { return cap_grid((size_t)rows, 16, 256); }
+int ader_ln_bwd_slabs(int rows) { return cap_grid((size_t)rows, 16, 1024); }
 
 int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const float* gamma, const float* mean_i,
                 const float* std_i, const float* add, long add_rs, float* dx, long dx_rs, float* slab, float* dgamma,
