@@ -241,18 +241,24 @@ def test_fused_table_adam_equals_unfused_step(cfg):
     for fuse in (True, False):
         eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
         eng.fuse_adam = fuse
+        snaps = []
         for seq, pos in batches:
             eng.train_step(seq, pos, N, 5e-4, rate=0.3)
-        torch.cuda.synchronize()
-        states.append((eng.theta.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(),
-                       eng.shadow.float().cpu().numpy().copy()))
-    a, b = states
+            torch.cuda.synchronize()
+            snaps.append((eng.theta.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(),
+                          eng.shadow.float().cpu().numpy().copy()))
+        states.append(snaps)
+    (a1, a2), (b1, b2) = states
+    # after ONE step from identical state the two paths differ by summation order only
+    assert nerr(a1[1], b1[1]) < 2e-5 and nerr(a1[2], b1[2]) < 2e-5          # Adam m, v
     # parameters: Adam divides by sqrt(v)+eps, so an element whose gradient is ~eps (1e-8) turns last-bit differences of
     # the gradient sum into O(lr) differences of the update; everything else agrees to 2e-6
-    d = np.abs(a[0] - b[0])
-    assert np.mean(d < 2e-6) > 0.999 and d.max() < 2.5e-3
-    assert nerr(a[1], b[1]) < 1e-4 and nerr(a[2], b[2]) < 1e-4   # Adam m, v
-    assert np.mean(a[3] != b[3]) < 1e-3                          # bf16 shadow: only last-bit rounding flips
+    d = np.abs(a1[0] - b1[0])
+    assert np.mean(d < 2e-6) > 0.999 and d.max() < 1.1e-3
+    assert np.mean(a1[3] != b1[3]) < 1e-3                                    # bf16 shadow: last-bit rounding flips only
+    # the second step starts from (slightly) different parameters: ReLU branch flips of near-zero pre-activations then
+    # move individual gradients by O(1e-3) (see oracle.forward_rep); require agreement at that level only
+    assert nerr(a2[1], b2[1]) < 1e-2 and np.abs(a2[0] - b2[0]).max() < 2.5e-3
 
 
 def test_adam_keeps_bf16_shadow_in_sync():
