@@ -43,7 +43,9 @@ _SIGS = {
     "ader_lbf_shadow_refresh": [P, P, Z, I, P],
     "ader_lbf_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
-    "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, F, F, F, F, P],
+    "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, P],
+    "ader_fused_bucket_gran": [],
+    "ader_fused_bucket_id0": [],
     "ader_set_fused_variant": [I],
     "ader_embed_bwd_rows": [P, P, P, I, I, I, I] + _DROP + [P],
     "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
@@ -53,7 +55,7 @@ _SIGS = {
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems"}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0"}
 
 
 class AderHipError(RuntimeError):

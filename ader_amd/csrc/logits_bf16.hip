@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, in
 struct FuseArgs {
     const int* sp_ids; const int* sp_rows; int n_sp; const float* sp_src; float sp_scale;   // input-embedding rows (sorted by id)
     const int* tg_ids; const int* tg_rows; int n_tg; const float* wrow;                      // one-hot targets (sorted by id)
+    const int* sp_start; const int* tg_start;   // bucket offsets into the two lists: bucket j = ids [gran*j + id0, gran*(j+1) + id0)
     float* emb1; float* m1; float* v1; bf16* sh1w;                                           // row of item 1 of theta/m/v/shadow
     float lr_t, omb1, omb2, eps;
 };
@@ -419,13 +420,14 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
         } else {
             // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
             const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
-            if (tid < H) {
-                for (int k = lower_bound_i32(f.sp_ids, f.n_sp, id_lo); k < f.n_sp; ++k) {
+            if (tid < H && id_lo < id_hi) {
+                const int bkt = base_it >> 6;                   // buckets of 64 ids starting at id 1
+                for (int k = f.sp_start[bkt]; k < f.n_sp; ++k) {
                     const int id = f.sp_ids[k];
                     if (id >= id_hi) break;
                     F_l[(id - id_lo) * FLD + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
                 }
-                for (int k = lower_bound_i32(f.tg_ids, f.n_tg, id_lo); k < f.n_tg; ++k) {
+                for (int k = f.tg_start[bkt]; k < f.n_tg; ++k) {
                     const int id = f.tg_ids[k];
                     if (id >= id_hi) break;
                     const int b = f.tg_rows[k];
@@ -610,14 +612,17 @@ __global__ __launch_bounds__(256) void k_lbf_bwd_adam2(LbfArgs a, FuseArgs f, in
         {   // sparse terms of rows [row_lo, row_lo+32) with ids in [1, N]; thread c owns column c
             const int id_lo = max(row_lo, 1), id_hi = min(row_lo + QROWS, N + 1);
             if (tid < H && id_lo < id_hi) {
-                for (int kk = lower_bound_i32(f.sp_ids, f.n_sp, id_lo); kk < f.n_sp; ++kk) {
+                const int bkt = row_lo >> 5;                    // buckets of 32 ids starting at id 0
+                for (int kk = f.sp_start[bkt]; kk < f.n_sp; ++kk) {
                     const int id = f.sp_ids[kk];
                     if (id >= id_hi) break;
+                    if (id < id_lo) continue;                   // id 0 (padding) in bucket 0
                     Fq[(id - row_lo) * H + tid] += f.sp_src[(size_t)f.sp_rows[kk] * H + tid] * f.sp_scale;
                 }
-                for (int kk = lower_bound_i32(f.tg_ids, f.n_tg, id_lo); kk < f.n_tg; ++kk) {
+                for (int kk = f.tg_start[bkt]; kk < f.n_tg; ++kk) {
                     const int id = f.tg_ids[kk];
                     if (id >= id_hi) break;
+                    if (id < id_lo) continue;
                     const int b = f.tg_rows[kk];
                     Fq[(id - row_lo) * H + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
                 }
@@ -748,9 +753,9 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
 // (the masked/dropout-scaled gradient rows left by ader_embed_bwd_rows); sp_scale = sqrt(H).
 // tg_ids/tg_rows: the B labels sorted by id and their batch row.  emb/adam_m/adam_v: fp32 [item_num+1, H].
 int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                      const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale, const int* tg_ids,
-                      const int* tg_rows, int n_tg, const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t,
-                      float beta1, float beta2, float eps, void* stream) {
+                      const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
+                      const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
+                      float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num) return -2;
     static bool f = false;
@@ -768,6 +773,7 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
     FuseArgs fa;
     fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
     fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
+    fa.sp_start = sp_start; fa.tg_start = tg_start;
     fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = (bf16*)shadow + LDR;
     fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
     // bandwidth-oriented variant: needs one workgroup per CU worth of LDS and 16-B aligned table rows (H % 4 == 2 or 0 -> H even)
@@ -791,5 +797,8 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
 
 // 1: item-tiled register-staged update (k_lbf_bwd_de<true>); 2 (default): row-aligned LDS-DMA update (k_lbf_bwd_adam2)
 int ader_set_fused_variant(int v) { g_fused_variant = v; return 0; }
+// bucket layout the caller must use for sp_start / tg_start: granularity (ids per bucket) and first id of bucket 0
+int ader_fused_bucket_gran(void) { return g_fused_variant == 2 ? 32 : 64; }
+int ader_fused_bucket_id0(void) { return g_fused_variant == 2 ? 0 : 1; }
 
 }  // extern "C"

@@ -565,10 +565,17 @@ class Engine:
         tids, torder = torch.sort(D["lab"][:D["B"]], stable=True)
         ids, order = ids.to(torch.int32), order.to(torch.int32)
         tids, torder = tids.to(torch.int32), torder.to(torch.int32)
+        gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
+        key = (gran, id0, D["N"])
+        if getattr(self, "_bkt_key", None) != key:          # bucket boundaries depend on (variant, N) only
+            self._bkt_key = key
+            self._bkt_bounds = torch.arange(id0, D["N"] + gran + 1, gran, dtype=torch.int32, device=self.device)
+        sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
+        tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
-                 ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids), ptr(torder),
-                 tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
+                 ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
+                 ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
                  self.beta2, self.eps, st)
         span = self.layout["pos"][0]
         with self._sec("adam"):

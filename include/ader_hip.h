@@ -137,10 +137,15 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
 /* Fused single-GPU table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both
  * sorted by item id) + TF-Adam on table rows 1..N of emb/adam_m/adam_v + shadow refresh.  The table gradient is never
  * written to memory.  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t). */
+/* sp_start / tg_start: offsets of id buckets in the sorted lists: bucket j covers ids [g*j + id0, g*(j+1) + id0) with
+ * g = ader_fused_bucket_gran(), id0 = ader_fused_bucket_id0(); one entry per bucket up to the bucket containing N. */
 int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                      const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
-                      const int* tg_ids, const int* tg_rows, int n_tg, const float* wrow, float* emb, float* adam_m,
-                      float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
+                      const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src,
+                      float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
+                      const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
+                      float eps, void* stream);
+int ader_fused_bucket_gran(void);
+int ader_fused_bucket_id0(void);
 
 /* implementation variant of ader_lbf_bwd_adam: 2 (default) = row-aligned tiles + LDS-DMA, 1 = register-staged */
 int ader_set_fused_variant(int variant);
