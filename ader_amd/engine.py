@@ -181,6 +181,8 @@ class Engine:
         # single-GPU bf16-logits steps: apply Adam to the item table inside the table-gradient GEMM (the table gradient
         # is never written to memory); needs the complete gradient locally, so it is off whenever a grad_hook is set
         self.fuse_adam = True
+        import os as _os
+        call("ader_set_fused_variant", int(_os.environ.get("ADER_FUSED_VARIANT", "1")))
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
