@@ -307,11 +307,10 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int H = a.H, N = a.N;
-    // ADAM: tiles are 128 TABLE rows from a multiple of 128 (item index = row - 1), so the theta/m/v streams of a tile
-    // are 16-B aligned; table row 0 (the padding row) rides along in tile 0 and is masked out
-    const int tile0 = blockIdx.x * 128 - (ADAM ? 1 : 0);
+    const int tile0 = blockIdx.x * 128;
+    const int it0 = tile0 + wave * 32;
     {   // table tile: 128 shadow rows, contiguous -> LDS (coalesced 16-B pieces) -> operand fragments in registers
-        const uint4* src = (const uint4*)(a.sh1 + (long)tile0 * LDR);
+        const uint4* src = (const uint4*)(a.sh1 + (size_t)tile0 * LDR);
         uint4* dst = (uint4*)R_l;
         for (int idx = tid; idx < 128 * PCS_ROW; idx += 256) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -394,10 +393,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
         __syncthreads();
         cur ^= 1;
     }
-    // dE acc (rows = items, col = channel) -> LDS [64 items][fld] -> coalesced row stores, two halves of 64 items
+    // dE acc (rows = items, col = channel) -> LDS [64 items][FLD] -> coalesced 8-byte row stores, two halves of 64 items
     float* F_l = (float*)smem_raw;
     const int HH = H >> 1;
-    const int fld = ADAM ? H : FLD;            // ADAM: LDS image == memory image of the 64 rows (float4 indexable)
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -405,9 +403,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
                 const int h = 32 * nb + r;
-                if (h < fld) {
+                if (h < FLD) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * fld + h] = dE[nb][j];
+                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * FLD + h] = dE[nb][j];
                 }
             }
         }
@@ -420,62 +418,51 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                     *(float2*)(a.demb1 + (size_t)(base_it + row) * H + 2 * c2) = *(const float2*)(F_l + row * FLD + 2 * c2);
             }
         } else {
-            // table rows [id_lo, id_lo+64) of this half (id_lo a multiple of 64); valid ids are [1, N]
-            const int id_lo = base_it + 1;
-            const int id_a = max(id_lo, 1), id_b = min(id_lo + 64, N + 1);
-            if (tid < H && id_a < id_b) {        // sparse terms; thread c owns column c of every row; list order = deterministic
-                const int bkt = id_lo >> 6;
+            // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
+            const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
+            if (tid < H && id_lo < id_hi) {
+                const int bkt = base_it >> 6;                   // buckets of 64 ids starting at id 1
                 for (int k = f.sp_start[bkt]; k < f.n_sp; ++k) {
                     const int id = f.sp_ids[k];
-                    if (id >= id_b) break;
-                    if (id < id_a) continue;     // id 0 = padding positions
-                    F_l[(id - id_lo) * H + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
+                    if (id >= id_hi) break;
+                    F_l[(id - id_lo) * FLD + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
                 }
                 for (int k = f.tg_start[bkt]; k < f.n_tg; ++k) {
                     const int id = f.tg_ids[k];
-                    if (id >= id_b) break;
-                    if (id < id_a) continue;
+                    if (id >= id_hi) break;
                     const int b = f.tg_rows[k];
-                    F_l[(id - id_lo) * H + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
+                    F_l[(id - id_lo) * FLD + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
                 }
             }
             __syncthreads();
-            // Adam on the half-tile as float4 streams (16-B aligned: id_lo*H*4 is a multiple of 38400); all theta/m/v
-            // loads of a chunk are issued before any math or store.  A float4 holds two channel pairs that may belong to
-            // different rows; an invalid pair (row 0, rows > N) is written back unchanged.
-            float* __restrict__ pe = f.emb1 - H; float* __restrict__ pm_ = f.m1 - H; float* __restrict__ pv = f.v1 - H;   // row 0
-            bf16* __restrict__ psh = f.sh1w - LDR;
-            const size_t gb = (size_t)id_lo * H;
-            const int nq4 = 16 * H;                                 // float4 per 64 rows
+            // Adam on the half-tile: all theta/m/v loads of a chunk are issued before any math or store
+            float* __restrict__ pe = f.emb1; float* __restrict__ pm_ = f.m1; float* __restrict__ pv = f.v1;
+            bf16* __restrict__ psh = f.sh1w;
 #define AU 5
-            for (int i0 = 0; i0 < nq4; i0 += 256 * AU) {
-                float4 p4[AU], m4[AU], v4[AU];
-                int okb[AU];
+            for (int i0 = 0; i0 < 64 * HH; i0 += 256 * AU) {
+                float2 p2[AU], m2[AU], v2[AU];
+                size_t e[AU]; int ok[AU], fo[AU], so[AU];
 #pragma unroll
                 for (int u = 0; u < AU; ++u) {
-                    const int q = i0 + tid + 256 * u;
-                    const int e0 = 4 * q;
-                    const int rw0 = id_lo + e0 / H, rw1 = id_lo + (e0 + 2) / H;
-                    okb[u] = (q < nq4) ? ((rw0 >= 1 && rw0 <= N) ? 1 : 0) | ((rw1 >= 1 && rw1 <= N) ? 2 : 0) : 0;
-                    if (okb[u]) { p4[u] = *(const float4*)(pe + gb + e0); m4[u] = *(const float4*)(pm_ + gb + e0); v4[u] = *(const float4*)(pv + gb + e0); }
+                    const int idx = i0 + tid + 256 * u;
+                    const int row = idx / HH, c2 = idx - row * HH;
+                    const int it = base_it + row;
+                    ok[u] = (idx < 64 * HH) && (it < N);
+                    e[u] = (size_t)it * H + 2 * c2;
+                    fo[u] = row * FLD + 2 * c2;
+                    so[u] = 2 * c2;
+                    if (ok[u]) { p2[u] = *(const float2*)(pe + e[u]); m2[u] = *(const float2*)(pm_ + e[u]); v2[u] = *(const float2*)(pv + e[u]); }
                 }
 #pragma unroll
                 for (int u = 0; u < AU; ++u) {
-                    if (!okb[u]) continue;
-                    const int q = i0 + tid + 256 * u;
-                    const int e0 = 4 * q;
-                    const float4 g4 = *(const float4*)(F_l + e0);
-                    float4 p = p4[u], m = m4[u], v = v4[u];
-#define AD1(c_, bit_) if (okb[u] & bit_) { m.c_ += (g4.c_ - m.c_) * f.omb1; v.c_ += (g4.c_ * g4.c_ - v.c_) * f.omb2; \
-                                           p.c_ -= (m.c_ * f.lr_t) / (sqrtf(v.c_) + f.eps); }
-                    AD1(x, 1) AD1(y, 1) AD1(z, 2) AD1(w, 2)
-#undef AD1
-                    *(float4*)(pe + gb + e0) = p; *(float4*)(pm_ + gb + e0) = m; *(float4*)(pv + gb + e0) = v;
-                    const int rl0 = e0 / H, rl1 = (e0 + 2) / H;
-                    if (okb[u] & 1) { bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;
-                                      *(bf16x2*)(psh + (size_t)(id_lo + rl0) * LDR + (e0 - rl0 * H)) = sb; }
-                    if (okb[u] & 2) { bf16x2 sb; sb[0] = (bf16)p.z; sb[1] = (bf16)p.w;
-                                      *(bf16x2*)(psh + (size_t)(id_lo + rl1) * LDR + (e0 + 2 - rl1 * H)) = sb; }
+                    if (!ok[u]) continue;
+                    const float2 g2 = *(const float2*)(F_l + fo[u]);
+                    float2 p = p2[u], m = m2[u], v = v2[u];
+                    m.x += (g2.x - m.x) * f.omb1; v.x += (g2.x * g2.x - v.x) * f.omb2; p.x -= (m.x * f.lr_t) / (sqrtf(v.x) + f.eps);
+                    m.y += (g2.y - m.y) * f.omb1; v.y += (g2.y * g2.y - v.y) * f.omb2; p.y -= (m.y * f.lr_t) / (sqrtf(v.y) + f.eps);
+                    *(float2*)(pe + e[u]) = p; *(float2*)(pm_ + e[u]) = m; *(float2*)(pv + e[u]) = v;
+                    bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;
+                    *(bf16x2*)(psh + (e[u] / H) * LDR + so[u]) = sb;
                 }
             }
 #undef AU
@@ -803,7 +790,7 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
         HIP_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(k_lbf_bwd_de<true>, dim3((N + 1 + 127) / 128), dim3(256), lds, (hipStream_t)stream, a, fa);
+    hipLaunchKernelGGL(k_lbf_bwd_de<true>, dim3((N + 127) / 128), dim3(256), lds, (hipStream_t)stream, a, fa);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -812,6 +799,6 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
 int ader_set_fused_variant(int v) { g_fused_variant = v; return 0; }
 // bucket layout the caller must use for sp_start / tg_start: granularity (ids per bucket) and first id of bucket 0
 int ader_fused_bucket_gran(void) { return g_fused_variant == 2 ? 32 : 64; }
-int ader_fused_bucket_id0(void) { return 0; }
+int ader_fused_bucket_id0(void) { return g_fused_variant == 2 ? 0 : 1; }
 
 }  // extern "C"
