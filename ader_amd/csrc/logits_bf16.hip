@@ -298,6 +298,9 @@ __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n,
 
 // dE tile (128 items per workgroup, 32 per wave); loops over all batch rows in chunks of 64 staged through LDS.
 #define FLD 152                    // fp32 row stride of the dE staging tile
+#ifndef NT_STORES
+#define NT_STORES 1
+#endif
 
 template <bool ADAM>
 __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
@@ -460,7 +463,14 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                     float2 p = p2[u], m = m2[u], v = v2[u];
                     m.x += (g2.x - m.x) * f.omb1; v.x += (g2.x * g2.x - v.x) * f.omb2; p.x -= (m.x * f.lr_t) / (sqrtf(v.x) + f.eps);
                     m.y += (g2.y - m.y) * f.omb1; v.y += (g2.y * g2.y - v.y) * f.omb2; p.y -= (m.y * f.lr_t) / (sqrtf(v.y) + f.eps);
-                    *(float2*)(pe + e[u]) = p; *(float2*)(pm_ + e[u]) = m; *(float2*)(pv + e[u]) = v;
+                    if (NT_STORES) {   // theta/m/v of this row are not touched again this step: keep them out of the caches
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store((f32x2_t){p.x, p.y}, (f32x2_t*)(pe + e[u]));
+                        __builtin_nontemporal_store((f32x2_t){m.x, m.y}, (f32x2_t*)(pm_ + e[u]));
+                        __builtin_nontemporal_store((f32x2_t){v.x, v.y}, (f32x2_t*)(pv + e[u]));
+                    } else {
+                        *(float2*)(pe + e[u]) = p; *(float2*)(pm_ + e[u]) = m; *(float2*)(pv + e[u]) = v;
+                    }
                     bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;
                     *(bf16x2*)(psh + (e[u] / H) * LDR + so[u]) = sb;
                 }

@@ -77,6 +77,7 @@ class DataParallel:
             # identical replicas: broadcast rank 0's state once
             for t in (engine.theta, engine.adam_m, engine.adam_v):
                 dist.broadcast(t, src=0, group=group)
+            engine.refresh_shadow()          # bf16 copies derived from theta
 
     def set_rows(self, global_row0, max_item):
         self.engine.row0 = int(global_row0)

@@ -136,6 +136,18 @@ def main():
             "logits_bwd_adam": ("hbm", 6.0 * N * H * 4 + 2.0 * N * 336, HBM_PEAK_GBS),
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
         }
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
+        # --pmc WRITE_SIZE passes of this same command, gfx950 x2 read correction applied; profiles/*_pmc_hbm.json)
+        pmc_kernel = {"logits_bwd_adam": "k_lbf_bwd_de<true>", "logits_fwd": "k_lbf_fwd", "adam": "k_adam",
+                      "logits_bwd_demb": "k_lbf_bwd_de<false>"}
+        pmc = {}
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+            if files and N == 1_000_000 and B == 512:
+                pmc = json.load(open(files[-1]))["kernels"]
+        except Exception:
+            pmc = {}
         roof = None
         if sections:
             if "logits_bwd_adam" in sections:     # the small-parameter Adam launch is not the 7*P*4-byte kernel any more
@@ -148,7 +160,8 @@ def main():
             else:
                 ach, unit = amount / sec / 1e9, "GB/s"
             roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                    "traffic": None, "ms": sections[dom],
+                    "traffic": (pmc.get(pmc_kernel.get(dom, ""), {}).get("hbm_bytes") if unit == "GB/s" else None),
+                    "ms": sections[dom],
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
         cpu = None
         if not args.no_cpu_baseline:
