@@ -43,7 +43,7 @@ _SIGS = {
     "ader_lbf_shadow_refresh": [P, P, Z, I, P],
     "ader_lbf_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
-    "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, P],
+    "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P],
     "ader_fused_bucket_gran": [],
     "ader_fused_bucket_id0": [],
     "ader_set_fused_variant": [I],

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_lbf_shadow(const float* __restrict__ em
 }
 
 struct LbfArgs {
+    int tile_off;               // first 128-item tile handled by this launch (row-sharded table update)
     const bf16* sh1;            // bf16 shadow of the table, row of item 1: rows of LDR elements (336 B), cols >= H zero
     int vrows;                  // shadow rows available from sh1 (= item_num)
     const bf16* rep_bf;         // [Bp][LDR]
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int H = a.H, N = a.N;
-    const int tile0 = blockIdx.x * 128;
+    const int tile0 = (blockIdx.x + a.tile_off) * 128;
     const int it0 = tile0 + wave * 32;
     {   // table tile: 128 shadow rows, contiguous -> LDS (coalesced 16-B pieces) -> operand fragments in registers
         const uint4* src = (const uint4*)(a.sh1 + (size_t)tile0 * LDR);
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void k_lbf_bwd_adam2(LbfArgs a, FuseArgs f, in
     const int H = a.H, N = a.N;
     const int qbytes = QB(H);                                   // 19200 for H = 150
     unsigned char* land = smem_raw + 2 * 64 * LDR * sizeof(bf16) + (size_t)a.Bp * sizeof(float);   // [2][3][qbytes]
-    const int r0 = blockIdx.x * 128;                            // first table row of the tile
+    const int r0 = (blockIdx.x + a.tile_off) * 128;             // first table row of the tile
     const bf16* sh = a.sh1 - LDR;                               // shadow row 0
     const float* gsrc[3] = {f.emb1 - H, f.m1 - H, f.v1 - H};    // table row 0 of theta / m / v
     const size_t table_bytes = ((size_t)vrows_total * H * 4 + 15) & ~(size_t)15;
@@ -721,7 +722,7 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     hipStream_t st = (hipStream_t)stream;
     LbfArgs a;
     if (N > item_num) return -2;
-    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = ader_lbf_ranges(N, Bp);
     a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
@@ -748,7 +749,7 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
     hipStream_t st = (hipStream_t)stream;
     LbfArgs a;
     if (N > item_num) return -2;
-    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
     a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = demb + H;
     FuseArgs fa = {};
@@ -765,7 +766,8 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
 int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
                       const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
                       const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
-                      float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream) {
+                      float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                      int tile_count, void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num) return -2;
     static bool f = false;
@@ -777,7 +779,7 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
         f = true; lds_set = (int)lds;
     }
     LbfArgs a;
-    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
     a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = nullptr;
     FuseArgs fa;
@@ -800,7 +802,15 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
         HIP_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(k_lbf_bwd_de<true>, dim3((N + 127) / 128), dim3(256), lds, (hipStream_t)stream, a, fa);
+    {   // tiles [tile_begin, tile_begin + tile_count) of the ceil(N/128) item tiles (tile_count < 0: all)
+        const int all = (N + 127) / 128;
+        int tb = tile_begin < 0 ? 0 : tile_begin;
+        int te = tile_count < 0 ? all : tb + tile_count;
+        if (te > all) te = all;
+        if (te <= tb) return 0;
+        a.tile_off = tb;
+        hipLaunchKernelGGL(k_lbf_bwd_de<true>, dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
+    }
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -7,6 +7,13 @@ its local loss terms by the GLOBAL sub-batch sizes (1/B_train,global and lambda/
 SUM-reduced; every rank then applies the identical Adam update.  Dropout counters are keyed by the global row index
 (Engine.row0) so the masks do not depend on the number of ranks.
 
+Two exchange schemes (both give the same update as a single process on the global batch):
+  * sharded table update (default with bf16 logits, Engine._fused_table_adam_sharded): the 600 MB dense table gradient is
+    never exchanged.  Ranks all-gather the INPUTS of the table-gradient product (~16 MB each), each updates its row shard
+    of the table for the global batch inside the fused gradient+Adam kernel, and the updated rows are all-gathered
+    (half the bytes of an all-reduce, and Adam's table traffic drops by the number of ranks).
+  * dense all-reduce (f32 logits, distilled steps): below.
+
 Exchange: the gradient lives in one flat buffer (ader_amd.engine.param_layout).  It is reduced in a few large buckets
 (xGMI rings are per-link bound: few, large collectives) -- the table rows [0, max_item] first, then the small block
 parameters.  `backend="gloo"` runs the same logic on CPU tensors for the world_size-2 tests.
@@ -73,7 +80,10 @@ class DataParallel:
         self.group = group
         self.max_item = engine.item_num
         if self.world > 1:
-            engine.grad_hook = self._exchange
+            assert engine.dp_world == self.world and engine.dp_rank == self.rank, \
+                "construct the Engine with dp_rank/dp_world (the table layout is sharded at allocation time)"
+            engine.dp_group = group
+            engine.grad_hook = self._exchange          # dense path (f32 logits / distilled steps / dp_sharded = False)
             # identical replicas: broadcast rank 0's state once
             for t in (engine.theta, engine.adam_m, engine.adam_v):
                 dist.broadcast(t, src=0, group=group)
@@ -84,6 +94,7 @@ class DataParallel:
         self.max_item = int(max_item)
 
     def _exchange(self, eng):
+        dist.all_reduce(eng.loss, group=self.group)
         H = eng.H
         table_span = eng.layout["pos"][0]
         allreduce_flat(eng.grad, (self.max_item + 1) * H, table_span, group=self.group)

@@ -111,8 +111,9 @@ class _NullCtx:
 _NULL = _NullCtx()
 
 
-def param_layout(item_num, T, H, L, align=64):
-    """name -> (offset, shape) in the flat buffer; every tensor starts on a 256-byte boundary."""
+def param_layout(item_num, T, H, L, align=64, table_rows_alloc=None):
+    """name -> (offset, shape) in the flat buffer; every tensor starts on a 256-byte boundary.  `table_rows_alloc`
+    reserves extra (zero, never used) rows after the item table so that it splits into equal row shards."""
     names = [("emb", (item_num + 1, H)), ("pos", (T, H))]
     for l in range(L):
         p = "b%d." % l
@@ -126,6 +127,8 @@ def param_layout(item_num, T, H, L, align=64):
     for n, shp in names:
         layout[n] = (off, shp)
         off += int(np.prod(shp))
+        if n == "emb" and table_rows_alloc is not None:
+            off = max(off, int(table_rows_alloc) * H)
         off = (off + align - 1) // align * align
     return layout, off
 
@@ -134,7 +137,7 @@ class Engine:
     MAX_ROWS = 1024   # padded batch rows per launch (logits kernels keep per-row state in LDS)
 
     def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0",
-                 logits_dtype="f32", gemm="x3"):
+                 logits_dtype="f32", gemm="x3", dp_rank=0, dp_world=1):
         if not torch.cuda.is_available():
             raise _lib.AderHipError("ader_amd.Engine needs an MI355X (no CPU fallback)")
         _lib.load()
@@ -148,14 +151,18 @@ class Engine:
         self.logits_dtype = logits_dtype
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.layout, self.P = param_layout(item_num, maxlen, hidden_units, num_blocks)
+        # data parallelism: the item table is split into `dp_world` equal shards of whole 128-item tiles (row 0 excluded)
+        self.dp_rank, self.dp_world, self.dp_group = int(dp_rank), int(dp_world), None
+        self.shard_items = -(-item_num // (128 * self.dp_world)) * 128
+        self.V_alloc = 1 + self.dp_world * self.shard_items
+        self.layout, self.P = param_layout(item_num, maxlen, hidden_units, num_blocks, table_rows_alloc=self.V_alloc)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.theta = torch.zeros(self.P, **f32)
         self.adam_m = torch.zeros(self.P, **f32)
         self.adam_v = torch.zeros(self.P, **f32)
         self.grad = torch.zeros(self.P, **f32)
         # bf16 shadow of the item table streamed by the bf16 logit GEMMs ([V][168], 336-B rows); Adam keeps it in sync
-        self.shadow = (torch.zeros(self.V * 168, dtype=torch.bfloat16, device=self.device)
+        self.shadow = (torch.zeros(self.V_alloc * 168, dtype=torch.bfloat16, device=self.device)
                        if logits_dtype == "bf16" and hidden_units % 2 == 0 else None)
         # block GEMMs: "x3" = bf16 hi/lo split on the bf16 matrix cores (float32-grade accuracy), "f32" = exact f32 MFMA
         assert gemm in ("x3", "f32")
@@ -181,6 +188,7 @@ class Engine:
         # single-GPU bf16-logits steps: apply Adam to the item table inside the table-gradient GEMM (the table gradient
         # is never written to memory); needs the complete gradient locally, so it is off whenever a grad_hook is set
         self.fuse_adam = True
+        self.dp_sharded = True   # dp_world > 1 with bf16 logits: row-sharded table update instead of a dense all-reduce
         import os as _os
         call("ader_set_fused_variant", int(_os.environ.get("ADER_FUSED_VARIANT", "1")))
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
@@ -587,13 +595,84 @@ class Engine:
         self._deferred = None
         self._advance_adam()
 
+    def _fused_table_adam_sharded(self, lr):
+        """Data-parallel table update without the dense gradient exchange (SURVEY 8e "ZeRO-1 style"): instead of
+        SUM-reducing the 600 MB table gradient, every rank all-gathers the INPUTS of the table-gradient product (bf16
+        representations, per-row exponent offsets/labels/weights, and the sparse input-embedding gradient rows: ~16 MB per
+        rank), runs the fused gradient+Adam kernel for the GLOBAL batch on ITS shard of table rows, and the updated rows
+        are all-gathered.  Mathematically the same update as the dense all-reduce (sum over all rows of the global batch);
+        Adam m/v of the table stay sharded.  The small parameters use a plain all-reduce."""
+        import torch.distributed as dist
+        D = self._deferred
+        st = self._stream()
+        W, r, grp = self.dp_world, self.dp_rank, self.dp_group
+        H, B, Bp, N = self.H, D["B"], D["Bp"], D["N"]
+        lr_t = self._lr_t(lr)
+
+        def ag(t):
+            t = t.contiguous()
+            out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t, group=grp)
+            return out
+
+        with self._sec("grad_exchange"):
+            rep_g, off_g = ag(D["rep_bf"]), ag(D["off"])
+            lab_g, w_g = ag(D["lab"]), ag(D["wrow"])
+            seq_g, g_g = ag(D["seq"]), ag(D["g"])
+            span = self.layout["pos"][0]
+            dist.all_reduce(self.grad[span:], group=grp)
+            dist.all_reduce(self.loss, group=grp)
+        ids, order = torch.sort(seq_g.reshape(-1), stable=True)
+        tids, torder = torch.sort(lab_g.reshape(-1), stable=True)
+        ids, order, tids, torder = ids.to(torch.int32), order.to(torch.int32), tids.to(torch.int32), torder.to(torch.int32)
+        gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
+        key = (gran, id0, N)
+        if getattr(self, "_bkt_key", None) != key:
+            self._bkt_key = key
+            self._bkt_bounds = torch.arange(id0, N + gran + 1, gran, dtype=torch.int32, device=self.device)
+        sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
+        tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
+        tiles = self.shard_items // 128
+        with self._sec("logits_bwd_adam"):
+            call("ader_lbf_bwd_adam", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+                 ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
+                 ptr(torder), ptr(tg_start), tids.numel(), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
+                 self.beta1, self.beta2, self.eps, r * tiles, tiles, st)
+        with self._sec("param_allgather"):
+            S = self.shard_items * H
+            table = self.theta[H:H + W * S]                       # rows 1 .. W*shard_items
+            own = table[r * S:(r + 1) * S].clone()
+            dist.all_gather_into_tensor(table, own, group=grp)
+            if self.shadow is not None:                           # bf16 shadow rows of the other shards
+                call("ader_lbf_shadow_refresh", self._pp["emb"], ptr(self.shadow), self.V, H, st)
+        with self._sec("adam"):
+            call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
+                 self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
+                 self.eps, None, 0, H, st)
+        self._deferred = None
+        self._advance_adam()
+
+    def gather_table_state(self):
+        """Sharded mode: make adam_m / adam_v of the table complete on every rank (before checkpointing)."""
+        if self.dp_world > 1 and self.dp_sharded:
+            import torch.distributed as dist
+            H, S = self.H, self.shard_items * self.H
+            for buf in (self.adam_m, self.adam_v):
+                table = buf[H:H + self.dp_world * S]
+                own = table[self.dp_rank * S:(self.dp_rank + 1) * S].clone()
+                dist.all_gather_into_tensor(table, own, group=self.dp_group)
+
     def train_step(self, seq, pos, max_item, lr, **kw):
         """One `sess.run(train_op)` (main.py:233-256): forward, loss, backward, [gradient exchange], Adam.
         Returns the loss as a 1-element device tensor (no host sync)."""
-        fuse = self.fuse_adam and self.grad_hook is None
+        sharded = self.dp_world > 1 and self.dp_sharded
+        fuse = self.fuse_adam and (self.grad_hook is None or sharded)
         loss = self.loss_and_grad(seq, pos, max_item, _defer_table=fuse, **kw)
         if self._deferred is not None:
-            self._fused_table_adam(lr)
+            if sharded:
+                self._fused_table_adam_sharded(lr)
+            else:
+                self._fused_table_adam(lr)
             return loss
         if self.grad_hook is not None:
             with self._sec("grad_exchange"):

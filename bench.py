@@ -85,7 +85,8 @@ def main():
     torch.cuda.set_device(dev)
 
     N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, 0.3, 5e-4
-    eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits)
+    eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits,
+                 dp_rank=rank, dp_world=world)
     dp = adist.DataParallel(eng, rank, world)
     dp.set_rows(rank * B, N)
     nbatch = 4
@@ -135,6 +136,7 @@ def main():
             # fused table update: theta/m/v of rows 1..N in and out + bf16 shadow row in and out (dE never hits memory)
             "logits_bwd_adam": ("hbm", 6.0 * N * H * 4 + 2.0 * N * 336, HBM_PEAK_GBS),
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
+            "param_allgather": ("hbm", 0.0, HBM_PEAK_GBS),
         }
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE passes of this same command, gfx950 x2 read correction applied; profiles/*_pmc_hbm.json)
@@ -152,7 +154,7 @@ def main():
         if sections:
             if "logits_bwd_adam" in sections:     # the small-parameter Adam launch is not the 7*P*4-byte kernel any more
                 work["adam"] = ("hbm", 7.0 * (P - eng.layout["pos"][0]) * 4, HBM_PEAK_GBS)
-            dom = max((k for k in sections if k != "grad_exchange"), key=lambda k: sections[k])
+            dom = max((k for k in sections if k not in ("grad_exchange", "param_allgather")), key=lambda k: sections[k])
             bound, amount, peak = work[dom]
             sec = sections[dom] * 1e-3
             if bound == "mfma":
@@ -177,6 +179,9 @@ def main():
             "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, dense regime (BASELINE.json configs[4])",
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam",
+                       "exchange": ("none" if world == 1 else
+                                    ("row-sharded table update + all-gather" if (eng.dp_sharded and eng.shadow is not None)
+                                     else "dense gradient all-reduce")),
                        "precision": ("logit GEMMs bf16 operands / fp32 accumulate+softmax; blocks, optimizer, master weights fp32"
                                      if args.logits == "bf16" else "fp32 throughout"), "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,

@@ -143,7 +143,9 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
                       const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src,
                       float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
                       const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
-                      float eps, void* stream);
+                      float eps, int tile_begin, int tile_count, void* stream);
+/* tile_begin/tile_count: restrict the update to 128-item tiles [tile_begin, tile_begin+tile_count) (row-sharded table
+ * update under data parallelism; tile_count < 0 = all tiles).  B/Bp then describe the GLOBAL batch. */
 int ader_fused_bucket_gran(void);
 int ader_fused_bucket_id0(void);
 

@@ -27,9 +27,10 @@ def _data():
     return seq, pos
 
 
-def _engine(logits):
+def _engine(logits, rank=0, world=1):
     from ader_amd.engine import Engine
-    eng = Engine(ITEMS, maxlen=T, hidden_units=H, num_blocks=L, num_heads=HEADS, seed=4, logits_dtype=logits)
+    eng = Engine(ITEMS, maxlen=T, hidden_units=H, num_blocks=L, num_heads=HEADS, seed=4, logits_dtype=logits,
+                 dp_rank=rank, dp_world=world)
     g = torch.Generator().manual_seed(2)
     for k in eng.layout:
         if k.endswith("_b"):
@@ -38,33 +39,34 @@ def _engine(logits):
     return eng
 
 
-def _worker(rank, world, port, out, logits):
+def _worker(rank, world, port, out, logits, sharded):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ader_amd import dist as adist
     seq, pos = _data()
-    eng = _engine(logits)
+    eng = _engine(logits, rank, world)
+    eng.dp_sharded = sharded
     dp = adist.DataParallel(eng, rank, world)
     lo, hi = adist.shard_bounds(B, world, rank)
     for step in range(2):
         dp.set_rows(lo, N)
         eng.train_step(seq[lo:hi], pos[lo:hi], N, 5e-4, rate=0.3, n_train_global=B)
     torch.cuda.synchronize()
-    if rank == 0:
-        torch.save(eng.theta.cpu(), out)
+    if rank == 1:          # the last rank: its own table shard and the gathered ones must both be right
+        torch.save(eng.theta.cpu()[:(ITEMS + 1) * H], out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("logits", ["f32", "bf16"])
-def test_two_ranks_match_single_process(logits):
+@pytest.mark.parametrize("logits,sharded", [("f32", False), ("bf16", False), ("bf16", True)])
+def test_two_ranks_match_single_process(logits, sharded):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "theta.pt")
-        mp.spawn(_worker, args=(2, port, out, logits), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, out, logits, sharded), nprocs=2, join=True)
         got = torch.load(out).numpy()
     seq, pos = _data()
     eng = _engine(logits)
@@ -72,7 +74,7 @@ def test_two_ranks_match_single_process(logits):
     for step in range(2):
         eng.train_step(seq, pos, N, 5e-4, rate=0.3)
     torch.cuda.synchronize()
-    ref = eng.theta.cpu().numpy()
+    ref = eng.theta.cpu().numpy()[:(ITEMS + 1) * H]
     d = np.abs(got - ref)
     # same masks (dropout keyed by global row), same math; differences: summation order of the row reductions, Adam's
     # eps-scale sensitivity for ~zero gradients, and (second step) ReLU branch flips -- see test_gpu_parity
