@@ -585,8 +585,8 @@ class Engine:
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
                  ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
-                 ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
-                 self.beta2, self.eps, st)
+                 ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
+                 self.beta1, self.beta2, self.eps, 0, -1, st)
         span = self.layout["pos"][0]
         with self._sec("adam"):
             call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
@@ -609,10 +609,10 @@ class Engine:
         H, B, Bp, N = self.H, D["B"], D["Bp"], D["N"]
         lr_t = self._lr_t(lr)
 
-        def ag(t):
+        def ag(t):                      # [W, *t.shape]; moved as raw bytes (any dtype, any backend)
             t = t.contiguous()
             out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t, group=grp)
+            dist.all_gather_into_tensor(out.view(torch.uint8).view(-1), t.view(torch.uint8).view(-1), group=grp)
             return out
 
         with self._sec("grad_exchange"):
