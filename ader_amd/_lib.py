@@ -30,6 +30,8 @@ _SIGS = {
     "ader_attn_last_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_attn_last_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_attn_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_attn_x3_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_attn_x3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_attn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_logits_sub": [I],
     "ader_logits_parts": [I],

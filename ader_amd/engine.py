@@ -167,6 +167,7 @@ class Engine:
         # block GEMMs: "x3" = bf16 hi/lo split on the bf16 matrix cores (float32-grade accuracy), "f32" = exact f32 MFMA
         assert gemm in ("x3", "f32")
         self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
+        self.attn_x3 = gemm == "x3" and (hidden_units // num_heads) % 2 == 0      # bf16x3 attention core (attn_x3.hip)
         self._wnames = ["b%d.%s" % (l, w) for l in range(num_blocks) for w in ("wq", "wk", "wv", "w1", "w2")]
         self._widx = {k: i for i, k in enumerate(self._wnames)}
         self.wbf = None
@@ -331,8 +332,8 @@ class Engine:
                 self._gemm(q_in, p + "wq", p + "bq", Q, None, None, rows, EPI_BIAS)
                 x1 = self.buf(n("x1"), (rows, H))
                 Pm = self.buf(n("P"), (B * self.heads * T * T,))
-                call("ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask), ptr(qmask), ptr(x1), ptr(Pm), B, T, H,
-                     self.heads, *da.args(), st)
+                call("ader_attn_x3_fwd" if self.attn_x3 else "ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask),
+                     ptr(qmask), ptr(x1), ptr(Pm), B, T, H, self.heads, *da.args(), st)
                 y = self.buf(n("y"), (rows, H))
                 mean2, std2 = self.buf(n("m2"), (rows,)), self.buf(n("s2"), (rows,))
                 call("ader_ln_fwd", ptr(x1), H, ptr(y), H, pp[p + "ln2_g"], pp[p + "ln2_b"], ptr(mean2), ptr(std2), None, None,
@@ -519,8 +520,9 @@ class Engine:
                 call("ader_attn_last_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
                      ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
             else:
-                call("ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
-                     ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
+                call("ader_attn_x3_bwd" if self.attn_x3 else "ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]),
+                     ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads,
+                     *S["da"].args(), st)
             self._gemm(dQ, p + "wq", None, dqin, dx1, None, M, EPI_ADD, trans=1)
             if S["pruned"]:
                 # LN1 backward on row T-1 only; dK/dV reach every row through the K/V projections

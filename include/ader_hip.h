@@ -81,6 +81,15 @@ int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
                   const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads,
                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
 
+/* bf16x3 variants (hi/lo operand split on v_mfma_f32_32x32x16_bf16, float32-grade accuracy); dh = H/heads even.
+ * PT is stored transposed ([B,heads,key,query]) and is private to this fwd/bwd pair. */
+int ader_attn_x3_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask,
+                     const float* qmask, float* out, float* PT, int B, int T, int H, int heads, unsigned drop_key,
+                     unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+int ader_attn_x3_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* PT, const float* kmask,
+                     const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads,
+                     unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+
 /* Last block: only position T-1 feeds the representation (ADER.py:85), so its attention needs one query row per sequence
  * (exact).  Q_last, q_in_last, out_last, dQ_last: [B,H]; K, V, dK, dV: [B,T,H]; P_last: [B,heads,T]; qmask_last: [B]. */
 int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, const float* q_in_last, const float* kmask,
