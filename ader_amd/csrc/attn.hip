@@ -275,10 +275,22 @@ __global__ __launch_bounds__(256) void k_attn_last_fwd(AttnLastArgs a) {
     const int b = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
     const int T = a.T, H = a.H, dh = H / a.heads, c0 = head * dh;
     const size_t base = (size_t)b * T * H;
-    for (int i = tid; i < T * dh; i += 256) {
-        const int t = i / dh, c = i - t * dh;
-        K_l[t * LAST_LD + c] = a.K[base + (size_t)t * H + c0 + c];
-        V_l[t * LAST_LD + c] = a.V[base + (size_t)t * H + c0 + c];
+    for (int i0 = 0; i0 < T * dh; i0 += 256 * 8) {          // 16 independent loads in flight per thread (latency-bound staging)
+        float kv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + tid + 256 * u;
+            const int t = i / dh, c = i - t * dh;
+            const bool ok = i < T * dh;
+            kv[u] = ok ? a.K[base + (size_t)t * H + c0 + c] : 0.0f;
+            vv[u] = ok ? a.V[base + (size_t)t * H + c0 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + tid + 256 * u;
+            const int t = i / dh, c = i - t * dh;
+            if (i < T * dh) { K_l[t * LAST_LD + c] = kv[u]; V_l[t * LAST_LD + c] = vv[u]; }
+        }
     }
     for (int c = tid; c < dh; c += 256) q_l[c] = a.Ql[(size_t)b * H + c0 + c];
     __syncthreads();
@@ -321,10 +333,22 @@ __global__ __launch_bounds__(256) void k_attn_last_bwd(AttnLastArgs a) {
     const int b = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
     const int T = a.T, H = a.H, dh = H / a.heads, c0 = head * dh;
     const size_t base = (size_t)b * T * H;
-    for (int i = tid; i < T * dh; i += 256) {
-        const int t = i / dh, c = i - t * dh;
-        K_l[t * LAST_LD + c] = a.K[base + (size_t)t * H + c0 + c];
-        V_l[t * LAST_LD + c] = a.V[base + (size_t)t * H + c0 + c];
+    for (int i0 = 0; i0 < T * dh; i0 += 256 * 8) {          // 16 independent loads in flight per thread (latency-bound staging)
+        float kv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + tid + 256 * u;
+            const int t = i / dh, c = i - t * dh;
+            const bool ok = i < T * dh;
+            kv[u] = ok ? a.K[base + (size_t)t * H + c0 + c] : 0.0f;
+            vv[u] = ok ? a.V[base + (size_t)t * H + c0 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + tid + 256 * u;
+            const int t = i / dh, c = i - t * dh;
+            if (i < T * dh) { K_l[t * LAST_LD + c] = kv[u]; V_l[t * LAST_LD + c] = vv[u]; }
+        }
     }
     for (int c = tid; c < dh; c += 256) { q_l[c] = a.Ql[(size_t)b * H + c0 + c]; g_l[c] = a.res[(size_t)b * H + c0 + c]; }
     __syncthreads();

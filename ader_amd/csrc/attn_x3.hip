@@ -49,14 +49,26 @@ struct AttnX3Args {
 // dst_hi/lo[t][c] = split(src[t][c0 + c]) for t < T, c < dh (pairs); padding untouched (zeroed once by the caller)
 __device__ __forceinline__ void stage_split(bf16* Th, bf16* Tl, const float* __restrict__ src, int T, int H, int c0, int dh, int tid) {
     const int HH = dh >> 1, n2 = T * HH;
-    for (int idx = tid; idx < n2; idx += 128) {
-        const int t = idx / HH, c2 = idx - t * HH;
-        const float2 v = *(const float2*)(src + (size_t)t * H + c0 + 2 * c2);
-        bf16x2 h, l;
-        h[0] = (bf16)v.x; h[1] = (bf16)v.y;
-        l[0] = (bf16)(v.x - (float)h[0]); l[1] = (bf16)(v.y - (float)h[1]);
-        *(bf16x2*)(Th + t * LDR + 2 * c2) = h;
-        *(bf16x2*)(Tl + t * LDR + 2 * c2) = l;
+    // 8 independent loads in flight per thread before any conversion (the tile comes from L2 / Infinity Cache: latency-bound)
+    for (int i0 = 0; i0 < n2; i0 += 128 * 8) {
+        float2 v[8];
+        int t[8], c2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + tid + 128 * u;
+            t[u] = idx / HH; c2[u] = idx - t[u] * HH;
+            v[u] = (idx < n2) ? *(const float2*)(src + (size_t)t[u] * H + c0 + 2 * c2[u]) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + tid + 128 * u < n2) {
+                bf16x2 h, l;
+                h[0] = (bf16)v[u].x; h[1] = (bf16)v[u].y;
+                l[0] = (bf16)(v[u].x - (float)h[0]); l[1] = (bf16)(v[u].y - (float)h[1]);
+                *(bf16x2*)(Th + t[u] * LDR + 2 * c2[u]) = h;
+                *(bf16x2*)(Tl + t[u] * LDR + 2 * c2[u]) = l;
+            }
+        }
     }
 }
 
