@@ -207,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
 }
 
 // One workgroup per batch row: merge range partials -> lse (natural log), loss row, dRep row, backward offset.
-__global__ __launch_bounds__(256) void k_lbf_combine(LbfArgs a, const int* __restrict__ lab, const float* __restrict__ wrow,
+// 640 threads: thread (g = tid/160, h = tid%160) sums ranges i = g mod 4 of channel h (fixed order: deterministic).
+__global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __restrict__ lab, const float* __restrict__ wrow,
                                                      float* __restrict__ lse, float* __restrict__ off, float* __restrict__ rowloss,
                                                      float* __restrict__ drep) {
-    __shared__ float red[256];
+    __shared__ float sc[1024];          // per-range scale 2^(pm - M) (0 for empty ranges)
+    __shared__ float red[640];
     __shared__ float sM, sL;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int R = a.ranges, H = a.H;
@@ -219,48 +221,60 @@ __global__ __launch_bounds__(256) void k_lbf_combine(LbfArgs a, const int* __res
         return;
     }
     float m = -INFINITY;
-    for (int i = tid; i < R; i += 256) m = fmaxf(m, a.pm[(size_t)i * a.Bp + b]);
+    for (int i = tid; i < R; i += 640) m = fmaxf(m, a.pm[(size_t)i * a.Bp + b]);
     red[tid] = m;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    if (tid == 0) sM = red[0];
+    if (tid < 64) {
+        float v = red[tid];
+        for (int k = tid + 64; k < 640; k += 64) v = fmaxf(v, red[k]);
+        v = wave_max(v);
+        if (tid == 0) sM = v;
+    }
     __syncthreads();
     const float M = sM;
     float l = 0.0f;
-    for (int i = tid; i < R; i += 256) {
+    for (int i = tid; i < R; i += 640) {
         const float pm = a.pm[(size_t)i * a.Bp + b];
-        if (pm != -INFINITY) l += a.pl[(size_t)i * a.Bp + b] * __builtin_amdgcn_exp2f(pm - M);
+        const float s_ = (pm != -INFINITY) ? __builtin_amdgcn_exp2f(pm - M) : 0.0f;
+        sc[i] = s_;
+        l += a.pl[(size_t)i * a.Bp + b] * s_;
     }
     red[tid] = l;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    if (tid == 0) sL = red[0];
+    if (tid == 0) {                                  // fixed order
+        float v = 0.0f;
+        for (int k = 0; k < 640; ++k) v += red[k];
+        sL = v;
+    }
     __syncthreads();
     const float L = sL;
     const float lse2 = M + log2f(L);
     const int t = lab[b] - 1;
     const float w = wrow[b];
-    // target logit with the same bf16-rounded operands as the MFMA path
-    float part = 0.0f;
-    float et = 0.0f, oh = 0.0f;
+    const int g = tid / 160, h = tid - g * 160;
+    float oh = 0.0f;
+    if (h < H) {
+#pragma unroll 8
+        for (int i = g; i < R; i += 4) oh += a.pO[((size_t)i * a.Bp + b) * HP + h] * sc[i];
+    }
+    __syncthreads();
+    red[tid] = oh;
+    __syncthreads();
+    float part = 0.0f, et = 0.0f;
     if (tid < H) {
-        if (t >= 0) {
+        oh = ((red[tid] + red[160 + tid]) + red[320 + tid]) + red[480 + tid];
+        if (t >= 0) {                                // target logit with the same bf16-rounded operands as the MFMA path
             et = (float)a.sh1[(size_t)t * LDR + tid];
             part = (float)a.rep_bf[(size_t)b * LDR + tid] * et;
         }
-#pragma unroll 8
-        for (int i = 0; i < R; ++i) {                      // fixed order: deterministic
-            const float pm = a.pm[(size_t)i * a.Bp + b];
-            const float o_ = a.pO[((size_t)i * a.Bp + b) * HP + tid];
-            oh += (pm != -INFINITY) ? o_ * __builtin_amdgcn_exp2f(pm - M) : 0.0f;
-        }
+        drep[(size_t)b * H + tid] = w * (oh / L - et);
     }
+    __syncthreads();
     red[tid] = part;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    const float s_lab = red[0];
-    if (tid < H) drep[(size_t)b * H + tid] = w * (oh / L - et);
     if (tid == 0) {
+        float s_lab = 0.0f;
+        for (int k = 0; k < H; ++k) s_lab += red[k];
         const float z = lse2 / LOG2E;
         lse[b] = z;
         rowloss[b] = (t >= 0) ? w * (z - s_lab) : 0.0f;
@@ -727,7 +741,7 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
-    hipLaunchKernelGGL(k_lbf_combine, dim3(Bp), dim3(256), 0, st, a, lab, wrow, lse, off, rowloss, drep);
+    hipLaunchKernelGGL(k_lbf_combine, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;

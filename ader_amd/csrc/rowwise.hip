@@ -262,12 +262,14 @@ __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ src,
 }
 
 // dst[r][c] = sum_s src[s*slab_stride + r*ld + c].  Rows r < n_rows go to dst, row n_rows (if dst_extra) goes to
-// dst_extra -- the "ones row" of the weight-gradient GEMM = bias gradient.  A workgroup owns 64 outputs; 4 thread
-// groups sum interleaved slab subsets (s = k mod 4, ascending) and are combined in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ src, long slab_stride, int S, int ld,
-                                                      int n_rows, int n_cols, float* __restrict__ dst,
-                                                      float* __restrict__ dst_extra) {
-    __shared__ float red[4][64];
+// dst_extra -- the "ones row" of the weight-gradient GEMM = bias gradient.  A workgroup owns 64 outputs; 16 thread
+// groups sum interleaved slab subsets (s = k mod 16, ascending, 8 loads in flight) and are combined in a fixed order:
+// deterministic, and the serial chain per thread is S/16 loads instead of S (the reads are latency-bound).
+#define RS_G 16
+__global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__ src, long slab_stride, int S, int ld,
+                                                       int n_rows, int n_cols, float* __restrict__ dst,
+                                                       float* __restrict__ dst_extra) {
+    __shared__ float red[RS_G][64];
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
     const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + o;
@@ -277,12 +279,14 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
         r = i / n_cols; c = i - r * n_cols;
         const float* p = src + (size_t)r * ld + c;
 #pragma unroll 8
-        for (int s = sg; s < S; s += 4) acc += p[(size_t)s * slab_stride];
+        for (int s = sg; s < S; s += RS_G) acc += p[(size_t)s * slab_stride];
     }
     red[sg][o] = acc;
     __syncthreads();
     if (sg == 0 && i < total) {
-        const float a = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+        float a = red[0][o];
+#pragma unroll
+        for (int k = 1; k < RS_G; ++k) a += red[k][o];
         if (r < n_rows) dst[(size_t)r * n_cols + c] = a;
         else dst_extra[c] = a;
     }
@@ -413,7 +417,7 @@ int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const fl
     hipLaunchKernelGGL(k_ln_bwd, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, dy_rs, x, x_rs, gamma, mean_i, std_i, add, add_rs,
                        dx, dx_rs, slab, rows, H);
     // slab layout [G][2][H]: row 0 = dgamma partial, row 1 = dbeta partial
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + 63) / 64), dim3(1024), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
                        dgamma, dbeta);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -440,7 +444,7 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
                       void* stream) {
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 63) / 64), dim3(1024), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
                        n_cols, dst, dst_extra);
     HIP_LAUNCH_CHECK();
     return 0;
