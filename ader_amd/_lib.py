@@ -48,7 +48,6 @@ _SIGS = {
     "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P],
     "ader_fused_bucket_gran": [],
     "ader_fused_bucket_id0": [],
-    "ader_set_fused_variant": [I],
     "ader_embed_bwd_rows": [P, P, P, I, I, I, I] + _DROP + [P],
     "ader_logits_store": [P, P, I, I, I, I, P, P, L, P],
     "ader_rank_targets": [P, P, I, I, I, I, P, P, P, P, P],

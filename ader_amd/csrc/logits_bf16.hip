@@ -495,190 +495,6 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fused table update, bandwidth-oriented variant (the default on a single GPU).  Same math as k_lbf_bwd_de<true>,
-// restructured around the memory system because the launch is HBM-bound (theta/m/v of 600 B rows in and out):
-//   * tiles are 128 TABLE rows starting at multiples of 128, so every global stream of the tile is 16-B aligned;
-//   * theta/m/v arrive by LDS-DMA (global_load_lds_dwordx4, no VGPRs) in quarter-tiles of 32 rows, double-buffered:
-//     the DMA of quarter k+1 is in flight while quarter k is updated, and the first quarter lands under the GEMM;
-//   * the update reads g/theta/m/v from LDS as float4 and writes theta/m/v back with 16-B coalesced stores.
-// One workgroup per CU (160 KB of LDS): [rep chunks / table tile / dE staging 43 KB][off][2 x (theta,m,v) quarter].
-#define QROWS 32
-#define QB(H_) ((H_) * QROWS * 4)            // bytes of one quarter of one array
-
-__global__ __launch_bounds__(256) void k_lbf_bwd_adam2(LbfArgs a, FuseArgs f, int vrows_total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* R_l = (bf16*)smem_raw;
-    float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int H = a.H, N = a.N;
-    const int qbytes = QB(H);                                   // 19200 for H = 150
-    unsigned char* land = smem_raw + 2 * 64 * LDR * sizeof(bf16) + (size_t)a.Bp * sizeof(float);   // [2][3][qbytes]
-    const int r0 = (blockIdx.x + a.tile_off) * 128;             // first table row of the tile
-    const bf16* sh = a.sh1 - LDR;                               // shadow row 0
-    const float* gsrc[3] = {f.emb1 - H, f.m1 - H, f.v1 - H};    // table row 0 of theta / m / v
-    const size_t table_bytes = ((size_t)vrows_total * H * 4 + 15) & ~(size_t)15;
-    const int qpieces = qbytes / 16, npieces = 3 * qpieces;     // 16-B pieces per quarter set
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // LDS-DMA of quarter k (rows r0+32k ..) of theta/m/v into landing set k&1: wave-instruction wi moves pieces 64wi..64wi+63
-#define ADAM2_DMA(k_)                                                                                    \
-    {                                                                                                    \
-        const size_t row_off_ = (size_t)(r0 + QROWS * (k_)) * H * 4;                                     \
-        unsigned char* set_ = land + ((k_) & 1) * 3 * qbytes;                                            \
-        for (int wi_ = wave_u; wi_ * 64 < npieces; wi_ += 4) {                                           \
-            const int p_ = wi_ * 64 + lane;                                                              \
-            const int arr_ = p_ / qpieces, q_ = p_ - arr_ * qpieces;                                     \
-            const size_t boff_ = row_off_ + (size_t)q_ * 16;                                             \
-            if (p_ < npieces && boff_ + 16 <= table_bytes)                                               \
-                __builtin_amdgcn_global_load_lds(                                                        \
-                    (const __attribute__((address_space(1))) void*)((const unsigned char*)gsrc[arr_ < 3 ? arr_ : 0] + boff_), \
-                    (__attribute__((address_space(3))) void*)(set_ + wi_ * 1024), 16, 0, 0);             \
-        }                                                                                                \
-    }
-    {   // table tile: 128 shadow rows -> LDS -> operand fragments in registers
-        const uint4* src = (const uint4*)(sh + (size_t)r0 * LDR);
-        uint4* dst = (uint4*)R_l;
-        for (int idx = tid; idx < 128 * PCS_ROW; idx += 256) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (r0 + idx / PCS_ROW < vrows_total) v = src[idx];
-            dst[idx] = v;
-        }
-    }
-    for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
-    __syncthreads();
-    bf16x8 efrag[10];
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks) efrag[ks] = *(const bf16x8*)(R_l + (wave * 32 + r) * LDR + 16 * ks + 8 * hh);
-    __syncthreads();
-    ADAM2_DMA(0);                                               // lands while the GEMM runs
-    f32x16 dE[5];
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) dE[nb][j] = 0.0f;
-    const int nch = a.Bp >> 6;
-    const int n16 = 64 * LDR * 2 / 16;
-    uint4 pf[6];
-    LBF_RPREFETCH(0); LBF_RSTAGE(0);
-    __syncthreads();
-    int cur = 0;
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    for (int c = 0; c < nch; ++c) {
-        const bool more = c + 1 < nch;
-        if (more) LBF_RPREFETCH(c + 1);
-        const bf16* Rb = R_l + cur * 64 * LDR;
-#pragma unroll 1
-        for (int bb = 0; bb < 2; ++bb) {
-            const int b0 = c * 64 + bb * 32;
-            f32x16 S;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) S[j] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 10; ++ks) {
-                const bf16x8 af = *(const bf16x8*)(Rb + (bb * 32 + r) * LDR + 16 * ks + 8 * hh);
-                S = mfma_bf16(af, efrag[ks], S);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 o4 = *(const float4*)(off_l + b0 + 8 * g + 4 * hh);
-                S[4 * g + 0] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 0], LOG2E, o4.x));
-                S[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 1], LOG2E, o4.y));
-                S[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 2], LOG2E, o4.z));
-                S[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 3], LOG2E, o4.w));
-            }
-            const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
-#pragma unroll
-            for (int nb = 0; nb < 5; ++nb) {
-                const bf16* base = Rb + (bb * 32 + 4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
-                const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
-                const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
-                bf16x8 b0v, b1v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
-                dE[nb] = mfma_bf16(pa0, b0v, dE[nb]);
-                dE[nb] = mfma_bf16(pa1, b1v, dE[nb]);
-            }
-        }
-        if (more) LBF_RSTAGE(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    // ---- update phase: quarter k = rows r0+32k.. = the accumulator of wave k; F_l[2][32][H] aliases the rep buffers
-    float* F_l = (float*)smem_raw;
-    const int fq = QROWS * H;                                   // floats per quarter
-#define ADAM2_PUT(k_)                                                                                    \
-    if (wave == (k_)) {                                                                                  \
-        float* dst_ = F_l + ((k_) & 1) * fq;                                                             \
-        _Pragma("unroll") for (int nb = 0; nb < 5; ++nb) {                                               \
-            const int h_ = 32 * nb + r;                                                                  \
-            if (h_ < H) { _Pragma("unroll") for (int j = 0; j < 16; ++j) dst_[acc_row(j, hh) * H + h_] = dE[nb][j]; } \
-        }                                                                                                \
-    }
-    ADAM2_PUT(0)
-    ADAM2_PUT(1)
-    const int nq4 = fq / 4;                                     // float4 per quarter (1200)
-#pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        __syncthreads();                                        // A: DMA(k) landed (vmcnt(0)), F_l[k&1] written, update k-1 done
-        if (k >= 1 && k + 1 < 4) { if (wave == k + 1) {        // wave k+1 stages its accumulator into the buffer freed by quarter k-1
-            float* dst_ = F_l + ((k + 1) & 1) * fq;
-#pragma unroll
-            for (int nb = 0; nb < 5; ++nb) {
-                const int h_ = 32 * nb + r;
-                if (h_ < H) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) dst_[acc_row(j, hh) * H + h_] = dE[nb][j];
-                }
-            }
-        } }
-        float* Fq = F_l + (k & 1) * fq;
-        const int row_lo = r0 + QROWS * k;
-        {   // sparse terms of rows [row_lo, row_lo+32) with ids in [1, N]; thread c owns column c
-            const int id_lo = max(row_lo, 1), id_hi = min(row_lo + QROWS, N + 1);
-            if (tid < H && id_lo < id_hi) {
-                const int bkt = row_lo >> 5;                    // buckets of 32 ids starting at id 0
-                for (int kk = f.sp_start[bkt]; kk < f.n_sp; ++kk) {
-                    const int id = f.sp_ids[kk];
-                    if (id >= id_hi) break;
-                    if (id < id_lo) continue;                   // id 0 (padding) in bucket 0
-                    Fq[(id - row_lo) * H + tid] += f.sp_src[(size_t)f.sp_rows[kk] * H + tid] * f.sp_scale;
-                }
-                for (int kk = f.tg_start[bkt]; kk < f.n_tg; ++kk) {
-                    const int id = f.tg_ids[kk];
-                    if (id >= id_hi) break;
-                    if (id < id_lo) continue;
-                    const int b = f.tg_rows[kk];
-                    Fq[(id - row_lo) * H + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
-                }
-            }
-        }
-        __syncthreads();                                        // B
-        if (k + 1 < 4) ADAM2_DMA(k + 1);                        // in flight during this quarter's update
-        const float* Lq = (const float*)(land + (k & 1) * 3 * qbytes);
-        const size_t gbase = (size_t)row_lo * H;                // element offset of the quarter in theta / m / v
-        for (int q = tid; q < nq4; q += 256) {
-            const int e0 = 4 * q;
-            const int rw0 = row_lo + e0 / H, rw1 = row_lo + (e0 + 2) / H;      // a pair never straddles rows (H even)
-            const bool ok0 = rw0 >= 1 && rw0 <= N, ok1 = rw1 >= 1 && rw1 <= N;
-            if (!ok0 && !ok1) continue;
-            const float4 g4 = *(const float4*)(Fq + e0);
-            float4 p4v = *(const float4*)(Lq + e0), m4v = *(const float4*)(Lq + fq + e0), v4v = *(const float4*)(Lq + 2 * fq + e0);
-#define AD1(c_, ok_) if (ok_) { m4v.c_ += (g4.c_ - m4v.c_) * f.omb1; v4v.c_ += (g4.c_ * g4.c_ - v4v.c_) * f.omb2; \
-                                p4v.c_ -= (m4v.c_ * f.lr_t) / (sqrtf(v4v.c_) + f.eps); }
-            AD1(x, ok0) AD1(y, ok0) AD1(z, ok1) AD1(w, ok1)
-#undef AD1
-            *(float4*)((float*)gsrc[0] + gbase + e0) = p4v;
-            *(float4*)((float*)gsrc[1] + gbase + e0) = m4v;
-            *(float4*)((float*)gsrc[2] + gbase + e0) = v4v;
-            if (ok0) { bf16x2 sb; sb[0] = (bf16)p4v.x; sb[1] = (bf16)p4v.y;
-                       *(bf16x2*)((bf16*)sh + (size_t)rw0 * LDR + (e0 - (rw0 - row_lo) * H)) = sb; }
-            if (ok1) { bf16x2 sb; sb[0] = (bf16)p4v.z; sb[1] = (bf16)p4v.w;
-                       *(bf16x2*)((bf16*)sh + (size_t)rw1 * LDR + (e0 + 2 - (rw1 - row_lo) * H)) = sb; }
-        }
-    }
-}
-
 // sparse one-hot term of dlogit: dE[label_b,:] -= w_b * rep_b  (one wave per batch row, float atomics)
 __global__ __launch_bounds__(256) void k_lbf_target_fix(const bf16* __restrict__ rep_bf, const int* __restrict__ lab,
                                                         const float* __restrict__ wrow, float* __restrict__ demb1, int B, int H) {
@@ -694,8 +510,6 @@ __global__ __launch_bounds__(256) void k_lbf_target_fix(const bf16* __restrict__
 // ============================================================================================= C ABI
 static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
 static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float); }
-
-static int g_fused_variant = 2;
 
 extern "C" {
 
@@ -802,20 +616,6 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
     fa.sp_start = sp_start; fa.tg_start = tg_start;
     fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = (bf16*)shadow + LDR;
     fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
-    // bandwidth-oriented variant: needs one workgroup per CU worth of LDS and 16-B aligned table rows (H % 4 == 2 or 0 -> H even)
-    const size_t lds2 = lds + (size_t)2 * 3 * QB(H);
-    if (g_fused_variant == 2 && lds2 <= 160 * 1024 && (QB(H) % 16) == 0) {
-        static bool f2 = false;
-        static int lds2_set = 0;
-        if (!f2 || (int)lds2 > lds2_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_adam2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            if (e != hipSuccess) return (int)e;
-            f2 = true; lds2_set = (int)lds2;
-        }
-        hipLaunchKernelGGL(k_lbf_bwd_adam2, dim3((N + 1 + 127) / 128), dim3(256), lds2, (hipStream_t)stream, a, fa, item_num + 1);
-        HIP_LAUNCH_CHECK();
-        return 0;
-    }
     {   // tiles [tile_begin, tile_begin + tile_count) of the ceil(N/128) item tiles (tile_count < 0: all)
         const int all = (N + 127) / 128;
         int tb = tile_begin < 0 ? 0 : tile_begin;
@@ -829,10 +629,9 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
     return 0;
 }
 
-// 1: item-tiled register-staged update (k_lbf_bwd_de<true>); 2 (default): row-aligned LDS-DMA update (k_lbf_bwd_adam2)
-int ader_set_fused_variant(int v) { g_fused_variant = v; return 0; }
 // bucket layout the caller must use for sp_start / tg_start: granularity (ids per bucket) and first id of bucket 0
-int ader_fused_bucket_gran(void) { return g_fused_variant == 2 ? 32 : 64; }
-int ader_fused_bucket_id0(void) { return g_fused_variant == 2 ? 0 : 1; }
+// (a half-tile of the update covers item ids [64j + 1, 64j + 65))
+int ader_fused_bucket_gran(void) { return 64; }
+int ader_fused_bucket_id0(void) { return 1; }
 
 }  // extern "C"

@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ seq, 
 
 // Backward of the prologue.  g = dx0 * mask * keep * scale is written back in place (it is the
 // gradient w.r.t. the positional rows before the batch sum); sqrt(H)*g is scatter-added into dE[id].
-// dE rows hit by several (b,t) use float atomics (order-dependent last bits; deterministic variant:
-// ader_embed_bwd_sorted).
+// dE rows hit by several (b,t) use float atomics (order-dependent last bits; the fused single-GPU table update
+// of logits_bf16.hip adds these rows from an id-sorted list instead: deterministic).
 __global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ seq, float* __restrict__ dx,
                                                    float* __restrict__ demb, int rows, int H, int V, float sqrtH,
                                                    DropArgs d) {
@@ -76,25 +76,6 @@ __global__ __launch_bounds__(256) void k_embed_bwd_rows(const int* __restrict__ 
             if (d.thr != 0) v = drop_keep(d, (uint32_t)row * (uint32_t)H + (uint32_t)c) ? v * d.scale : 0.0f;
         }
         g[c] = v;
-    }
-}
-
-// Deterministic scatter: rows pre-sorted by id (order[] = argsort(seq) stable, computed by the caller);
-// one wave per distinct id run sums its rows in order and adds once (no atomics: each id is owned by one wave).
-__global__ __launch_bounds__(256) void k_embed_bwd_sorted(const int* __restrict__ seq, const int* __restrict__ order,
-                                                          const int* __restrict__ run_start, int n_runs,
-                                                          const float* __restrict__ g, float* __restrict__ demb,
-                                                          int rows, int H, float sqrtH) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int run = blockIdx.x * 4 + wave;
-    if (run >= n_runs) return;
-    const int s = run_start[run], e = (run + 1 < n_runs) ? run_start[run + 1] : rows;
-    const int id = seq[order[s]];
-    if (id == 0) return;
-    for (int c = lane; c < H; c += 64) {
-        float acc = 0.0f;
-        for (int i = s; i < e; ++i) acc += g[(size_t)order[i] * H + c];
-        demb[(size_t)id * H + c] += acc * sqrtH;
     }
 }
 

@@ -190,8 +190,6 @@ class Engine:
         # is never written to memory); needs the complete gradient locally, so it is off whenever a grad_hook is set
         self.fuse_adam = True
         self.dp_sharded = True   # dp_world > 1 with bf16 logits: row-sharded table update instead of a dense all-reduce
-        import os as _os
-        call("ader_set_fused_variant", int(_os.environ.get("ADER_FUSED_VARIANT", "1")))
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -541,6 +539,7 @@ class Engine:
             self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
             self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
             dx, dxn = dxn, dx
+        self._last_g = dx       # per-position gradient rows of the input embeddings (tests: column-sum checks)
         if defer:
             call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
             self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)

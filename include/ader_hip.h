@@ -158,9 +158,6 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
 int ader_fused_bucket_gran(void);
 int ader_fused_bucket_id0(void);
 
-/* implementation variant of ader_lbf_bwd_adam: 2 (default) = row-aligned tiles + LDS-DMA, 1 = register-staged */
-int ader_set_fused_variant(int variant);
-
 /* ---- optimiser: tf.train.AdamOptimizer (ADER.py:96), dense over one flat buffer ------------------------ */
 /* shadow (optional, may be NULL): bf16 shadow of the first table_elems parameters (the item table, rows of H), see above */
 int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,
