@@ -25,6 +25,8 @@ _SIGS = {
     "ader_wprep": [P, P, I, I, P, P],
     "ader_gemm_x3": [P, P, P, P, P, P, I, I, I, I, I, I] + _DROP + [P],
     "ader_gemm_atb_x3": [P, P, P, P, P, I, I, P],
+    "ader_gemm_atb_batch_slabs": [P, I],
+    "ader_gemm_atb_x3_batch": [P, P, P, P, P, I, P, I, P],
     "ader_mask_dropgrad": [P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_add_rows": [P, P, I, I, I, I, P],
     "ader_attn_last_fwd": [P, P, P, P, P, P, P, P, I, I, I, I] + _DROP + [P],
@@ -56,7 +58,7 @@ _SIGS = {
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0"}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0"}
 
 
 class AderHipError(RuntimeError):

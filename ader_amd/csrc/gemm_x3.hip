@@ -168,8 +168,8 @@ __global__ __launch_bounds__(640) void k_gemm_x3(GemmX3Args g) {
 
 // dW_aug slab [HP][HP] per workgroup: rows = input channel (row H = ones column -> bias gradient), cols = output channel.
 // 5 waves: wave w owns input channels 32w..32w+31 and all 5 output-channel blocks (80 accumulator registers).
-__global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ slab,
-                                                      int M, int H) {
+__device__ __forceinline__ void atb_x3_body(const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ out,
+                                            int M, int H, int wg, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Ah = (bf16*)smem_raw;                  // [TM][LDR] each
     bf16* Al = Ah + TM * LDR;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A
     const int n_tiles = (M + TM - 1) / TM;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
     __syncthreads();
-    int tile = blockIdx.x;
+    int tile = wg;
 #define AT_PREFETCH(m0_)                                                                                 \
     {                                                                                                    \
         int it_ = it_first, c2_ = c2_first;                                                              \
@@ -222,11 +222,11 @@ __global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A
         if (tid < TM) Ah[tid * LDR + H] = (bf16)(((m0_) + tid < M) ? 1.0f : 0.0f);   /* ones column -> db */ \
     }
     if (tile < n_tiles) AT_PREFETCH(tile * TM);
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles; tile += nwg) {
         __syncthreads();                                    // previous tile's reads are done
         AT_STAGE(tile * TM);
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) AT_PREFETCH((tile + gridDim.x) * TM);
+        if (tile + nwg < n_tiles) AT_PREFETCH((tile + nwg) * TM);
 #pragma unroll
         for (int ks = 0; ks < TM / 16; ++ks) {
             const int ro = (16 * ks + 4 * hh + q4) * LDR + 16 * g1 + 4 * p4;
@@ -250,11 +250,57 @@ __global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A
             }
         }
     }
-    float* out = slab + (size_t)blockIdx.x * HP * HP;
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) out[(size_t)(32 * wave + acc_row(j, hh)) * HP + 32 * nb + r] = acc[nb][j];
+}
+
+__global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ slab,
+                                                      int M, int H) {
+    atb_x3_body(A, G, slab + (size_t)blockIdx.x * HP * HP, M, H, blockIdx.x, gridDim.x);
+}
+
+// All weight-gradient products of a backward pass in ONE launch (they only depend on saved activations and on the
+// gradient rows the backward chain has already written): workgroup w serves product y with wg0[y] <= w < wg0[y+1].
+#define ATB_MAX 16
+struct AtbBatch {
+    const float* A[ATB_MAX]; const float* G[ATB_MAX]; float* dW[ATB_MAX]; float* db[ATB_MAX];
+    int M[ATB_MAX]; int wg0[ATB_MAX + 1]; int n;
+};
+__global__ __launch_bounds__(320) void k_gemm_atb_x3_batch(AtbBatch b, float* __restrict__ slab, int H) {
+    int y = 0;
+#pragma unroll 1
+    while (y + 1 < b.n && (int)blockIdx.x >= b.wg0[y + 1]) ++y;
+    atb_x3_body(b.A[y], b.G[y], slab + (size_t)blockIdx.x * HP * HP, b.M[y], H, blockIdx.x - b.wg0[y], b.wg0[y + 1] - b.wg0[y]);
+}
+
+// dW[y] = sum of product y's slabs (fixed order), row H of the augmented slab -> db[y].  grid (blocks of 64 outputs, n).
+__global__ __launch_bounds__(1024) void k_atb_reduce_batch(AtbBatch b, const float* __restrict__ slab, int H) {
+    __shared__ float red[16][64];
+    const int y = blockIdx.y;
+    const int S = b.wg0[y + 1] - b.wg0[y];
+    const float* src = slab + (size_t)b.wg0[y] * HP * HP;
+    const int total = (H + 1) * H;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float acc = 0.0f;
+    int r = 0, c = 0;
+    if (i < total) {
+        r = i / H; c = i - r * H;
+        const float* p = src + (size_t)r * HP + c;
+#pragma unroll 4
+        for (int s = sg; s < S; s += 16) acc += p[(size_t)s * HP * HP];
+    }
+    red[sg][o] = acc;
+    __syncthreads();
+    if (sg == 0 && i < total) {
+        float a = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) a += red[k][o];
+        if (r < H) b.dW[y][(size_t)r * H + c] = a;
+        else if (b.db[y]) b.db[y][c] = a;
+    }
 }
 
 // ============================================================================================= C ABI
@@ -327,6 +373,55 @@ int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, flo
     hipLaunchKernelGGL(k_gemm_atb_x3, dim3(S), dim3(320), kAtbX3Lds, (hipStream_t)stream, A, G, slab, M, H);
     HIP_LAUNCH_CHECK();
     return ader_reduce_slabs(slab, (long)HP * HP, S, HP, H, H, dW, db, stream);
+}
+
+// Batched form: n <= 16 products dW[i] = A[i]^T . G[i] (M[i] rows each), db[i] = colsum(G[i]) (db[i] may be NULL), one
+// product launch + one reduce launch.  Host arrays of device pointers.  slab: ader_gemm_atb_batch_slabs(M, n)*160*160
+// floats.  Workgroups are shared out in proportion to the rows of each product (about one per CU in total).
+static void atb_batch_plan(const int* M, int n, int* wg0) {
+    long tiles_total = 0;
+    for (int i = 0; i < n; ++i) tiles_total += (M[i] + TM - 1) / TM;
+    wg0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const long t = (M[i] + TM - 1) / TM;
+        long s = tiles_total > 256 ? (t * 256 + tiles_total / 2) / tiles_total : t;
+        if (s < 1) s = 1;
+        if (s > t && t > 0) s = t;
+        // balanced: every workgroup of the product gets ceil(t/s) or one fewer tiles
+        wg0[i + 1] = wg0[i] + (int)s;
+    }
+}
+
+int ader_gemm_atb_batch_slabs(const int* M, int n) {
+    if (n <= 0 || n > ATB_MAX) return 0;
+    int wg0[ATB_MAX + 1];
+    atb_batch_plan(M, n, wg0);
+    return wg0[n];
+}
+
+int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* const* dW, float* const* db, const int* M, int n,
+                           float* slab, int H, void* stream) {
+    if (n <= 0) return 0;
+    if (n > ATB_MAX) return -2;
+    if (H >= HP || H < 2 || (H & 1) || H > 2 * PFA * 5) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_atb_x3_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAtbX3Lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    AtbBatch b;
+    for (int i = 0; i < n; ++i) {
+        if (M[i] <= 0) return -2;
+        b.A[i] = A[i]; b.G[i] = G[i]; b.dW[i] = dW[i]; b.db[i] = db[i]; b.M[i] = M[i];
+    }
+    b.n = n;
+    atb_batch_plan(M, n, b.wg0);
+    hipLaunchKernelGGL(k_gemm_atb_x3_batch, dim3(b.wg0[n]), dim3(320), kAtbX3Lds, (hipStream_t)stream, b, slab, H);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_atb_reduce_batch, dim3(((H + 1) * H + 63) / 64, n), dim3(1024), 0, (hipStream_t)stream, b, slab, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

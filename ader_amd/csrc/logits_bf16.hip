@@ -159,9 +159,11 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
             float tmax = S[0];
 #pragma unroll
             for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, S[j]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float t2 = tmax * LOG2E;
+            // the two half-waves of a lane pair (l, l+32) hold different items of the SAME batch row; m_run is kept equal in
+            // both, so the cross-half exchange is only needed on the (rare) rescale path
+            float t2 = tmax * LOG2E;
             if (__any(t2 > m_run + RESCALE_THR)) {
+                t2 = fmaxf(t2, __shfl_xor(t2, 32, 64));
                 const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;
                 const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;

@@ -7,6 +7,7 @@ the saved activations, and issues the HIP launchers of include/ader_hip.h on tor
 
 Nothing here computes on the CPU: without libader_hip.so / a GPU the constructor raises.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -167,6 +168,8 @@ class Engine:
         # block GEMMs: "x3" = bf16 hi/lo split on the bf16 matrix cores (float32-grade accuracy), "f32" = exact f32 MFMA
         assert gemm in ("x3", "f32")
         self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
+        self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
+        self._atb_q = []
         self.attn_x3 = gemm == "x3" and (hidden_units // num_heads) % 2 == 0      # bf16x3 attention core (attn_x3.hip)
         self._wnames = ["b%d.%s" % (l, w) for l in range(num_blocks) for w in ("wq", "wk", "wv", "w1", "w2")]
         self._widx = {k: i for i, k in enumerate(self._wnames)}
@@ -291,8 +294,27 @@ class Engine:
                  rmap[1], *d, self._stream())
 
     def _atb(self, A, G, wname, bname, slab, M):
+        """dW = A^T.G, db = colsum(G).  In x3 mode the products are queued (A and G stay untouched until the end of the
+        backward pass) and issued as one batched launch by _atb_flush."""
+        if self.gemm_x3 and self.atb_batch:
+            self._atb_q.append((A, G, self._gp[wname], self._gp[bname], M))
+            if len(self._atb_q) == 16:
+                self._atb_flush()
+            return
         fn = "ader_gemm_atb_x3" if self.gemm_x3 else "ader_gemm_atb"
         call(fn, ptr(A), ptr(G), ptr(slab), self._gp[wname], self._gp[bname], M, self.H, self._stream())
+
+    def _atb_flush(self):
+        q, self._atb_q = self._atb_q, []
+        if not q:
+            return
+        n = len(q)
+        VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        Ms = IA(*[it[4] for it in q])
+        slabs = call("ader_gemm_atb_batch_slabs", Ms, n)
+        slab = self.buf("atb_slab", (slabs * 160 * 160,))
+        call("ader_gemm_atb_x3_batch", VP(*[it[0].data_ptr() for it in q]), VP(*[it[1].data_ptr() for it in q]),
+             VP(*[it[2] for it in q]), VP(*[it[3] for it in q]), Ms, n, ptr(slab), self.H, self._stream())
 
     def forward(self, seq, training=False, rate=0.0, step=0, save=False):
         """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward.
@@ -429,12 +451,17 @@ class Engine:
         step = self.global_step
         st = self._stream()
         rows = B * T
-        with self._sec("blocks_fwd"):
-            rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
-        A = self._act
         use_bf16 = self.shadow is not None and teacher is None
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
         self._deferred = None
+        if defer and self.dp_world == 1:
+            # the id-sorted lists of the fused table update need only the inputs: build them on a side stream, under the
+            # block kernels, instead of between backward and the update
+            labs = pos if n_ex == 0 else torch.cat([pos, ex_pos])
+            self._lists_async(seq, labs, N)
+        with self._sec("blocks_fwd"):
+            rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
+        A = self._act
         emb = self._pp["emb"]
         demb = self.gradient("emb")
         if N < self._grad_hi:   # catalog shrank (never in the reference flow): clear stale rows
@@ -500,13 +527,13 @@ class Engine:
                 M, rmap, dxo = rows, (1, 0), dx
             tg = "L" if S["pruned"] else ""
             g = self.buf("bw_g" + tg, (M, H))
-            dh2 = self.buf("bw_dh2" + tg, (M, H))
-            da_ = self.buf("bw_da" + tg, (M, H))
+            dh2 = self.buf("bw_dh2%d" % l, (M, H))       # the weight-gradient operands stay alive until _atb_flush
+            da_ = self.buf("bw_da%d" % l, (M, H))
             dy = self.buf("bw_dy" + tg, (M, H))
             dx1 = self.buf("bw_dx1" + tg, (M, H))
-            dQ = self.buf("bw_dQ" + tg, (M, H))
+            dQ = self.buf("bw_dQ%d" % l, (M, H))
             dqin = self.buf("bw_dqin" + tg, (M, H))
-            dK, dV = self.buf("bw_dK", (rows, H)), self.buf("bw_dV", (rows, H))
+            dK, dV = self.buf("bw_dK%d" % l, (rows, H)), self.buf("bw_dV%d" % l, (rows, H))
             call("ader_mask_dropgrad", ptr(dxo), ptr(seq), ptr(g), ptr(dh2), M, H, rmap[0], rmap[1], *S["d2"].args(), st)
             self._gemm(dh2, p + "w2", None, da_, S["h1d"], None, M, EPI_RELUDROPGRAD, trans=1, drop=S["d1"])
             self._gemm(da_, p + "w1", None, dy, g, None, M, EPI_ADD, trans=1)
@@ -539,6 +566,7 @@ class Engine:
             self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
             self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
             dx, dxn = dxn, dx
+        self._atb_flush()
         self._last_g = dx       # per-position gradient rows of the input embeddings (tests: column-sum checks)
         if defer:
             call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
@@ -564,6 +592,37 @@ class Engine:
                  self.beta1, self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
         self._advance_adam()
 
+    def _sparse_lists(self, seq, lab, N):
+        """Id-sorted lists of the sparse table-gradient terms (input positions, one-hot targets) + bucket offsets."""
+        ids, order = torch.sort(seq.reshape(-1), stable=True)
+        tids, torder = torch.sort(lab.reshape(-1), stable=True)
+        ids, order = ids.to(torch.int32), order.to(torch.int32)
+        tids, torder = tids.to(torch.int32), torder.to(torch.int32)
+        gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
+        key = (gran, id0, N)
+        if getattr(self, "_bkt_key", None) != key:          # bucket boundaries depend on N only
+            self._bkt_key = key
+            self._bkt_bounds = torch.arange(id0, N + gran + 1, gran, dtype=torch.int32, device=self.device)
+        sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
+        tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
+        return ids, order, sp_start, tids, torder, tg_start
+
+    def _lists_async(self, seq, lab, N):
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(main)         # inputs ready; also orders reuse of last step's list memory after its reader
+        with torch.cuda.stream(self._side):
+            self._lists = self._sparse_lists(seq, lab, N)
+        self._lists_seq = (seq, lab)         # keep the inputs alive until the side stream has consumed them
+
+    def _lists_wait(self):
+        torch.cuda.current_stream().wait_stream(self._side)
+        out, self._lists = self._lists, None
+        for t in out:
+            t.record_stream(torch.cuda.current_stream())
+        return out
+
     def _fused_table_adam(self, lr):
         """Table rows 1..N: gradient GEMM + sparse terms + Adam in one pass (ader_lbf_bwd_adam); all other parameters:
         the flat Adam kernel on the tail of the buffer.  Rows 0 and > N have zero gradient and zero Adam state (the
@@ -572,17 +631,7 @@ class Engine:
         st = self._stream()
         H, T = self.H, self.T
         lr_t = self._lr_t(lr)
-        ids, order = torch.sort(D["seq"].reshape(-1), stable=True)
-        tids, torder = torch.sort(D["lab"][:D["B"]], stable=True)
-        ids, order = ids.to(torch.int32), order.to(torch.int32)
-        tids, torder = tids.to(torch.int32), torder.to(torch.int32)
-        gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
-        key = (gran, id0, D["N"])
-        if getattr(self, "_bkt_key", None) != key:          # bucket boundaries depend on (variant, N) only
-            self._bkt_key = key
-            self._bkt_bounds = torch.arange(id0, D["N"] + gran + 1, gran, dtype=torch.int32, device=self.device)
-        sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
-        tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
+        ids, order, sp_start, tids, torder, tg_start = self._lists_wait()
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
                  ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
@@ -623,16 +672,7 @@ class Engine:
             span = self.layout["pos"][0]
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
-        ids, order = torch.sort(seq_g.reshape(-1), stable=True)
-        tids, torder = torch.sort(lab_g.reshape(-1), stable=True)
-        ids, order, tids, torder = ids.to(torch.int32), order.to(torch.int32), tids.to(torch.int32), torder.to(torch.int32)
-        gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
-        key = (gran, id0, N)
-        if getattr(self, "_bkt_key", None) != key:
-            self._bkt_key = key
-            self._bkt_bounds = torch.arange(id0, N + gran + 1, gran, dtype=torch.int32, device=self.device)
-        sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
-        tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
+        ids, order, sp_start, tids, torder, tg_start = self._sparse_lists(seq_g, lab_g, N)
         tiles = self.shard_items // 128
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),

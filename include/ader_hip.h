@@ -67,6 +67,12 @@ int ader_gemm_x3(const float* A, const void* wplanes, const float* bias, float* 
                  int H, int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr,
                  float drop_scale, unsigned drop_base, void* stream);
 int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
+/* The same products batched: n <= 16 independent (A[i], G[i], M[i]) -> (dW[i], db[i] or NULL) in one product launch + one
+ * reduce launch (all weight gradients of a backward pass, tf.gradients of modules.py:172-174,254-261).  A/G/dW/db/M are HOST
+ * arrays (of device pointers).  slab: ader_gemm_atb_batch_slabs(M, n) * 160 * 160 floats of scratch. */
+int ader_gemm_atb_batch_slabs(const int* M, int n);
+int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* const* dW, float* const* db, const int* M, int n,
+                           float* slab, int H, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
                        unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
