@@ -25,6 +25,7 @@ _SIGS = {
     "ader_wprep": [P, P, I, I, P, P],
     "ader_gemm_x3": [P, P, P, P, P, P, I, I, I, I, I, I] + _DROP + [P],
     "ader_gemm_atb_x3": [P, P, P, P, P, I, I, P],
+    "ader_seq_fwd": [P, P],
     "ader_gemm_atb_batch_slabs": [P, I],
     "ader_gemm_atb_x3_batch": [P, P, P, P, P, I, P, I, P],
     "ader_mask_dropgrad": [P, P, P, P, I, I, I, I] + _DROP + [P],
@@ -58,6 +59,28 @@ _SIGS = {
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
+SEQ_MAXL = 4
+
+
+class AderDrop(ctypes.Structure):
+    _fields_ = [("key", c_uint), ("thr", c_uint), ("scale", c_float), ("base", c_uint)]
+
+
+class AderSeqBlock(ctypes.Structure):
+    """include/ader_hip.h: AderSeqBlock"""
+    _PTRS = ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "q_in", "mean1", "std1", "kmask", "qmask", "Q", "K", "V", "P", "x1", "y", "mean2",
+             "std2", "h1d", "x2")
+    _fields_ = ([("w", c_void_p * 5), ("bias", c_void_p * 5)] + [(k, c_void_p) for k in _PTRS] +
+                [("d_attn", AderDrop), ("d_ffn1", AderDrop), ("d_ffn2", AderDrop), ("pruned", c_int), ("pad_", c_int)])
+
+
+class AderSeqFwd(ctypes.Structure):
+    """include/ader_hip.h: AderSeqFwd"""
+    _fields_ = ([(k, c_void_p) for k in ("seq", "emb", "pos", "x0", "status", "lnf_g", "lnf_b", "rep", "meanf", "stdf")] +
+                [(k, c_int) for k in ("B", "T", "H", "V", "L")] + [("sqrtH", c_float), ("sqrt_dh", c_float), ("pad_", c_int),
+                                                                  ("d_emb", AderDrop), ("blk", AderSeqBlock * SEQ_MAXL)])
+
+
 _NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0"}
 
 

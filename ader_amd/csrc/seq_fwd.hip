@@ -1,0 +1,613 @@
+// Whole SASRec forward of one session in ONE workgroup (reference ADER.py:41-91 + modules.py: embedding prologue,
+// num_blocks x [LayerNorm -> Q/K/V -> causal masked attention -> residual -> LayerNorm -> FFN -> residual -> mask],
+// final LayerNorm of position T-1).  Every operation of the stack is local to a row or to a session, so a workgroup
+// that owns the T <= 64 rows of a session never has to leave the CU: the residual stream and the GEMM / attention
+// operands stay in LDS, the weights stream from L2, and only the activations the backward pass needs are written to
+// memory (same buffers and layouts as the per-op kernels of rowwise/gemm_x3/attn_x3.hip, which this kernel replaces:
+// ~24 dependent launches -> 1).  Arithmetic is the same "bf16x3" scheme: fp32 operands split into bf16 hi+lo, three
+// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation, fp32 LayerNorm / softmax / residuals.
+//
+// 10 waves; in GEMM and attention phases wave (mh = w/5, nb = w%5) owns rows 32mh.. and columns 32nb.. of the 64x160 tile,
+// so a lane always holds element (row 32mh + acc_row(j,hh), col 32nb + r) in accumulator register j.
+// LDS: three hi/lo tile pairs R0,R1,R2 of [64][168] bf16 (stride 336 B: conflict-free ds_read_b128); R2 doubles as the
+// fp32 residual-stream tile Xf [64][164] while no K tile is live.
+// heads == 1, T <= 64, H even and <= 150 (the engine falls back to the per-op kernels otherwise).  gfx950 only.
+#include "common.h"
+#include "../../include/ader_hip.h"
+#include <stddef.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define HP 160
+#define LDR 168
+#define WSZ (HP * LDR)
+#define TR 64
+#define XS 164                      // fp32 row stride of Xf
+#define RSZ (2 * TR * LDR)          // bf16 elements of one hi/lo tile pair
+#define LDP 72                      // row stride of the 64x64 probability tile
+
+static_assert(sizeof(AderDrop) == sizeof(DropArgs), "AderDrop must mirror DropArgs");
+static_assert(TR * XS * sizeof(float) <= RSZ * sizeof(bf16), "Xf must fit in one tile pair");
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+    return o;
+}
+// Launders a lane-derived index so that the offsets computed from it are rebuilt per phase instead of being hoisted out of
+// the block loop and kept (spilled) across all phases.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+#define PHASE_IDS                                             \
+    const int lane_p = opaque(lane);                          \
+    const int r = lane_p & 31, hh = lane_p >> 5;              \
+    const int n = 32 * nb + r;                                \
+    (void)hh; (void)n
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store of the wave
+// (vmcnt(0)): with ~100 activation stores per lane between barriers that costs a memory round trip per phase.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <class D> __device__ __forceinline__ DropArgs drop_of(const D& d) {
+    DropArgs o; o.key = d.key; o.thr = d.thr; o.scale = d.scale; o.base = d.base;
+    return o;
+}
+__device__ __forceinline__ void put_split(bf16* Th, bf16* Tl, int off, float v) {
+    const bf16 h = (bf16)v;
+    Th[off] = h;
+    Tl[off] = (bf16)(v - (float)h);
+}
+
+// B fragments of this wave's 32 output columns: planes [n][k] (W^T hi at W, lo at W + WSZ), zero padded
+__device__ __forceinline__ void load_bfrags(const bf16* __restrict__ W, int nb, int r, int hh, bf16x8 (&bh)[10], bf16x8 (&bl)[10]) {
+    const bf16* p = W + (size_t)(32 * nb + r) * LDR + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+        bh[ks] = *(const bf16x8*)(p + 16 * ks);
+        bl[ks] = *(const bf16x8*)(p + WSZ + 16 * ks);
+    }
+}
+// acc = tile rows 32mh.. (hi/lo in LDS) . W columns 32nb..
+__device__ __forceinline__ f32x16 tile_mma(const bf16* Th, int mh, int r, int hh, const bf16x8 (&bh)[10], const bf16x8 (&bl)[10]) {
+    const bf16* Ah = Th + (32 * mh + r) * LDR + 8 * hh;
+    const bf16* Al = Ah + TR * LDR;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+        const bf16x8 ah = *(const bf16x8*)(Ah + 16 * ks);
+        const bf16x8 al = *(const bf16x8*)(Al + 16 * ks);
+        acc = mfma_bf16(al, bh[ks], acc);
+        acc = mfma_bf16(ah, bl[ks], acc);
+        acc = mfma_bf16(ah, bh[ks], acc);
+    }
+    return acc;
+}
+
+// LayerNorm of one fp32 LDS row (modules.py:44-48), one wave; x[i], y[i], gamma g[i], beta be[i] for columns lane + 64 i
+__device__ __forceinline__ void ln_row(const float* xr, bool valid, int H, int lane, const float (&g)[3], const float (&be)[3],
+                                       float (&x)[3], float (&y)[3], float& mean, float& sd, float& xsum, float& ysum) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        x[i] = (valid && c < H) ? xr[c] : 0.0f;
+        s += x[i];
+    }
+    s = wave_sum(s);
+    mean = s / (float)H;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        const float dlt = (c < H) ? (x[i] - mean) : 0.0f;
+        q += dlt * dlt;
+    }
+    q = wave_sum(q);
+    sd = sqrtf(q / (float)H + LN_EPS);
+    float ys = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        y[i] = 0.0f;
+        if (valid && c < H) {
+            y[i] = g[i] * ((x[i] - mean) / sd) + be[i];   // a true division: bit-equal to k_ln_fwd
+            ys += y[i];
+        }
+    }
+    xsum = s;
+    ysum = wave_sum(ys);
+}
+// Sum over the 16 lanes of a DPP row, result in every lane: xor-1 and xor-2 inside quads, then the two mirror swaps.
+// (4 VALU ops with DPP modifiers; a __shfl_xor is an LDS round trip.)
+#define DPP_F(v_, ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v_)), (ctrl_), 0xf, 0xf, false))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += DPP_F(v, 0xB1);      // quad_perm [1,0,3,2]
+    v += DPP_F(v, 0x4E);      // quad_perm [2,3,0,1]
+    v += DPP_F(v, 0x141);     // row_half_mirror
+    v += DPP_F(v, 0x140);     // row_mirror
+    return v;
+}
+// per-column parameters in the 16-lanes-per-row layout: column sub + 16 i
+__device__ __forceinline__ void load10(const float* __restrict__ p, int H, int sub, float (&o)[10]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int c = sub + 16 * i;
+        o[i] = (c < H) ? p[c] : 0.0f;
+    }
+}
+__device__ __forceinline__ void load3(const float* __restrict__ p, int H, int lane, float (&o)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        o[i] = (c < H) ? p[c] : 0.0f;
+    }
+}
+
+// ---- bounds-checked activation traffic -------------------------------------------------------------------------------
+// Every activation store/load of a phase goes through a raw buffer descriptor that covers exactly the rows of THIS session
+// (or, for a pruned block, the single compact row of position T-1): rows >= T, columns >= H and the non-kept rows fall
+// outside the descriptor and are dropped by the hardware range check instead of by per-element branches, and the address
+// is one 32-bit add per element.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define OOB 0x80000000u
+struct Out { rsrc_t r; uint32_t sub; };
+// rows_elems: elements per row of the tensor (H, 1 or T); the tensor is [B*T][rows_elems] or, pruned, [B][rows_elems]
+__device__ __forceinline__ Out make_out(const void* base, int b, int T, int row_elems, bool pruned) {
+    Out o;
+    const size_t first = pruned ? (size_t)b * row_elems : (size_t)b * T * row_elems;
+    o.r = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)base + first), 0, (pruned ? row_elems : T * row_elems) * 4, 0x00020000);
+    o.sub = pruned ? (uint32_t)(T - 1) * row_elems * 4u : 0u;
+    return o;
+}
+__device__ __forceinline__ void bstore(const Out& o, uint32_t boff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), o.r, (int)(boff - o.sub), 0, 0);
+}
+__device__ __forceinline__ float bload(const Out& o, uint32_t boff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o.r, (int)(boff - o.sub), 0, 0));
+}
+#define ROWJ(j) (((j) & 3) + 8 * ((j) >> 2))          // row of accumulator register j relative to 32mh + 4hh
+
+__global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* R0 = (bf16*)smem_raw;
+    bf16* R1 = R0 + RSZ;
+    bf16* R2 = R1 + RSZ;
+    float* Xf = (float*)R2;
+    float* km_l = (float*)(R2 + RSZ);            // [64] key mask of the current block
+    float* qm_l = km_l + TR;                     // [64] query mask
+    int* sq_l = (int*)(qm_l + TR);               // [64] item ids of the session
+    float* red_l = (float*)(sq_l + TR);          // [2][2][64] softmax max / sum halves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = wave % 5, mh = wave / 5;
+    const int b = blockIdx.x, T = a.T, H = a.H;
+    const uint32_t H4 = (uint32_t)H * 4u;
+    const uint32_t didx_row0 = (uint32_t)b * (uint32_t)T * (uint32_t)H;      // dropout counter of element (row0, 0)
+    bf16x8 bh[10], bl[10];
+    // per-block descriptors are indexed with a runtime l: read them straight from the kernarg segment (indexing the by-value
+    // struct would make the compiler copy it to scratch)
+    typedef const AderSeqBlock __attribute__((address_space(4))) * BlkPtr;
+    const BlkPtr blks = (BlkPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                 offsetof(AderSeqFwd, blk));
+
+    // ---- prologue (modules.py:118-130, ADER.py:41-60): x0 = dropout(E[seq]*sqrt(H) + P[t]) * (seq != 0)
+    {
+        const DropArgs d0 = drop_of(a.d_emb);
+        const Out ox0 = make_out(a.x0, b, T, H, false);
+        int ids[7];
+        float ev[7][3], pv[7][3];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {                       // the wave's rows: all gathers in flight before any use
+            const int t = wave + 10 * u;
+            int id = 0;
+            if (t < T) {
+                id = a.seq[(size_t)b * T + t];
+                if (id < 0 || id >= a.V) {
+                    if (lane == 0) atomicOr(a.status, ADER_ST_BAD_ID);
+                    id = 0;
+                }
+            }
+            ids[u] = id;
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int t = wave + 10 * u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = lane + 64 * i;
+                const bool ok = t < T && c < H;
+                ev[u][i] = (ok && ids[u] != 0) ? a.emb[(size_t)ids[u] * H + c] : 0.0f;
+                pv[u][i] = ok ? a.pos[(size_t)t * H + c] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int t = wave + 10 * u;
+            if (t < TR) {
+                if (lane == 0) sq_l[t] = ids[u];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int c = lane + 64 * i;
+                    float v = ev[u][i] * a.sqrtH + pv[u][i];
+                    v = drop_apply(d0, didx_row0 + (uint32_t)(t * H + c), v);
+                    v = (ids[u] != 0 && t < T && c < H) ? v : 0.0f;
+                    if (c < XS) Xf[t * XS + c] = v;
+                    bstore(ox0, (c < H) ? (uint32_t)(t * H + c) * 4u : OOB, v);
+                }
+            }
+        }
+    }
+    {
+        const int r = lane & 31, hh = lane >> 5;
+        load_bfrags((const bf16*)blks[0].w[0], nb, r, hh, bh, bl);       // Wq of block 0 (in flight across the barrier)
+    }
+    lds_barrier();
+
+#pragma unroll 1
+    for (int l = 0; l < a.L; ++l) {
+        const BlkPtr kp = blks + l;
+#define k (*kp)
+        const bool pruned = k.pruned != 0;      // last block: only position T-1 of the query / FFN path is kept (ADER.py:85)
+        // small parameters of the block: requested now, consumed phases later
+        float g1[10], be1[10], bias5[5];
+        load10(k.ln1_g, H, lane & 15, g1); load10(k.ln1_b, H, lane & 15, be1);
+        {
+            const int n = 32 * nb + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) bias5[i] = (n < H) ? k.bias[i][n] : 0.0f;
+        }
+        // ---- LN1 (ADER.py:67 via modules.py:44-48) + key/query masks (modules.py:188,208); x -> R0, LN(x) -> R1
+        //      16 lanes per row, 4 rows per wave at a time: lane (rsub, sub) owns columns sub + 16 i of row 4*(wave + 10 pass) + rsub
+        {
+            const Out oq = make_out(k.q_in, b, T, H, pruned);
+            const Out om = make_out(k.mean1, b, T, 1, pruned), os = make_out(k.std1, b, T, 1, pruned);
+            const Out okm = make_out(k.kmask, b, T, 1, false), oqm = make_out(k.qmask, b, T, 1, pruned);
+            const int sub = lane & 15, rsub = lane >> 4;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                const int t = 40 * pass + 4 * wave + rsub;
+                if (t < TR) {
+                    const bool valid = t < T;
+                    float x[10], s = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const int c = sub + 16 * i;
+                        x[i] = (valid && c < H) ? Xf[t * XS + c] : 0.0f;
+                        s += x[i];
+                    }
+                    s = row16_sum(s);
+                    const float mean = s / (float)H;
+                    float q = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const float dlt = (sub + 16 * i < H) ? (x[i] - mean) : 0.0f;
+                        q += dlt * dlt;
+                    }
+                    q = row16_sum(q);
+                    const float sd = sqrtf(q / (float)H + LN_EPS);
+                    float ys = 0.0f;
+                    bf16* T0 = R0 + t * LDR + sub;
+                    bf16* T1 = R1 + t * LDR + sub;
+                    const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const int c = sub + 16 * i;
+                        const float y = (valid && c < H) ? g1[i] * ((x[i] - mean) / sd) + be1[i] : 0.0f;
+                        ys += y;
+                        put_split(T0, T0 + TR * LDR, 16 * i, x[i]);
+                        put_split(T1, T1 + TR * LDR, 16 * i, y);
+                        bstore(oq, (c < H) ? bo + 64u * i : OOB, y);
+                    }
+                    ys = row16_sum(ys);
+                    const float kmv = (valid && s != 0.0f) ? 1.0f : 0.0f, qmv = (valid && ys != 0.0f) ? 1.0f : 0.0f;
+                    const uint32_t so = (sub == 0) ? (uint32_t)t * 4u : OOB;
+                    if (sub == 0) { km_l[t] = kmv; qm_l[t] = qmv; }
+                    bstore(okm, so, kmv); bstore(oqm, so, qmv); bstore(om, so, mean); bstore(os, so, sd);
+                }
+            }
+        }
+        lds_barrier();
+        // ---- Q = LN(x).Wq + bq (modules.py:172) -> memory, hi/lo -> R1 (in place)
+        {
+            PHASE_IDS;
+            f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
+            load_bfrags((const bf16*)k.w[1], nb, r, hh, bh, bl);
+            const Out o = make_out(k.Q, b, T, H, pruned);
+            const int t0 = 32 * mh + 4 * hh;
+            const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
+            bf16* Th = R1 + t0 * LDR + n;
+            lds_barrier();                                              // every wave has read its R1 rows
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = (n < H) ? acc[j] + bias5[0] : 0.0f;
+                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                bstore(o, boff0 + ROWJ(j) * H4, v);
+            }
+        }
+        // ---- K = x.Wk + bk (modules.py:173) -> memory, hi/lo -> R2 (the fp32 tile is dead)
+        {
+            PHASE_IDS;
+            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+            load_bfrags((const bf16*)k.w[2], nb, r, hh, bh, bl);
+            const Out o = make_out(k.K, b, T, H, false);
+            const int t0 = 32 * mh + 4 * hh;
+            const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
+            bf16* Th = R2 + t0 * LDR + n;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = (n < H) ? acc[j] + bias5[1] : 0.0f;
+                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                bstore(o, boff0 + ROWJ(j) * H4, v);
+            }
+        }
+        // ---- V = x.Wv + bv (modules.py:174) -> memory, hi/lo -> R0 (in place)
+        {
+            PHASE_IDS;
+            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+            const Out o = make_out(k.V, b, T, H, false);
+            const int t0 = 32 * mh + 4 * hh;
+            const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
+            bf16* Th = R0 + t0 * LDR + n;
+            lds_barrier();                                              // every wave has read its R0 rows
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = (n < H && t0 + ROWJ(j) < T) ? acc[j] + bias5[2] : 0.0f;   // rows >= T: exact zeros (0 * V below)
+                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                bstore(o, boff0 + ROWJ(j) * H4, v);
+            }
+        }
+        __syncthreads();        // full barrier: LN(x) rows written to memory by other waves are re-read after the attention
+        // ---- attention (modules.py:177-223).  Scores and softmax are computed ONCE per session by four waves -- wave (mq, kb)
+        //      owns the 32x32 block S^T[keys 32kb..][queries 32mq..] (keys on the MFMA rows, the lane's query on the column, so a
+        //      query's statistics are lane-local up to one exchange with the wave holding its other 32 keys) -- and the dropped
+        //      probabilities go through a [query][key] hi/lo tile in LDS to all ten waves for O[:, 32nb..] = P_drop . V.
+        float qres[16], g2[10], be2[10];
+        load10(k.ln2_g, H, lane & 15, g2); load10(k.ln2_b, H, lane & 15, be2);      // consumed by LN2, after the attention
+        {
+            PHASE_IDS;
+            const Out oq = make_out(k.q_in, b, T, H, pruned);
+            const uint32_t boff0 = (n < H) ? (uint32_t)((32 * mh + 4 * hh) * H + n) * 4u : OOB;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) qres[j] = bload(oq, boff0 + ROWJ(j) * H4);    // residual rows, added after P.V
+        }
+        bf16* Ph = R1;                                   // [64 queries][LDP] hi, then lo: overlays the Q tile once S is done
+        bf16* Pl = R1 + TR * LDP;
+        {
+            PHASE_IDS;
+            const bool swave = wave < 4;
+            const int mq = wave >> 1, kb = wave & 1;
+            const int q = 32 * mq + r;
+            const int key0 = 32 * kb + 4 * hh;           // key of register j: key0 + ROWJ(j)
+            f32x16 S;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) S[j] = 0.0f;
+            float mx = -INFINITY, sum = 0.0f;
+            if (swave) {
+                const bf16* Qh = R1 + q * LDR + 8 * hh;
+                const bf16* Kh = R2 + (32 * kb + r) * LDR + 8 * hh;
+#pragma unroll
+                for (int ks = 0; ks < 10; ++ks) {
+                    const bf16x8 qh = *(const bf16x8*)(Qh + 16 * ks), ql = *(const bf16x8*)(Qh + TR * LDR + 16 * ks);
+                    const bf16x8 ah = *(const bf16x8*)(Kh + 16 * ks), al = *(const bf16x8*)(Kh + TR * LDR + 16 * ks);
+                    S = mfma_bf16(al, qh, S);
+                    S = mfma_bf16(ah, ql, S);
+                    S = mfma_bf16(ah, qh, S);
+                }
+                const float r_sqrt_dh = 1.0f / a.sqrt_dh;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int key = key0 + ROWJ(j);
+                    float sc = S[j] * r_sqrt_dh;                                 // modules.py:185
+                    if (km_l[key] == 0.0f) sc = NEG_PAD;                         // modules.py:188-193 (0 beyond T)
+                    if (key > q) sc = NEG_PAD;                                   // modules.py:196-202
+                    if (key < T) mx = fmaxf(mx, sc);
+                    S[j] = sc;
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (hh == 0) red_l[kb * TR + q] = mx;
+            }
+            lds_barrier();                               // also: every read of the Q and K tiles is done
+            if (swave) {
+                mx = fmaxf(mx, red_l[(kb ^ 1) * TR + q]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float e = (key0 + ROWJ(j) < T) ? expf(S[j] - mx) : 0.0f;
+                    S[j] = e;
+                    sum += e;
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                if (hh == 0) red_l[2 * TR + kb * TR + q] = sum;
+            }
+            lds_barrier();
+            if (swave) {
+                sum += red_l[2 * TR + (kb ^ 1) * TR + q];
+                const float r_sum = 1.0f / sum;
+                const float qm = (q < T) ? qm_l[q] : 0.0f;                        // modules.py:208-211
+                const DropArgs da = drop_of(k.d_attn);
+                // P^T [key][query] (pruned: the row of query T-1 only, [key])
+                const Out op = make_out(k.P, b, T, pruned ? 1 : T, false);
+                const uint32_t T4 = pruned ? 4u : (uint32_t)T * 4u;
+                uint32_t poff0 = pruned ? ((q == T - 1) ? 0u : OOB) : ((q < T) ? (uint32_t)q * 4u : OOB);
+                poff0 += (uint32_t)key0 * T4;
+                const uint32_t dbase = (uint32_t)b * (uint32_t)T * (uint32_t)T + (uint32_t)(q * T + key0);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    bf16x4 h4, l4;
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        const int j = 4 * jj + j2;
+                        float p = S[j] * r_sum;
+                        bstore(op, poff0 + (uint32_t)ROWJ(j) * T4, p);
+                        p = drop_apply(da, dbase + (uint32_t)ROWJ(j), p * qm);   // modules.py:214
+                        p = (q < T && key0 + ROWJ(j) < T) ? p : 0.0f;
+                        h4[j2] = (bf16)p;
+                        l4[j2] = (bf16)(p - (float)h4[j2]);
+                    }
+                    *(bf16x4*)(Ph + q * LDP + key0 + 8 * jj) = h4;               // keys key0 + 8jj .. +3 of query q
+                    *(bf16x4*)(Pl + q * LDP + key0 + 8 * jj) = l4;
+                }
+            }
+        }
+        lds_barrier();
+        {
+            PHASE_IDS;
+            f32x16 O;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) O[j] = 0.0f;
+            const int q4 = (lane_p & 15) >> 2, p4 = lane_p & 3, g1_ = (lane_p >> 4) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 ph = *(const bf16x8*)(Ph + (32 * mh + r) * LDP + 16 * ks + 8 * hh);
+                const bf16x8 pl = *(const bf16x8*)(Pl + (32 * mh + r) * LDP + 16 * ks + 8 * hh);
+                const bf16* Vp = R0 + (16 * ks + 8 * hh + q4) * LDR + 16 * g1_ + 4 * p4 + 32 * nb;
+                const bf16x8 vh = cat4(tr_read(Vp), tr_read(Vp + 4 * LDR));
+                const bf16x8 vl = cat4(tr_read(Vp + TR * LDR), tr_read(Vp + TR * LDR + 4 * LDR));
+                O = mfma_bf16(pl, vh, O);
+                O = mfma_bf16(ph, vl, O);
+                O = mfma_bf16(ph, vh, O);
+            }
+            load_bfrags((const bf16*)k.w[3], nb, r, hh, bh, bl);        // W1, consumed after LN2
+            const Out o = make_out(k.x1, b, T, H, pruned);
+            const int t0 = 32 * mh + 4 * hh;
+            const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
+            float* Xp = Xf + t0 * XS + n;
+            // ---- x1 = O + LN(x) (modules.py:223); the K tile is dead since the first barrier of the phase: R2 is Xf again
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = O[j] + qres[j];
+                Xp[ROWJ(j) * XS] = v;
+                bstore(o, boff0 + ROWJ(j) * H4, v);
+            }
+        }
+        lds_barrier();
+        // ---- LN2 (ADER.py:75): y -> memory, Xf (fp32, the FFN residual) and hi/lo -> R0
+        {
+            const Out oy = make_out(k.y, b, T, H, pruned);
+            const Out om = make_out(k.mean2, b, T, 1, pruned), os = make_out(k.std2, b, T, 1, pruned);
+            const int sub = lane & 15, rsub = lane >> 4;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                const int t = 40 * pass + 4 * wave + rsub;
+                if (t < TR) {
+                    const bool valid = t < T && (!pruned || t == T - 1);
+                    float x[10], s = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const int c = sub + 16 * i;
+                        x[i] = (valid && c < H) ? Xf[t * XS + c] : 0.0f;
+                        s += x[i];
+                    }
+                    s = row16_sum(s);
+                    const float mean = s / (float)H;
+                    float q = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const float dlt = (sub + 16 * i < H) ? (x[i] - mean) : 0.0f;
+                        q += dlt * dlt;
+                    }
+                    q = row16_sum(q);
+                    const float sd = sqrtf(q / (float)H + LN_EPS);
+                    bf16* T0 = R0 + t * LDR + sub;
+                    const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const int c = sub + 16 * i;
+                        const float y = (valid && c < H) ? g2[i] * ((x[i] - mean) / sd) + be2[i] : 0.0f;
+                        put_split(T0, T0 + TR * LDR, 16 * i, y);
+                        Xf[t * XS + c] = y;
+                        bstore(oy, (c < H) ? bo + 64u * i : OOB, y);
+                    }
+                    const uint32_t so = (sub == 0) ? (uint32_t)t * 4u : OOB;
+                    bstore(om, so, mean); bstore(os, so, sd);
+                }
+            }
+        }
+        lds_barrier();
+        // ---- h1 = dropout(relu(y.W1 + b1)) (modules.py:254-257) -> memory, hi/lo -> R1
+        {
+            PHASE_IDS;
+            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+            load_bfrags((const bf16*)k.w[4], nb, r, hh, bh, bl);
+            const DropArgs d1 = drop_of(k.d_ffn1);
+            const Out o = make_out(k.h1d, b, T, H, pruned);
+            const int t0 = 32 * mh + 4 * hh;
+            const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
+            const uint32_t didx0 = didx_row0 + (uint32_t)(t0 * H + n);
+            bf16* Th = R1 + t0 * LDR + n;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = t0 + ROWJ(j);
+                float v = fmaxf(acc[j] + bias5[3], 0.0f);
+                v = drop_apply(d1, didx0 + ROWJ(j) * (uint32_t)H, v);
+                v = (n < H && t < T && (!pruned || t == T - 1)) ? v : 0.0f;
+                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                bstore(o, boff0 + ROWJ(j) * H4, v);
+            }
+        }
+        lds_barrier();
+        // ---- x2 = (dropout(h1.W2 + b2) + y) * (seq != 0) (modules.py:258-266, ADER.py:80)
+        {
+            PHASE_IDS;
+            f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
+            if (l + 1 < a.L) load_bfrags((const bf16*)kp[1].w[0], nb, r, hh, bh, bl);
+            const DropArgs d2 = drop_of(k.d_ffn2);
+            const Out o = make_out(k.x2, b, T, H, pruned);
+            const int t0 = 32 * mh + 4 * hh;
+            const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
+            const uint32_t didx0 = didx_row0 + (uint32_t)(t0 * H + n);
+            float* Xp = Xf + t0 * XS + n;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = t0 + ROWJ(j);
+                float v = drop_apply(d2, didx0 + ROWJ(j) * (uint32_t)H, acc[j] + bias5[4]);
+                const float yv = (n < XS) ? Xp[ROWJ(j) * XS] : 0.0f;
+                v = (sq_l[t] != 0) ? v + yv : 0.0f;
+                if (n < XS) Xp[ROWJ(j) * XS] = v;
+                bstore(o, boff0 + ROWJ(j) * H4, v);
+            }
+        }
+        lds_barrier();
+#undef k
+    }
+    // ---- final LayerNorm of position T-1 (ADER.py:83-85) -> rep[b]
+    if (wave == 0) {
+        float x[3], y[3], mean, sd, xs, ys, gf[3], bf_[3];
+        load3(a.lnf_g, H, lane, gf); load3(a.lnf_b, H, lane, bf_);
+        ln_row(Xf + (T - 1) * XS, true, H, lane, gf, bf_, x, y, mean, sd, xs, ys);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H) a.rep[(size_t)b * H + c] = y[i];
+        }
+        if (lane == 0) { a.meanf[b] = mean; a.stdf[b] = sd; }
+    }
+}
+
+static const size_t kSeqFwdLds = (size_t)3 * RSZ * sizeof(bf16) + (size_t)7 * TR * sizeof(float);
+
+extern "C" {
+
+int ader_seq_fwd(const AderSeqFwd* desc, void* stream) {
+    const AderSeqFwd& a = *desc;
+    if (a.B <= 0) return 0;
+    if (a.T < 1 || a.T > TR || a.H < 2 || a.H > 150 || (a.H & 1) || a.L < 1 || a.L > ADER_SEQ_MAXL) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_seq_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSeqFwdLds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_seq_fwd, dim3(a.B), dim3(640), kSeqFwdLds, (hipStream_t)stream, a);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@ Nothing here computes on the CPU: without libader_hip.so / a GPU the constructor
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -71,10 +72,11 @@ class SectionTimer:
     """HIP-event timing of named launch groups on the stream the kernels are launched on (bench.py roofline leg).
     Events are recorded around each section; elapsed times are read back after a sync with collect()."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.pending = []
         self.totals = {}
         self.counts = {}
+        self.only = only          # restrict the event pairs to these sections (each pair costs a few us of stream time)
 
     class _Ctx:
         def __init__(self, owner, name):
@@ -90,6 +92,8 @@ class SectionTimer:
             self.o.pending.append((self.name, self.a, self.b))
 
     def section(self, name):
+        if self.only is not None and name not in self.only:
+            return _NULL
         return SectionTimer._Ctx(self, name)
 
     def collect(self):
@@ -168,6 +172,9 @@ class Engine:
         # block GEMMs: "x3" = bf16 hi/lo split on the bf16 matrix cores (float32-grade accuracy), "f32" = exact f32 MFMA
         assert gemm in ("x3", "f32")
         self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
+        # whole forward stack in one launch (seq_fwd.hip); the per-op kernels remain for the shapes it does not cover
+        self.seq_fused = (self.gemm_x3 and num_heads == 1 and maxlen <= 64 and num_blocks <= _lib.SEQ_MAXL)
+        self.lists_side_stream = os.environ.get("ADER_LISTS_SIDE", "1") == "1"
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
         self._atb_q = []
         self.attn_x3 = gemm == "x3" and (hidden_units // num_heads) % 2 == 0      # bf16x3 attention core (attn_x3.hip)
@@ -320,6 +327,8 @@ class Engine:
         """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward.
         The final block computes only position T-1 of its query / FFN path (Engine.prune_last): the representation is
         x[:, -1, :] (ADER.py:85) and rows interact only through K/V, so the other T-1 rows of that block are dead work."""
+        if self.seq_fused:
+            return self._forward_fused(seq, training, rate, step, save)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
         rows = B * T
         st = self._stream()
@@ -397,6 +406,63 @@ class Engine:
             x_last = x.view(B, T, H)[:, T - 1, :]
             call("ader_ln_fwd", ptr(x_last), T * H, ptr(rep), H, pp["lnf_g"], pp["lnf_b"], ptr(meanf), ptr(stdf), None, None,
                  B, H, st)
+        A.update(xL=x, rep=rep, meanf=meanf, stdf=stdf)
+        if save:
+            self._act = A
+        return rep
+
+    def _forward_fused(self, seq, training, rate, step, save):
+        """forward() as one launch of ader_seq_fwd (seq_fwd.hip): same buffers, layouts and saved-activation dict as the
+        per-op path above, so the backward pass does not care which one ran."""
+        B, T, H, L = seq.shape[0], self.T, self.H, self.L
+        rows = B * T
+        tag = "t" if save else "e"
+        A = {"B": B, "seq": seq, "rate": rate, "training": training, "step": step}
+        per_row = T * H
+        pp = self._pp
+        d = _lib.AderSeqFwd()
+        d0 = _Drop(self.seed, step, SITE_EMB, rate, training, self.row0 * per_row)
+        A["d_emb"] = d0
+        x = self.buf(tag + "x0", (rows, H))
+        rep = self.buf(tag + "rep", (B, H))
+        meanf, stdf = self.buf(tag + "mf", (B,)), self.buf(tag + "sf", (B,))
+        d.seq, d.emb, d.pos, d.x0, d.status = ptr(seq), pp["emb"], pp["pos"], ptr(x), ptr(self.status)
+        d.lnf_g, d.lnf_b, d.rep, d.meanf, d.stdf = pp["lnf_g"], pp["lnf_b"], ptr(rep), ptr(meanf), ptr(stdf)
+        d.B, d.T, d.H, d.V, d.L = B, T, H, self.V, L
+        d.sqrtH = float(np.sqrt(np.float32(H)))
+        d.sqrt_dh = float(np.sqrt(np.float32(H // self.heads)))
+        d.d_emb = _lib.AderDrop(*d0.args())
+        for l in range(L):
+            p = "b%d." % l
+            n = lambda s: "%s%d%s" % (tag, l, s)   # noqa: E731
+            pruned = self.prune_last and l == L - 1
+            da = _Drop(self.seed, step, site_attn(l), rate, training, self.row0 * self.heads * T * T)
+            d1 = _Drop(self.seed, step, site_ffn1(l), rate, training, self.row0 * per_row)
+            d2 = _Drop(self.seed, step, site_ffn2(l), rate, training, self.row0 * per_row)
+            M, sfx = (B, "L") if pruned else (rows, "")
+            kmask = self.buf(n("km"), (rows,))
+            K, Vv = self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
+            q_in = self.buf(n("qin" + sfx), (M, H))
+            mean1, std1, qmask = self.buf(n("m1" + sfx), (M,)), self.buf(n("s1" + sfx), (M,)), self.buf(n("qm" + sfx), (M,))
+            Q, x1, y = self.buf(n("Q" + sfx), (M, H)), self.buf(n("x1" + sfx), (M, H)), self.buf(n("y" + sfx), (M, H))
+            Pm = self.buf(n("P" + sfx), (B * self.heads * T * (1 if pruned else T),))
+            mean2, std2 = self.buf(n("m2" + sfx), (M,)), self.buf(n("s2" + sfx), (M,))
+            h1d, x2 = self.buf(n("h1" + sfx), (M, H)), self.buf(n("x2" + sfx), (M, H))
+            k = d.blk[l]
+            for i, w in enumerate(("wq", "wk", "wv", "w1", "w2")):
+                k.w[i] = self.wbf.data_ptr() + self._widx[p + w] * self._wplane
+            for i, bn in enumerate(("bq", "bk", "bv", "b1", "b2")):
+                k.bias[i] = pp[p + bn]
+            k.ln1_g, k.ln1_b, k.ln2_g, k.ln2_b = pp[p + "ln1_g"], pp[p + "ln1_b"], pp[p + "ln2_g"], pp[p + "ln2_b"]
+            k.q_in, k.mean1, k.std1, k.kmask, k.qmask = ptr(q_in), ptr(mean1), ptr(std1), ptr(kmask), ptr(qmask)
+            k.Q, k.K, k.V, k.P, k.x1, k.y = ptr(Q), ptr(K), ptr(Vv), ptr(Pm), ptr(x1), ptr(y)
+            k.mean2, k.std2, k.h1d, k.x2 = ptr(mean2), ptr(std2), ptr(h1d), ptr(x2)
+            k.d_attn, k.d_ffn1, k.d_ffn2 = _lib.AderDrop(*da.args()), _lib.AderDrop(*d1.args()), _lib.AderDrop(*d2.args())
+            k.pruned = 1 if pruned else 0
+            A[l] = dict(pruned=pruned, x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv, P=Pm,
+                        x1=x1, y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
+            x = x2
+        call("ader_seq_fwd", ctypes.byref(d), self._stream())
         A.update(xL=x, rep=rep, meanf=meanf, stdf=stdf)
         if save:
             self._act = A
@@ -609,6 +675,9 @@ class Engine:
 
     def _lists_async(self, seq, lab, N):
         main = torch.cuda.current_stream()
+        if not self.lists_side_stream:
+            self._lists = self._sparse_lists(seq, lab, N)
+            return
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         self._side.wait_stream(main)         # inputs ready; also orders reuse of last step's list memory after its reader
@@ -617,10 +686,11 @@ class Engine:
         self._lists_seq = (seq, lab)         # keep the inputs alive until the side stream has consumed them
 
     def _lists_wait(self):
-        torch.cuda.current_stream().wait_stream(self._side)
         out, self._lists = self._lists, None
-        for t in out:
-            t.record_stream(torch.cuda.current_stream())
+        if self.lists_side_stream:
+            torch.cuda.current_stream().wait_stream(self._side)
+            for t in out:
+                t.record_stream(torch.cuda.current_stream())
         return out
 
     def _fused_table_adam(self, lr):

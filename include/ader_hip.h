@@ -73,6 +73,36 @@ int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, flo
 int ader_gemm_atb_batch_slabs(const int* M, int n);
 int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* const* dW, float* const* db, const int* M, int n,
                            float* slab, int H, void* stream);
+/* ---- whole forward stack of a session in one workgroup (seq_fwd.hip) ------------------------------------------------
+ * Replaces, for heads == 1, T <= 64, even H <= 150 and <= ADER_SEQ_MAXL blocks, the chain embed_fwd -> per block [ln_fwd,
+ * gemm_x3 x3, attn_x3_fwd, ln_fwd, gemm_x3 x2] -> ln_fwd of the reference forward (ADER.py:41-91; modules.py:44-48,
+ * 118-130,172-223,254-266) by a single launch of B workgroups.  Writes exactly the activations those kernels write (same
+ * buffers and layouts; a block with pruned != 0 keeps only position T-1 of its query / FFN path in compact [B,H] /
+ * [B] / [B,T] buffers, K, V and kmask stay [B*T,..]).  w[i]: the 4 prepared planes (ader_wprep) of wq, wk, wv, w1, w2. */
+#define ADER_SEQ_MAXL 4
+typedef struct { unsigned key, thr; float scale; unsigned base; } AderDrop;   /* counter-based dropout site (see common.h) */
+typedef struct {
+    const void* w[5];
+    const float* bias[5];
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float *q_in, *mean1, *std1, *kmask, *qmask, *Q, *K, *V, *P, *x1, *y, *mean2, *std2, *h1d, *x2;
+    AderDrop d_attn, d_ffn1, d_ffn2;
+    int pruned, pad_;
+} AderSeqBlock;
+typedef struct {
+    const int* seq;               /* [B,T] item ids, 0 = padding */
+    const float *emb, *pos;       /* item table [V,H], positional table [T,H] */
+    float* x0;                    /* [B*T,H] block-0 input (saved for backward) */
+    int* status;                  /* device status word (bad item id) */
+    const float *lnf_g, *lnf_b;
+    float *rep, *meanf, *stdf;    /* [B,H], [B], [B] */
+    int B, T, H, V, L;
+    float sqrtH, sqrt_dh;
+    int pad_;
+    AderDrop d_emb;
+    AderSeqBlock blk[ADER_SEQ_MAXL];
+} AderSeqFwd;
+int ader_seq_fwd(const AderSeqFwd* desc, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
                        unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);

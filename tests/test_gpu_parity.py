@@ -225,6 +225,50 @@ def test_full_last_block_equals_pruned_last_block():
         assert nerr(out[0][1][k], out[1][1][k], floor=1e-4) < 5e-4, k
 
 
+@pytest.mark.parametrize("shape", [(700, 50, 150, 2, 70, 650), (400, 64, 150, 1, 5, 400), (300, 7, 64, 3, 33, 250)])
+@pytest.mark.parametrize("prune", [True, False])
+def test_one_launch_forward_equals_per_op_forward(shape, prune):
+    """ader_seq_fwd (whole stack per session in one workgroup) writes the same representation and the same saved
+    activations as the chain of per-op kernels it replaces: identical arithmetic per element (bf16x3 products, fp32
+    LayerNorm / softmax), identical dropout masks; differences are fp32 rounding of differently ordered MFMA k-steps."""
+    item_num, T, H, L, B, N = shape
+    rs = np.random.RandomState(3)
+    seq = _seqs(rs, B, T, N)
+    seq[0, :] = 0                                 # an all-padding session
+    seq[1, :-1] = 0                               # a single-item session
+    acts = []
+    for fused in (True, False):
+        eng = _engine(item_num, T, H, L, 1, seed=9)
+        assert eng.seq_fused
+        eng.seq_fused = fused
+        eng.prune_last = prune
+        rep = eng.forward(eng._dev_i32(seq), training=True, rate=0.3, step=2, save=True)
+        torch.cuda.synchronize()
+        A = eng._act
+        d = {"rep": rep.cpu().numpy().copy(), "meanf": A["meanf"].cpu().numpy().copy(), "stdf": A["stdf"].cpu().numpy().copy(),
+             "xL": A["xL"].cpu().numpy().copy()}
+        for l in range(L):
+            for k2, v in A[l].items():
+                if isinstance(v, torch.Tensor):
+                    d["%d.%s" % (l, k2)] = v.cpu().numpy().copy()
+        acts.append(d)
+    assert acts[0].keys() == acts[1].keys()
+    for k2 in acts[0]:
+        a, b = acts[0][k2], acts[1][k2]
+        assert a.shape == b.shape, k2
+        if k2.endswith("mask"):
+            assert np.array_equal(a, b), k2
+        elif k2.endswith(".h1d"):
+            # a pre-activation within rounding of zero may take the other ReLU branch
+            same = (a != 0) == (b != 0)
+            assert np.mean(~same) < 1e-3, k2
+            assert nerr(np.where(same, a, 0), np.where(same, b, 0), floor=1e-3) < 1e-4, k2
+        else:
+            # 1e-4: the per-op path evaluates the pruned block's single-query attention with exact f32 FMAs, the fused kernel
+            # with bf16x3 products (2^-16 relative each); everything else agrees to ~1e-6
+            assert nerr(a, b, floor=1e-3) < 1e-4, (k2, nerr(a, b, floor=1e-3))
+
+
 @pytest.mark.parametrize("cfg", [BF16_CFGS[0], BF16_CFGS[1]])
 def test_fused_table_adam_equals_unfused_step(cfg):
     """Engine.fuse_adam applies Adam to the item table inside the table-gradient kernel (dE never written to memory,
