@@ -26,6 +26,8 @@ _SIGS = {
     "ader_gemm_x3": [P, P, P, P, P, P, I, I, I, I, I, I] + _DROP + [P],
     "ader_gemm_atb_x3": [P, P, P, P, P, I, I, P],
     "ader_seq_fwd": [P, P],
+    "ader_seq_bwd_ffn": [P, P],
+    "ader_seq_bwd_qkv": [P, P],
     "ader_gemm_atb_batch_slabs": [P, I],
     "ader_gemm_atb_x3_batch": [P, P, P, P, P, I, P, I, P],
     "ader_mask_dropgrad": [P, P, P, P, I, I, I, I] + _DROP + [P],
@@ -79,6 +81,19 @@ class AderSeqFwd(ctypes.Structure):
     _fields_ = ([(k, c_void_p) for k in ("seq", "emb", "pos", "x0", "status", "lnf_g", "lnf_b", "rep", "meanf", "stdf")] +
                 [(k, c_int) for k in ("B", "T", "H", "V", "L")] + [("sqrtH", c_float), ("sqrt_dh", c_float), ("pad_", c_int),
                                                                   ("d_emb", AderDrop), ("blk", AderSeqBlock * SEQ_MAXL)])
+
+
+class AderSeqBwdFfn(ctypes.Structure):
+    """include/ader_hip.h: AderSeqBwdFfn"""
+    _fields_ = ([(k, c_void_p) for k in ("seq", "dx2", "h1d", "x1", "mean2", "std2", "ln2_g", "w2", "w1", "dh2", "da", "dx1", "slab")] +
+                [("d_ffn1", AderDrop), ("d_ffn2", AderDrop)] + [(k, c_int) for k in ("B", "T", "H", "pruned")])
+
+
+class AderSeqBwdQkv(ctypes.Structure):
+    """include/ader_hip.h: AderSeqBwdQkv"""
+    _fields_ = ([(k, c_void_p) for k in ("seq", "dQ", "dx1", "dK", "dV", "x", "mean1", "std1", "ln1_g", "wq", "wk", "wv", "dx",
+                                         "slab")] +
+                [("d_emb", AderDrop)] + [(k, c_int) for k in ("B", "T", "H", "pruned", "emb_bwd", "pad_")])
 
 
 _NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0"}

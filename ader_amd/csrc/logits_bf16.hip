@@ -441,13 +441,13 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
             // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
             const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
             if (tid < H && id_lo < id_hi) {
-                const int bkt = base_it >> 6;                   // buckets of 64 ids starting at id 1
-                for (int k = f.sp_start[bkt]; k < f.n_sp; ++k) {
+                const int bkt = base_it >> 6;                   // buckets of 64 ids starting at id 1: exactly this half-tile
+                for (int k = f.sp_start[bkt], k1 = f.sp_start[bkt + 1]; k < k1; ++k) {
                     const int id = f.sp_ids[k];
                     if (id >= id_hi) break;
                     F_l[(id - id_lo) * FLD + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
                 }
-                for (int k = f.tg_start[bkt]; k < f.n_tg; ++k) {
+                for (int k = f.tg_start[bkt], k1 = f.tg_start[bkt + 1]; k < k1; ++k) {
                     const int id = f.tg_ids[k];
                     if (id >= id_hi) break;
                     const int b = f.tg_rows[k];

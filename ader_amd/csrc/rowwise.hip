@@ -369,8 +369,9 @@ int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, in
                         float drop_scale, unsigned drop_base, void* stream) {
     const int rows = B * T;
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_embed_bwd_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, rows, H, V,
-                       mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+    if (seq)     // seq == NULL: dx already holds the masked / dropout-scaled rows (ader_seq_bwd_qkv with emb_bwd)
+        hipLaunchKernelGGL(k_embed_bwd_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, rows, H, V,
+                           mk_drop(drop_key, drop_thr, drop_scale, drop_base));
     hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
     HIP_LAUNCH_CHECK();
     return 0;

@@ -174,7 +174,7 @@ class Engine:
         self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
         # whole forward stack in one launch (seq_fwd.hip); the per-op kernels remain for the shapes it does not cover
         self.seq_fused = (self.gemm_x3 and num_heads == 1 and maxlen <= 64 and num_blocks <= _lib.SEQ_MAXL)
-        self.lists_side_stream = os.environ.get("ADER_LISTS_SIDE", "1") == "1"
+        self.lists_side_stream = True      # build the sparse lists under the block kernels
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
         self._atb_q = []
         self.attn_x3 = gemm == "x3" and (hidden_units // num_heads) % 2 == 0      # bf16x3 attention core (attn_x3.hip)
@@ -520,13 +520,13 @@ class Engine:
         use_bf16 = self.shadow is not None and teacher is None
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
         self._deferred = None
-        if defer and self.dp_world == 1:
-            # the id-sorted lists of the fused table update need only the inputs: build them on a side stream, under the
-            # block kernels, instead of between backward and the update
-            labs = pos if n_ex == 0 else torch.cat([pos, ex_pos])
-            self._lists_async(seq, labs, N)
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
+        if defer and self.dp_world == 1:
+            # the id-bucketed lists of the fused table update need only the inputs: build them on a side stream, under the
+            # logit kernels (the one-launch forward owns every CU's LDS; the logit kernels leave room for it)
+            labs = pos if n_ex == 0 else torch.cat([pos, ex_pos])
+            self._lists_async(seq, labs, N)
         A = self._act
         emb = self._pp["emb"]
         demb = self.gradient("emb")
@@ -582,6 +582,7 @@ class Engine:
             call("ader_ln_bwd", ptr(drep), H, ptr(xL.view(B, T, H)[:, T - 1, :]), T * H, pp["lnf_g"], ptr(A["meanf"]),
                  ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
         last_map = (T, T - 1)
+        fused_emb = False
         for l in reversed(range(L)):
             p = "b%d." % l
             S = A[l]
@@ -591,6 +592,12 @@ class Engine:
                 M, rmap, dxo = B, last_map, dxl
             else:
                 M, rmap, dxo = rows, (1, 0), dx
+            if self.seq_fused:
+                emb_bwd = defer and l == 0
+                self._bwd_block_fused(l, S, seq, dxo, dxn, M, B, emb_bwd, A["d_emb"])
+                fused_emb = fused_emb or emb_bwd
+                dx, dxn = dxn, dx
+                continue
             tg = "L" if S["pruned"] else ""
             g = self.buf("bw_g" + tg, (M, H))
             dh2 = self.buf("bw_dh2%d" % l, (M, H))       # the weight-gradient operands stay alive until _atb_flush
@@ -635,12 +642,59 @@ class Engine:
         self._atb_flush()
         self._last_g = dx       # per-position gradient rows of the input embeddings (tests: column-sum checks)
         if defer:
-            call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+            # (block 0's ader_seq_bwd_qkv has already applied the prologue mask / dropout to the rows: seq = NULL)
+            call("ader_embed_bwd_rows", None if fused_emb else ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
             self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)
         else:
             call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)
         return self.loss
+
+    def _bwd_block_fused(self, l, S, seq, dxo, dxn, M, B, emb_bwd, d_emb):
+        """Backward of block l with the session-tiled chains (seq_bwd.hip) around the attention backward; queues the five
+        weight-gradient products.  dxo: gradient of the block output ([B*T,H], or [B,H] for the pruned last block);
+        dxn [B*T,H] receives the gradient of the block input."""
+        T, H = self.T, self.H
+        rows = B * T
+        st = self._stream()
+        p = "b%d." % l
+        pp, gp = self._pp, self._gp
+        pruned = 1 if S["pruned"] else 0
+        wp = lambda w: self.wbf.data_ptr() + self._widx[p + w] * self._wplane     # noqa: E731
+        dh2, da_ = self.buf("bw_dh2%d" % l, (M, H)), self.buf("bw_da%d" % l, (M, H))
+        dx1, dQ = self.buf("bw_dx1%d" % l, (M, H)), self.buf("bw_dQ%d" % l, (M, H))
+        dK, dV = self.buf("bw_dK%d" % l, (rows, H)), self.buf("bw_dV%d" % l, (rows, H))
+        slab = self.buf("ln_slab", (B * 2 * H,))
+        f = _lib.AderSeqBwdFfn()
+        f.seq, f.dx2, f.h1d, f.x1, f.mean2, f.std2 = ptr(seq), ptr(dxo), ptr(S["h1d"]), ptr(S["x1"]), ptr(S["mean2"]), ptr(S["std2"])
+        f.ln2_g, f.w2, f.w1 = pp[p + "ln2_g"], wp("w2"), wp("w1")
+        f.dh2, f.da, f.dx1, f.slab = ptr(dh2), ptr(da_), ptr(dx1), ptr(slab)
+        f.d_ffn1, f.d_ffn2 = _lib.AderDrop(*S["d1"].args()), _lib.AderDrop(*S["d2"].args())
+        f.B, f.T, f.H, f.pruned = B, T, H, pruned
+        call("ader_seq_bwd_ffn", ctypes.byref(f), st)
+        call("ader_reduce_slabs", ptr(slab), 2 * H, B, H, 1, H, gp[p + "ln2_g"], gp[p + "ln2_b"], st)
+        wslab = self._ws["w_slab"]
+        self._atb(S["h1d"], dh2, p + "w2", p + "b2", wslab, M)
+        self._atb(S["y"], da_, p + "w1", p + "b1", wslab, M)
+        if pruned:
+            call("ader_attn_last_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
+                 ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads, *S["da"].args(), st)
+        else:
+            call("ader_attn_x3_bwd" if self.attn_x3 else "ader_attn_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]),
+                 ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, self.heads,
+                 *S["da"].args(), st)
+        q = _lib.AderSeqBwdQkv()
+        q.seq, q.dQ, q.dx1, q.dK, q.dV, q.x = ptr(seq), ptr(dQ), ptr(dx1), ptr(dK), ptr(dV), ptr(S["x"])
+        q.mean1, q.std1, q.ln1_g = ptr(S["mean1"]), ptr(S["std1"]), pp[p + "ln1_g"]
+        q.wq, q.wk, q.wv = wp("wq"), wp("wk"), wp("wv")
+        q.dx, q.slab = ptr(dxn), ptr(slab)
+        q.d_emb = _lib.AderDrop(*d_emb.args())
+        q.B, q.T, q.H, q.pruned, q.emb_bwd = B, T, H, pruned, 1 if emb_bwd else 0
+        call("ader_seq_bwd_qkv", ctypes.byref(q), st)
+        call("ader_reduce_slabs", ptr(slab), 2 * H, B, H, 1, H, gp[p + "ln1_g"], gp[p + "ln1_b"], st)
+        self._atb(S["q_in"], dQ, p + "wq", p + "bq", wslab, M)
+        self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
+        self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
 
     def _lr_t(self, lr):
         return float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
@@ -659,9 +713,11 @@ class Engine:
         self._advance_adam()
 
     def _sparse_lists(self, seq, lab, N):
-        """Id-sorted lists of the sparse table-gradient terms (input positions, one-hot targets) + bucket offsets."""
-        ids, order = torch.sort(seq.reshape(-1), stable=True)
-        tids, torder = torch.sort(lab.reshape(-1), stable=True)
+        """Id-sorted lists of the sparse table-gradient terms (input positions, one-hot targets) for ader_lbf_bwd_adam:
+        (ids, rows, bucket starts) x 2 -- a stable sort, so duplicates of an id are added in row order (deterministic)."""
+        seq, lab = seq.reshape(-1), lab.reshape(-1)
+        ids, order = torch.sort(seq, stable=True)
+        tids, torder = torch.sort(lab, stable=True)
         ids, order = ids.to(torch.int32), order.to(torch.int32)
         tids, torder = tids.to(torch.int32), torder.to(torch.int32)
         gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
@@ -742,6 +798,7 @@ class Engine:
             span = self.layout["pos"][0]
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
+        tiles = self.shard_items // 128
         ids, order, sp_start, tids, torder, tg_start = self._sparse_lists(seq_g, lab_g, N)
         tiles = self.shard_items // 128
         with self._sec("logits_bwd_adam"):

@@ -32,7 +32,8 @@ int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, i
                    unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
 
 /* as ader_embed_bwd but without the scatter into demb: dx is left holding the per-position gradient rows (consumed by
- * ader_lbf_bwd_adam through an id-sorted list); dpos is overwritten. */
+ * ader_lbf_bwd_adam through an id-sorted list); dpos is overwritten.  seq == NULL: dx already holds those rows
+ * (ader_seq_bwd_qkv with emb_bwd) and only dpos is computed. */
 int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, unsigned drop_key,
                         unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
 
@@ -103,6 +104,31 @@ typedef struct {
     AderSeqBlock blk[ADER_SEQ_MAXL];
 } AderSeqFwd;
 int ader_seq_fwd(const AderSeqFwd* desc, void* stream);
+
+/* ---- session-tiled backward chains of one block (seq_bwd.hip) --------------------------------------------------------
+ * The row-local kernels on either side of the attention backward, one launch of B workgroups each (tf.gradients of
+ * ADER.py:62-81).  Tensors and layouts as written by the per-op kernels they replace; pruned != 0: the block kept only
+ * position T-1 of its query / FFN path (compact [B,H] / [B] tensors: dx2, h1d, x1, mean2, std2, dh2, da, dx1, dQ, mean1,
+ * std1); K/V-side tensors (dK, dV, x, dx) are always [B*T,H].  slab: [B][2][H] per-session partial sums of the LayerNorm
+ * gamma / beta gradients (reduce with ader_reduce_slabs).  w*: prepared planes (ader_wprep).  */
+typedef struct {      /* replaces ader_mask_dropgrad, ader_gemm_x3<RELUDROPGRAD,trans>, ader_gemm_x3<ADD,trans>, ader_ln_bwd */
+    const int* seq;                       /* [B,T] */
+    const float *dx2, *h1d, *x1, *mean2, *std2, *ln2_g;
+    const void *w2, *w1;
+    float *dh2, *da, *dx1, *slab;
+    AderDrop d_ffn1, d_ffn2;
+    int B, T, H, pruned;
+} AderSeqBwdFfn;
+typedef struct {      /* replaces ader_gemm_x3<ADD,trans> x3, ader_ln_bwd, ader_add_rows (and ader_embed_bwd_rows if emb_bwd) */
+    const int* seq;                       /* [B,T]; read only when emb_bwd != 0 */
+    const float *dQ, *dx1, *dK, *dV, *x, *mean1, *std1, *ln1_g;
+    const void *wq, *wk, *wv;
+    float *dx, *slab;                     /* dx: [B*T,H] gradient of the block input */
+    AderDrop d_emb;                       /* emb_bwd: also apply the prologue backward dx *= (seq != 0) * keep * scale */
+    int B, T, H, pruned, emb_bwd, pad_;
+} AderSeqBwdQkv;
+int ader_seq_bwd_ffn(const AderSeqBwdFfn* desc, void* stream);
+int ader_seq_bwd_qkv(const AderSeqBwdQkv* desc, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
                        unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);

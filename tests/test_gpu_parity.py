@@ -269,6 +269,34 @@ def test_one_launch_forward_equals_per_op_forward(shape, prune):
             assert nerr(a, b, floor=1e-3) < 1e-4, (k2, nerr(a, b, floor=1e-3))
 
 
+@pytest.mark.parametrize("shape", [(700, 50, 150, 2, 70, 650), (400, 64, 150, 1, 5, 400), (300, 7, 64, 3, 33, 250)])
+@pytest.mark.parametrize("prune", [True, False])
+def test_session_tiled_step_equals_per_op_step(shape, prune):
+    """Loss and every gradient from the session-tiled kernels (ader_seq_fwd, ader_seq_bwd_ffn, ader_seq_bwd_qkv) against the
+    per-op kernel chain they replace, same parameters, inputs and dropout masks."""
+    item_num, T, H, L, B, N = shape
+    rs = np.random.RandomState(4)
+    seq = _seqs(rs, B, T, N)
+    seq[0, :] = 0
+    seq[1, :-1] = 0
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    out = []
+    for fused in (True, False):
+        eng = _engine(item_num, T, H, L, 1, seed=9)
+        eng.seq_fused = fused
+        eng.prune_last = prune
+        eng.global_step = 3
+        loss = eng.loss_and_grad(seq, pos, N, rate=0.3)
+        torch.cuda.synchronize()
+        out.append((float(loss.item()), {k: eng.gradient(k).cpu().numpy().copy() for k in eng.layout},
+                    eng._last_g.cpu().numpy().copy()))
+    assert abs(out[0][0] - out[1][0]) < 2e-5 * max(1.0, abs(out[1][0]))
+    assert nerr(out[0][2], out[1][2], floor=1e-6) < 2e-3        # per-position input-gradient rows
+    for k in out[0][1]:
+        # differences: fp32 summation order, ReLU branch flips of ~zero pre-activations (cf. the x3 oracle test: 6e-4)
+        assert nerr(out[0][1][k], out[1][1][k], floor=1e-4) < 6e-4, (k, nerr(out[0][1][k], out[1][1][k], floor=1e-4))
+
+
 @pytest.mark.parametrize("cfg", [BF16_CFGS[0], BF16_CFGS[1]])
 def test_fused_table_adam_equals_unfused_step(cfg):
     """Engine.fuse_adam applies Adam to the item table inside the table-gradient kernel (dE never written to memory,
