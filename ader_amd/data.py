@@ -230,7 +230,8 @@ class Evaluator:
     matrix as in the reference; when the model offers `rank_targets(seq, pos, max_item)` (the HIP
     count-greater kernel) that is used instead -- only pred[label-1] is ever read (util.py:325)."""
 
-    def __init__(self, data, is_subseq, maxlen, batch_size, max_item, mode, model, sess):
+    def __init__(self, data, is_subseq, maxlen, batch_size, max_item, mode, model, sess, shard=(0, 1)):
+        self.shard = shard          # (rank, world): evaluation batches are independent units (SURVEY 8e)
         self.max_item = max_item
         self.model = model
         self.sess = sess
@@ -240,17 +241,23 @@ class Evaluator:
         self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq)
 
     def evaluate(self, epoch):
-        self.ranks = []
+        rank, world = self.shard
         fast = getattr(self.model, "rank_targets", None)
-        for _ in range(self.evaluate_sampler.batch_num()):
-            seq, pos = self.evaluate_sampler.next_batch()
-            if len(pos) == 0:
+        mine = []                    # [(batch index, ranks)] of the batches this rank evaluates
+        for b in range(self.evaluate_sampler.batch_num()):
+            seq, pos = self.evaluate_sampler.next_batch()       # every rank walks the same batch sequence
+            if len(pos) == 0 or b % world != rank:
                 continue
             if fast is not None:
-                self.ranks.extend(int(x) for x in fast(seq, pos, self.max_item))
+                r = [int(x) for x in fast(seq, pos, self.max_item)]
             else:
                 pred = self.model.predict(self.sess, seq, list(range(1, self.max_item + 1)))
-                self.ranks.extend(int(p[i - 1]) for p, i in zip(pred, pos))
+                r = [int(p[i - 1]) for p, i in zip(pred, pos)]
+            mine.append((b, r))
+        if world > 1:                # ranks back in batch order on every rank: the metric sums run in the reference's order
+            from . import dist as _dist
+            mine = sorted(x for part in _dist.gather_lists(mine, world) for x in part)
+        self.ranks = [x for _, r in mine for x in r]
         return self.display(epoch)
 
     def results(self):
@@ -260,7 +267,8 @@ class Evaluator:
         r = self.results()
         info = 'epoch:%d, %s (MRR@20: %.4f, RECALL@20: %.4f, MRR@10: %.4f, RECALL@10: %.4f)' \
                % (epoch, self.mode, r[0], r[1], r[2], r[3])
-        print(info)
+        if self.shard[0] == 0:
+            print(info)
         return info
 
 

@@ -67,6 +67,31 @@ def allreduce_flat(grad, used_table_elems, table_span, bucket_elems=64 << 20, gr
         dist.all_reduce(grad[table_span:], op=dist.ReduceOp.SUM, group=group)
 
 
+def gather_lists(local, world, group=None):
+    """[list of rank 0, list of rank 1, ...] of picklable host objects (ranks, selected indices): tiny payloads."""
+    if world == 1:
+        return [local]
+    out = [None] * world
+    dist.all_gather_object(out, local, group=group)
+    return out
+
+
+def split_groups(sizes, world):
+    """Contiguous split of label groups into `world` chunks of near-equal ROW counts: [(g_lo, g_hi)] per rank
+    (herding groups are independent units)."""
+    n = len(sizes)
+    total = int(sum(sizes))
+    bounds, acc, g = [0], 0, 0
+    for r in range(1, world):
+        target = total * r / world
+        while g < n and acc + sizes[g] / 2.0 <= target:
+            acc += sizes[g]
+            g += 1
+        bounds.append(g)
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
 class DataParallel:
     """Installs the gradient exchange into an Engine.  Usage per step:
          dp.set_step(n_train_local_offset)  (row offset of this rank's first row in the global batch)

@@ -175,6 +175,8 @@ class Engine:
         # whole forward stack in one launch (seq_fwd.hip); the per-op kernels remain for the shapes it does not cover
         self.seq_fused = (self.gemm_x3 and num_heads == 1 and maxlen <= 64 and num_blocks <= _lib.SEQ_MAXL)
         self.lists_side_stream = True      # build the sparse lists under the block kernels
+        self.late_side_stream = True       # small-parameter gradients / Adam run beside the (HBM-bound) fused table update
+        self._late, self._late_on = [], False
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
         self._atb_q = []
         self.attn_x3 = gemm == "x3" and (hidden_units // num_heads) % 2 == 0      # bf16x3 attention core (attn_x3.hip)
@@ -310,6 +312,14 @@ class Engine:
             return
         fn = "ader_gemm_atb_x3" if self.gemm_x3 else "ader_gemm_atb"
         call(fn, ptr(A), ptr(G), ptr(slab), self._gp[wname], self._gp[bname], M, self.H, self._stream())
+
+    def _late_call(self, name, *args):
+        """A launch whose result only feeds the small-parameter update: issued now, or queued for the side stream that runs
+        beside the fused table update (_fused_table_adam)."""
+        if self._late_on:
+            self._late.append((name, args))
+        else:
+            call(name, *args, self._stream())
 
     def _atb_flush(self):
         q, self._atb_q = self._atb_q, []
@@ -583,6 +593,7 @@ class Engine:
                  ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
         last_map = (T, T - 1)
         fused_emb = False
+        self._late_on = bool(defer and self.dp_world == 1 and self.seq_fused and self.late_side_stream)
         for l in reversed(range(L)):
             p = "b%d." % l
             S = A[l]
@@ -639,15 +650,20 @@ class Engine:
             self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
             self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
             dx, dxn = dxn, dx
-        self._atb_flush()
+        if not self._late_on:
+            self._atb_flush()
         self._last_g = dx       # per-position gradient rows of the input embeddings (tests: column-sum checks)
         if defer:
             # (block 0's ader_seq_bwd_qkv has already applied the prologue mask / dropout to the rows: seq = NULL)
-            call("ader_embed_bwd_rows", None if fused_emb else ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+            if fused_emb:
+                self._late_call("ader_embed_bwd_rows", None, ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args())
+            else:
+                call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
             self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)
         else:
             call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)
+        self._late_on = False
         return self.loss
 
     def _bwd_block_fused(self, l, S, seq, dxo, dxn, M, B, emb_bwd, d_emb):
@@ -664,15 +680,15 @@ class Engine:
         dh2, da_ = self.buf("bw_dh2%d" % l, (M, H)), self.buf("bw_da%d" % l, (M, H))
         dx1, dQ = self.buf("bw_dx1%d" % l, (M, H)), self.buf("bw_dQ%d" % l, (M, H))
         dK, dV = self.buf("bw_dK%d" % l, (rows, H)), self.buf("bw_dV%d" % l, (rows, H))
-        slab = self.buf("ln_slab", (B * 2 * H,))
+        slab2, slab1 = self.buf("ln_slab%d_2" % l, (B * 2 * H,)), self.buf("ln_slab%d_1" % l, (B * 2 * H,))
         f = _lib.AderSeqBwdFfn()
         f.seq, f.dx2, f.h1d, f.x1, f.mean2, f.std2 = ptr(seq), ptr(dxo), ptr(S["h1d"]), ptr(S["x1"]), ptr(S["mean2"]), ptr(S["std2"])
         f.ln2_g, f.w2, f.w1 = pp[p + "ln2_g"], wp("w2"), wp("w1")
-        f.dh2, f.da, f.dx1, f.slab = ptr(dh2), ptr(da_), ptr(dx1), ptr(slab)
+        f.dh2, f.da, f.dx1, f.slab = ptr(dh2), ptr(da_), ptr(dx1), ptr(slab2)
         f.d_ffn1, f.d_ffn2 = _lib.AderDrop(*S["d1"].args()), _lib.AderDrop(*S["d2"].args())
         f.B, f.T, f.H, f.pruned = B, T, H, pruned
         call("ader_seq_bwd_ffn", ctypes.byref(f), st)
-        call("ader_reduce_slabs", ptr(slab), 2 * H, B, H, 1, H, gp[p + "ln2_g"], gp[p + "ln2_b"], st)
+        self._late_call("ader_reduce_slabs", ptr(slab2), 2 * H, B, H, 1, H, gp[p + "ln2_g"], gp[p + "ln2_b"])
         wslab = self._ws["w_slab"]
         self._atb(S["h1d"], dh2, p + "w2", p + "b2", wslab, M)
         self._atb(S["y"], da_, p + "w1", p + "b1", wslab, M)
@@ -687,11 +703,11 @@ class Engine:
         q.seq, q.dQ, q.dx1, q.dK, q.dV, q.x = ptr(seq), ptr(dQ), ptr(dx1), ptr(dK), ptr(dV), ptr(S["x"])
         q.mean1, q.std1, q.ln1_g = ptr(S["mean1"]), ptr(S["std1"]), pp[p + "ln1_g"]
         q.wq, q.wk, q.wv = wp("wq"), wp("wk"), wp("wv")
-        q.dx, q.slab = ptr(dxn), ptr(slab)
+        q.dx, q.slab = ptr(dxn), ptr(slab1)
         q.d_emb = _lib.AderDrop(*d_emb.args())
         q.B, q.T, q.H, q.pruned, q.emb_bwd = B, T, H, pruned, 1 if emb_bwd else 0
         call("ader_seq_bwd_qkv", ctypes.byref(q), st)
-        call("ader_reduce_slabs", ptr(slab), 2 * H, B, H, 1, H, gp[p + "ln1_g"], gp[p + "ln1_b"], st)
+        self._late_call("ader_reduce_slabs", ptr(slab1), 2 * H, B, H, 1, H, gp[p + "ln1_g"], gp[p + "ln1_b"])
         self._atb(S["q_in"], dQ, p + "wq", p + "bq", wslab, M)
         self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
         self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
@@ -735,7 +751,7 @@ class Engine:
             self._lists = self._sparse_lists(seq, lab, N)
             return
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
         self._side.wait_stream(main)         # inputs ready; also orders reuse of last step's list memory after its reader
         with torch.cuda.stream(self._side):
             self._lists = self._sparse_lists(seq, lab, N)
@@ -758,18 +774,39 @@ class Engine:
         H, T = self.H, self.T
         lr_t = self._lr_t(lr)
         ids, order, sp_start, tids, torder, tg_start = self._lists_wait()
+        span = self.layout["pos"][0]
+
+        def small_update():     # everything that feeds / is the update of the non-table parameters
+            for name, args in self._late:
+                call(name, *args, self._stream())
+            self._late = []
+            self._atb_flush()
+            with self._sec("adam"):
+                call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
+                     self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1,
+                     self.beta2, self.eps, None, 0, H, self._stream())
+            self._advance_adam()
+
+        main = torch.cuda.current_stream()
+        overlap = bool(self._late or self._atb_q) and self.late_side_stream
+        if overlap:
+            # weight-gradient products, LayerNorm / positional reductions, small Adam and the bf16 weight planes are compute /
+            # latency bound and independent of the table: a side stream runs them under the HBM-bound table update
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.device, priority=-1)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                small_update()
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
                  ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                  ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
                  self.beta1, self.beta2, self.eps, 0, -1, st)
-        span = self.layout["pos"][0]
-        with self._sec("adam"):
-            call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
-                 self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
-                 self.eps, None, 0, H, st)
+        if overlap:
+            main.wait_stream(self._side)
+        else:
+            small_update()
         self._deferred = None
-        self._advance_adam()
 
     def _fused_table_adam_sharded(self, lr):
         """Data-parallel table update without the dense gradient exchange (SURVEY 8e "ZeRO-1 style"): instead of

@@ -55,7 +55,8 @@ class ExemplarStore:
 class ExemplarGenerator:
     """Same constructor arguments as the reference (util.py:366-374)."""
 
-    def __init__(self, data, exemplar_size, disable_m, batch_size, maxlen, dropout_rate, max_item):
+    def __init__(self, data, exemplar_size, disable_m, batch_size, maxlen, dropout_rate, max_item, shard=(0, 1)):
+        self.shard = shard          # (rank, world): label groups are independent herding units (SURVEY 8e)
         self.exemplars = defaultdict(list)
         self.m = exemplar_size
         self.max_item = max_item
@@ -78,7 +79,24 @@ class ExemplarGenerator:
         """Select exemplars by herding (util.py:436-461).  `model` is an ader_amd.model.Ader; `sess` is
         accepted for call-surface compatibility.  Returns the number of exemplars saved."""
         labels, offs, quota, rows = self._segments()
-        sel_idx, sel_cnt = model.engine.herding_select(rows[:, :self.maxlen], offs, quota, self.max_item)
+        rank, world = self.shard
+        if world == 1:
+            sel_idx, sel_cnt = model.engine.herding_select(rows[:, :self.maxlen], offs, quota, self.max_item)
+        else:
+            # each rank selects inside its contiguous chunk of label groups; the per-group index lists are exchanged
+            # (quotas were drawn from the same RNG stream on every rank, util.py:398)
+            from . import dist as _dist
+            chunks = _dist.split_groups(np.diff(offs).tolist(), world)
+            g0, g1 = chunks[rank]
+            r0, r1 = int(offs[g0]), int(offs[g1])
+            if g1 > g0:
+                li, lc = model.engine.herding_select(rows[r0:r1, :self.maxlen], offs[g0:g1 + 1] - r0, quota[g0:g1],
+                                                     self.max_item)
+            else:
+                li, lc = np.zeros(0, np.int64), np.zeros(0, np.int32)
+            parts = _dist.gather_lists((np.asarray(li), np.asarray(lc)), world)
+            sel_idx = np.concatenate([np.asarray(p[0]) for p in parts])
+            sel_cnt = np.concatenate([np.asarray(p[1]) for p in parts])
         keep = []
         for g, label in enumerate(labels):
             c = int(sel_cnt[g])

@@ -7,6 +7,12 @@ Differences from the reference that do not change results: booleans are parsed w
 batches and teacher logits stay on the GPU (the reference feeds Python float lists every step, util.py:254);
 the best-epoch checkpoint is kept in memory and written to disk only with --save_ckpt.
 Extra flags: --logits_dtype, --max_periods, --data_root, --device, --save_ckpt.
+
+Data parallel: launched as `python -m torch.distributed.run --nproc-per-node W -m ader_amd.main ...` every
+rank builds the same batches from the same RNG streams, trains on its slice of the train rows and of the exemplar rows
+(loss terms scaled by the global sub-batch sizes, gradients exchanged by ader_amd.dist), evaluates every W-th batch and
+runs herding on its chunk of label groups; ranks / selected indices are exchanged so every rank holds the reference's
+metrics and exemplar set.  Rank 0 writes the logs.
 """
 import argparse
 import math
@@ -64,6 +70,7 @@ def build_parser():
     p.add_argument('--data_root', default=None, type=str)
     p.add_argument('--results_root', default='results', type=str)
     p.add_argument('--save_ckpt', default=False, type=str2bool)
+    p.add_argument('--dist_backend', default='nccl', type=str, help="torch.distributed backend when WORLD_SIZE > 1")
     p.add_argument('--eval_batch', default=1024, type=int, help="rows per evaluation launch (results do not depend on it)")
     return p
 
@@ -71,10 +78,22 @@ def build_parser():
 ITEM_NUM = {'DIGINETICA': 43136, 'YOOCHOOSE': 25958}     # main.py:133-138
 
 
+class _NullLog:
+    def write(self, *_):
+        pass
+
+    flush = close = write
+
+
 def run(args, log=print):
+    from . import dist as adist
+    rank, world, local = adist.init(getattr(args, "dist_backend", "nccl"))
+    shard = (rank, world)
+    if rank != 0:
+        log = lambda *_: None      # noqa: E731
     out_dir = os.path.join(args.results_root, args.dataset + '-' + args.save_dir)
     os.makedirs(out_dir, exist_ok=True)
-    logs = open(os.path.join(out_dir, 'Training_logs.txt'), mode='w')
+    logs = open(os.path.join(out_dir, 'Training_logs.txt'), mode='w') if rank == 0 else _NullLog()
     logs.write('\n'.join([str(k) + ',' + str(v) for k, v in sorted(vars(args).items(), key=lambda x: x[0])]))
     np.random.seed(args.random_seed)
     random.seed(args.random_seed)
@@ -83,7 +102,9 @@ def run(args, log=print):
         raise ValueError('Invalid dataset name')
     item_num = ITEM_NUM[args.dataset]
     args.dropout_rate = 0 if args.finetune else args.dropout_rate      # main.py:141
-    model = Ader(item_num, args, device="cuda:%d" % args.device_num)
+    dev_index = (local % max(torch.cuda.device_count(), 1)) if world > 1 else args.device_num
+    model = Ader(item_num, args, device="cuda:%d" % dev_index, dp_rank=rank, dp_world=world)
+    dp = adist.DataParallel(model.engine, rank, world)
     baseline = args.finetune or args.dropout or args.joint
     dataloader = DataLoader(args.dataset, root=args.data_root)
     n_periods = dataloader.num_periods() - 1
@@ -141,18 +162,26 @@ def run(args, log=print):
             for epoch in range(1, args.num_epochs + 1):
                 for _ in range(batch_num):
                     seq, pos = train_sampler.next_batch()
+                    kw = {}
+                    lo, hi = adist.shard_bounds(len(pos), world, rank)       # this rank's train rows
+                    if world > 1:
+                        kw.update(n_train_global=len(pos))
+                        dp.set_rows(lo, max_item)
                     if use_ex:
                         ex_seq, ex_pos, idx = exemplar_sampler.next_exemplar_batch()
-                        seq = np.concatenate([seq, ex_seq]) if len(ex_seq) else seq
+                        elo, ehi = adist.shard_bounds(len(ex_seq), world, rank)  # ... and exemplar rows (main.py:229 order kept)
+                        if world > 1:
+                            kw.update(n_ex_global=len(ex_seq))
+                        seq_l = np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]) if ehi > elo else seq[lo:hi]
                         if args.disable_distillation:
-                            model.train_step(seq, pos, max_item, args.lr, args.dropout_rate, ex_pos=ex_pos)
+                            model.train_step(seq_l, pos[lo:hi], max_item, args.lr, args.dropout_rate, ex_pos=ex_pos[elo:ehi], **kw)
                         else:
-                            model.train_step(seq, pos, max_item, args.lr, args.dropout_rate, teacher=store.logits,
-                                             ex_trow=idx.astype(np.int32))
+                            model.train_step(seq_l, pos[lo:hi], max_item, args.lr, args.dropout_rate, teacher=store.logits,
+                                             ex_trow=idx[elo:ehi].astype(np.int32), **kw)
                     else:
-                        model.train_step(seq, pos, max_item, args.lr, args.dropout_rate)
+                        model.train_step(seq[lo:hi], pos[lo:hi], max_item, args.lr, args.dropout_rate, **kw)
                 model.engine.check_status()
-                valid_evaluator = Evaluator(valid_subseq, True, args.maxlen, args.eval_batch, max_item, 'valid', model, sess)
+                valid_evaluator = Evaluator(valid_subseq, True, args.maxlen, args.eval_batch, max_item, 'valid', model, sess, shard)
                 info = valid_evaluator.evaluate(epoch)
                 logs.write(info + '\n')
                 performance = valid_evaluator.results()[1]
@@ -165,14 +194,14 @@ def run(args, log=print):
                     best_epoch = epoch
                     best_performance = performance
                     period_best = best_state = model.engine.state_dict()
-                    if args.save_ckpt:
+                    if args.save_ckpt and rank == 0:
                         d = os.path.join(out_dir, 'model', 'period%d' % period)
                         os.makedirs(d, exist_ok=True)
                         saver.save(sess, os.path.join(d, 'epoch=%d.ckpt' % epoch))
             if period_best is None:                                      # no epoch improved on 0: keep the last state
                 best_state = model.engine.state_dict()
             model.engine.load_state_dict(best_state)                    # saver.restore(best), main.py:283
-            test_evaluator = Evaluator(test_sess, False, args.maxlen, args.eval_batch, max_item, 'test', model, sess)
+            test_evaluator = Evaluator(test_sess, False, args.maxlen, args.eval_batch, max_item, 'test', model, sess, shard)
             info = test_evaluator.evaluate(best_epoch)
             logs.write(info + '\n')
             r = test_evaluator.results()
@@ -184,7 +213,7 @@ def run(args, log=print):
                 exemplar_candidate.extend(valid_subseq)
                 exemplar_candidate.extend(exemplar_subseq)
                 exemplar = ExemplarGenerator(exemplar_candidate, args.exemplar_size, args.equal_exemplar, args.batch_size,
-                                             args.maxlen, args.dropout_rate, max_item)
+                                             args.maxlen, args.dropout_rate, max_item, shard)
                 if args.selection == 'herding':
                     saved_num = exemplar.herding_selection(sess, model)
                 elif args.selection == 'random':

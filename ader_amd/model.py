@@ -25,12 +25,13 @@ class _Handle:
 
 
 class Ader:
-    def __init__(self, item_num, args, reuse=None, device="cuda:0", logits_dtype=None):
+    def __init__(self, item_num, args, reuse=None, device="cuda:0", logits_dtype=None, dp_rank=0, dp_world=1):
         self.args = args
         self.item_num = item_num
         ld = logits_dtype or getattr(args, "logits_dtype", "f32")
         self.engine = Engine(item_num, maxlen=args.maxlen, hidden_units=args.hidden_units, num_blocks=args.num_blocks,
-                             num_heads=args.num_heads, seed=args.random_seed, device=device, logits_dtype=ld)
+                             num_heads=args.num_heads, seed=args.random_seed, device=device, logits_dtype=ld,
+                             dp_rank=dp_rank, dp_world=dp_world)
         for n in ("is_training", "input_seq", "pos", "exemplar_logits", "exemplar_pos", "max_item", "lr", "dropout_rate",
                   "test_item", "rep", "logits", "loss", "train_op", "pred_last", "exemp_loss"):
             setattr(self, n, _Handle(n))

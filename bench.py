@@ -31,11 +31,28 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 
-def synth_batch(B, T, N, seed, device):
+def synth_batch(B, T, N, seed, device, regime="dense"):
+    """dense: every row full length, ids ~ U[1,N] (BASELINE.json configs[4], the headline).  realistic: session
+    length ~ 1 + Geometric(0.2) clipped to [1,T] (mean ~5, left-padded with 0), ids ~ Zipf(1.05) over a random permutation
+    of [1,N]; labels follow the same id law."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    seq = torch.randint(1, N + 1, (B, T), generator=g, dtype=torch.int32)
-    pos = torch.randint(1, N + 1, (B,), generator=g, dtype=torch.int32)
-    return seq.to(device), pos.to(device)
+    if regime == "dense":
+        seq = torch.randint(1, N + 1, (B, T), generator=g, dtype=torch.int32)
+        pos = torch.randint(1, N + 1, (B,), generator=g, dtype=torch.int32)
+        return seq.to(device), pos.to(device)
+    rs = np.random.RandomState(seed)
+    perm = np.random.RandomState(12345).permutation(N).astype(np.int64) + 1
+    w = 1.0 / np.arange(1, N + 1, dtype=np.float64) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+
+    def ids(n):
+        return perm[np.minimum(np.searchsorted(cdf, rs.rand(n)), N - 1)]
+    seq = np.zeros((B, T), dtype=np.int32)
+    ln = np.clip(rs.geometric(0.2, size=B), 1, T)
+    for b in range(B):
+        seq[b, T - ln[b]:] = ids(ln[b])
+    pos = ids(B).astype(np.int32)
+    return torch.from_numpy(seq).to(device), torch.from_numpy(pos).to(device)
 
 
 def cpu_baseline(N, B, T, H, L, heads, rate, lr):
@@ -71,6 +88,10 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--logits", choices=["bf16", "f32"], default="bf16",
                     help="operand type of the logit GEMMs (fp32 master table, fp32 accumulate/softmax either way)")
+    ap.add_argument("--regime", choices=["dense", "realistic"], default="dense",
+                    help="synthetic id/length law (SURVEY 8d); the headline number is the dense regime")
+    ap.add_argument("--exemplars", type=int, default=0,
+                    help="ADER-mode variant: append this many exemplar rows distilled against N(0,1) teacher logits over 0.9 N items")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -90,8 +111,14 @@ def main():
     dp = adist.DataParallel(eng, rank, world)
     dp.set_rows(rank * B, N)
     nbatch = 4
-    batches = [synth_batch(B, T, N, 1000 * s + rank, dev) for s in range(nbatch)]   # resident in HBM before timing
+    E = args.exemplars
+    batches = [synth_batch(B + E, T, N, 1000 * s + rank, dev, args.regime) for s in range(nbatch)]   # resident in HBM before timing
     kw = dict(rate=rate, n_train_global=B * world)
+    if E:
+        Np = int(0.9 * N)
+        teacher = torch.randn(E, Np, generator=torch.Generator().manual_seed(7)).to(dev)     # resident teacher logits [E,Np]
+        kw.update(teacher=teacher, ex_trow=torch.arange(E, dtype=torch.int32, device=dev), lambda_=0.8, n_ex_global=E * world)
+        batches = [(sq, ps[:B]) for sq, ps in batches]
 
     def sync():
         if world > 1:
@@ -186,7 +213,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.logits == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, dense regime (BASELINE.json configs[4])",
+            "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, %s regime%s (BASELINE.json configs[4])"
+                                   % (args.regime, ", +%d distilled exemplar rows" % E if E else ""),
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam",
                        "exchange": ("none" if world == 1 else

@@ -110,3 +110,82 @@ def test_parameter_layout_is_aligned_and_disjoint():
     assert all(off % 64 == 0 for off, _ in spans)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
     assert spans[-1][1] <= total and total % 64 == 0
+
+
+# ----------------------------------------------------------------------------------------------- sharded eval / herding
+class _FakeModel:
+    """rank_targets / herding stand-ins that are pure functions of their inputs (the sharding logic is what is tested)."""
+
+    class _Eng:
+        H = 4
+
+        def herding_select(self, seq_rows, offs, quota, max_item):
+            n = len(seq_rows)
+            sel = np.zeros(n, dtype=np.int64)
+            cnt = np.zeros(len(quota), dtype=np.int32)
+            for g in range(len(quota)):
+                rows = seq_rows[offs[g]:offs[g + 1]]
+                order = np.argsort(-(rows.sum(axis=1) % 7), kind="stable")[:quota[g]]
+                sel[offs[g]:offs[g] + len(order)] = order
+                cnt[g] = len(order)
+            return sel, cnt
+
+        def teacher_logits(self, rows, max_item):
+            return torch.zeros(len(rows), 3)
+
+    engine = _Eng()
+
+    def rank_targets(self, seq, pos, max_item):
+        return [int((int(np.asarray(s).sum()) * 31 + int(p)) % 50) for s, p in zip(seq, pos)]
+
+
+def _host_problem():
+    rs = np.random.RandomState(3)
+    sessions = [rs.randint(1, 40, size=rs.randint(2, 9)).tolist() for _ in range(173)]
+    return sessions
+
+
+def _host_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    from ader_amd.data import Evaluator
+    from ader_amd.exemplar import ExemplarGenerator
+    random.seed(0)
+    np.random.seed(0)
+    ev = Evaluator(_host_problem(), False, 10, 16, 40, "test", _FakeModel(), None, shard=(rank, world))
+    ev.evaluate(1)
+    gen = ExemplarGenerator(_host_problem(), 60, False, 16, 10, 0.0, 40, shard=(rank, world))
+    saved = gen.herding_selection(None, _FakeModel())
+    torch.save({"ranks": ev.ranks, "res": ev.results(), "saved": saved, "rows": np.asarray(gen.store.rows)}, out_path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluator_and_herding_equal_single_process():
+    """evaluation batches and herding label groups are independent units; with W = 2 every rank must end with
+    the single-process rank list (same order => same float64 metric sums) and the single-process exemplar rows."""
+    import random
+    from ader_amd.data import Evaluator
+    from ader_amd.exemplar import ExemplarGenerator
+    random.seed(0)
+    np.random.seed(0)
+    ev = Evaluator(_host_problem(), False, 10, 16, 40, "test", _FakeModel(), None)
+    ev.evaluate(1)
+    gen = ExemplarGenerator(_host_problem(), 60, False, 16, 10, 0.0, 40)
+    saved = gen.herding_selection(None, _FakeModel())
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r%d.pt")
+        mp.spawn(_host_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+        for r in range(2):
+            got = torch.load(out % r, weights_only=False)
+            assert got["ranks"] == ev.ranks and got["res"] == ev.results()
+            assert got["saved"] == saved and np.array_equal(got["rows"], np.asarray(gen.store.rows))
+
+
+def test_split_groups_is_contiguous_and_balanced():
+    sizes = [5, 1, 1, 30, 2, 2, 2, 9, 1]
+    for w in (1, 2, 3, 4, 8):
+        ch = adist.split_groups(sizes, w)
+        assert ch[0][0] == 0 and ch[-1][1] == len(sizes)
+        assert all(a[1] == b[0] for a, b in zip(ch, ch[1:])) and all(lo <= hi for lo, hi in ch)
