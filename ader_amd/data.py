@@ -267,7 +267,7 @@ class Evaluator:
         r = self.results()
         info = 'epoch:%d, %s (MRR@20: %.4f, RECALL@20: %.4f, MRR@10: %.4f, RECALL@10: %.4f)' \
                % (epoch, self.mode, r[0], r[1], r[2], r[3])
-        if self.shard[0] == 0:
+        if getattr(self, "shard", (0, 1))[0] == 0:
             print(info)
         return info
 
