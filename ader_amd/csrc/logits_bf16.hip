@@ -413,9 +413,13 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
         __syncthreads();
         cur ^= 1;
     }
-    // dE acc (rows = items, col = channel) -> LDS [64 items][FLD] -> coalesced 8-byte row stores, two halves of 64 items
+    // dE acc (rows = items, col = channel) -> LDS [64 items][fs] -> coalesced row stores, two halves of 64 items.
+    // ADAM: fs = H, so the LDS tile is the same flat [64*H] block as the half-tile's rows of theta / m / v in memory.
     float* F_l = (float*)smem_raw;
     const int HH = H >> 1;
+    const int fs = ADAM ? H : FLD;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -423,9 +427,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
                 const int h = 32 * nb + r;
-                if (h < FLD) {
+                if (h < fs) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * FLD + h] = dE[nb][j];
+                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * fs + h] = dE[nb][j];
                 }
             }
         }
@@ -445,54 +449,86 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                 for (int k = f.sp_start[bkt], k1 = f.sp_start[bkt + 1]; k < k1; ++k) {
                     const int id = f.sp_ids[k];
                     if (id >= id_hi) break;
-                    F_l[(id - id_lo) * FLD + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
+                    F_l[(id - id_lo) * fs + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
                 }
                 for (int k = f.tg_start[bkt], k1 = f.tg_start[bkt + 1]; k < k1; ++k) {
                     const int id = f.tg_ids[k];
                     if (id >= id_hi) break;
                     const int b = f.tg_rows[k];
-                    F_l[(id - id_lo) * FLD + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
+                    F_l[(id - id_lo) * fs + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
                 }
             }
             __syncthreads();
-            // Adam on the half-tile: all theta/m/v loads of a chunk are issued before any math or store
-            float* __restrict__ pe = f.emb1; float* __restrict__ pm_ = f.m1; float* __restrict__ pv = f.v1;
-            bf16* __restrict__ psh = f.sh1w;
-#define AU 5
-            for (int i0 = 0; i0 < 64 * HH; i0 += 256 * AU) {
-                float2 p2[AU], m2[AU], v2[AU];
-                size_t e[AU]; int ok[AU], fo[AU], so[AU];
+            // Adam on the half-tile.  Its rows are ONE contiguous block of 64*H floats in theta / m / v (and in F_l): it is
+            // walked as 16-byte vectors (the block starts 0 or 8 bytes past a 16-byte boundary: `head` floats are peeled),
+            // all loads of a round issued before any math or store; (row, col) of a vector -- needed only for the bf16
+            // shadow row -- is stepped without divisions.
+            const int rows_valid = min(64, N - base_it);
+            const int n_el = rows_valid > 0 ? rows_valid * H : 0;
+            float* __restrict__ gp = f.emb1 + (size_t)base_it * H;
+            float* __restrict__ gm = f.m1 + (size_t)base_it * H;
+            float* __restrict__ gv = f.v1 + (size_t)base_it * H;
+            bf16* __restrict__ psh = f.sh1w + (size_t)base_it * LDR;
+            const int head = (((uintptr_t)gp) & 15) ? 2 : 0;
+#define ADAM1(p_, m_, v_, g_)                                                                              \
+            { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
+            if (head && tid == 0 && n_el > 0) {                   // elements 0,1 (row 0, columns 0,1)
+                f32x2_t p = *(const f32x2_t*)gp, m = *(const f32x2_t*)gm, v = *(const f32x2_t*)gv;
+                const float2 g2 = *(const float2*)F_l;
+                ADAM1(p[0], m[0], v[0], g2.x); ADAM1(p[1], m[1], v[1], g2.y);
+                *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
+                bf16x2 sb; sb[0] = (bf16)p[0]; sb[1] = (bf16)p[1];
+                *(bf16x2*)psh = sb;
+            }
+#define AV 3
+            int e = head + 4 * tid;
+            int row = e / H, col = e - row * H;
+            const int step_r = 1024 / H, step_c = 1024 - step_r * H;
+#pragma unroll 1
+            for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160
+                f32x4_t P[AV], M[AV], V[AV];
+                int E[AV], RC[AV], NV[AV];
 #pragma unroll
-                for (int u = 0; u < AU; ++u) {
-                    const int idx = i0 + tid + 256 * u;
-                    const int row = idx / HH, c2 = idx - row * HH;
-                    const int it = base_it + row;
-                    ok[u] = (idx < 64 * HH) && (it < N);
-                    e[u] = (size_t)it * H + 2 * c2;
-                    fo[u] = row * FLD + 2 * c2;
-                    so[u] = 2 * c2;
-                    if (ok[u]) { p2[u] = *(const float2*)(pe + e[u]); m2[u] = *(const float2*)(pm_ + e[u]); v2[u] = *(const float2*)(pv + e[u]); }
+                for (int u = 0; u < AV; ++u) {
+                    E[u] = e; RC[u] = (row << 16) | col;
+                    NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);
+                    if (NV[u] == 2) {
+                        P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e);
+                    } else if (NV[u] == 1) {
+                        const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e);
+                        P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f};
+                    }
+                    e += 1024; row += step_r; col += step_c;
+                    if (col >= H) { col -= H; ++row; }
                 }
 #pragma unroll
-                for (int u = 0; u < AU; ++u) {
-                    if (!ok[u]) continue;
-                    const float2 g2 = *(const float2*)(F_l + fo[u]);
-                    float2 p = p2[u], m = m2[u], v = v2[u];
-                    m.x += (g2.x - m.x) * f.omb1; v.x += (g2.x * g2.x - v.x) * f.omb2; p.x -= (m.x * f.lr_t) / (sqrtf(v.x) + f.eps);
-                    m.y += (g2.y - m.y) * f.omb1; v.y += (g2.y * g2.y - v.y) * f.omb2; p.y -= (m.y * f.lr_t) / (sqrtf(v.y) + f.eps);
-                    if (NT_STORES) {   // theta/m/v of this row are not touched again this step: keep them out of the caches
-                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                        __builtin_nontemporal_store((f32x2_t){p.x, p.y}, (f32x2_t*)(pe + e[u]));
-                        __builtin_nontemporal_store((f32x2_t){m.x, m.y}, (f32x2_t*)(pm_ + e[u]));
-                        __builtin_nontemporal_store((f32x2_t){v.x, v.y}, (f32x2_t*)(pv + e[u]));
+                for (int u = 0; u < AV; ++u) {
+                    if (NV[u] == 0) continue;
+                    const float2 ga = *(const float2*)(F_l + E[u]);
+                    const float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
+                    f32x4_t p = P[u], m = M[u], v = V[u];
+                    ADAM1(p[0], m[0], v[0], ga.x); ADAM1(p[1], m[1], v[1], ga.y);
+                    ADAM1(p[2], m[2], v[2], gb.x); ADAM1(p[3], m[3], v[3], gb.y);
+                    const int r0 = RC[u] >> 16, c0 = RC[u] & 0xffff;
+                    bf16x2 s0; s0[0] = (bf16)p[0]; s0[1] = (bf16)p[1];
+                    *(bf16x2*)(psh + r0 * LDR + c0) = s0;
+                    if (NV[u] == 2) {
+                        // theta/m/v of this block are not touched again this step: keep them out of the caches
+                        __builtin_nontemporal_store(p, (f32x4_t*)(gp + E[u]));
+                        __builtin_nontemporal_store(m, (f32x4_t*)(gm + E[u]));
+                        __builtin_nontemporal_store(v, (f32x4_t*)(gv + E[u]));
+                        const int c1 = c0 + 2;
+                        bf16x2 s1; s1[0] = (bf16)p[2]; s1[1] = (bf16)p[3];
+                        *(bf16x2*)(psh + ((c1 >= H) ? (r0 + 1) * LDR + (c1 - H) : r0 * LDR + c1)) = s1;
                     } else {
-                        *(float2*)(pe + e[u]) = p; *(float2*)(pm_ + e[u]) = m; *(float2*)(pv + e[u]) = v;
+                        *(f32x2_t*)(gp + E[u]) = (f32x2_t){p[0], p[1]};
+                        *(f32x2_t*)(gm + E[u]) = (f32x2_t){m[0], m[1]};
+                        *(f32x2_t*)(gv + E[u]) = (f32x2_t){v[0], v[1]};
                     }
-                    bf16x2 sb; sb[0] = (bf16)p.x; sb[1] = (bf16)p.y;
-                    *(bf16x2*)(psh + (e[u] / H) * LDR + so[u]) = sb;
                 }
             }
-#undef AU
+#undef AV
+#undef ADAM1
         }
     }
 }
