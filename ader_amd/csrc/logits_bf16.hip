@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
     float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
+    int* meta_l = (int*)(off_l + a.Bp);      // ADAM: per (half, list): [k0, k1, 8 x (id, row)] = 18 ints, 4 lists (SP_PRE entries prefetched)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int H = a.H, N = a.N;
@@ -339,6 +340,20 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
         }
     }
     for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+    if (ADAM && tid < 4) {
+        // the sparse lists of the two half-tiles (bucket bounds and the first entries) are fetched now, under the GEMM phase:
+        // three dependent global round trips less between the GEMM and the streaming update
+        const int half = tid >> 1, lst = tid & 1;
+        const int bkt = (tile0 + half * 64) >> 6;
+        const int* st = lst ? f.tg_start : f.sp_start;
+        const int* ids = lst ? f.tg_ids : f.sp_ids;
+        const int* rows = lst ? f.tg_rows : f.sp_rows;
+        int* mt = meta_l + tid * 18;
+        int k0 = 0, k1 = 0;
+        if (tile0 + half * 64 < N) { k0 = st[bkt]; k1 = st[bkt + 1]; }
+        mt[0] = k0; mt[1] = k1;
+        for (int i = 0; i < 8 && k0 + i < k1; ++i) { mt[2 + 2 * i] = ids[k0 + i]; mt[3 + 2 * i] = rows[k0 + i]; }
+    }
     __syncthreads();
     bf16x8 efrag[10];                                   // lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
 #pragma unroll
@@ -445,16 +460,19 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
             // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
             const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
             if (tid < H && id_lo < id_hi) {
-                const int bkt = base_it >> 6;                   // buckets of 64 ids starting at id 1: exactly this half-tile
-                for (int k = f.sp_start[bkt], k1 = f.sp_start[bkt + 1]; k < k1; ++k) {
-                    const int id = f.sp_ids[k];
+                // entries of bucket base_it >> 6 (ids [base_it+1, base_it+65): exactly this half-tile), (id, row)-ordered
+                const int* ms = meta_l + (half * 2 + 0) * 18;
+                const int* mg = meta_l + (half * 2 + 1) * 18;
+                for (int k = ms[0], k1 = ms[1], i = 0; k < k1; ++k, ++i) {
+                    const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
                     if (id >= id_hi) break;
-                    F_l[(id - id_lo) * fs + tid] += f.sp_src[(size_t)f.sp_rows[k] * H + tid] * f.sp_scale;
+                    const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
+                    F_l[(id - id_lo) * fs + tid] += f.sp_src[(size_t)row * H + tid] * f.sp_scale;
                 }
-                for (int k = f.tg_start[bkt], k1 = f.tg_start[bkt + 1]; k < k1; ++k) {
-                    const int id = f.tg_ids[k];
+                for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
+                    const int id = (i < 8) ? mg[2 + 2 * i] : f.tg_ids[k];
                     if (id >= id_hi) break;
-                    const int b = f.tg_rows[k];
+                    const int b = (i < 8) ? mg[3 + 2 * i] : f.tg_rows[k];
                     F_l[(id - id_lo) * fs + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
                 }
             }
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(256) void k_lbf_target_fix(const bf16* __restrict__
 
 // ============================================================================================= C ABI
 static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
-static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float); }
+static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 4 * 18 * sizeof(int); }
 
 extern "C" {
 
