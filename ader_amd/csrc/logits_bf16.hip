@@ -319,6 +319,9 @@ __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n,
 #define NT_STORES 1
 #endif
 
+// workgroup barrier that orders LDS traffic only (__syncthreads also drains every outstanding global access of the wave)
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool ADAM>
 __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -435,9 +438,38 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     const int fs = ADAM ? H : FLD;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define AV 3
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        __syncthreads();
+        // ADAM: the first round of theta/m/v vectors of this half-tile is requested BEFORE the dE staging and the sparse
+        // terms (independent of both); the barriers in between order LDS only, so the loads stay in flight across them
+        const int base_it = tile0 + half * 64;
+        const int rows_valid = min(64, N - base_it);
+        const int n_el = rows_valid > 0 ? rows_valid * H : 0;
+        float* __restrict__ gp = ADAM ? f.emb1 + (size_t)base_it * H : nullptr;
+        float* __restrict__ gm = ADAM ? f.m1 + (size_t)base_it * H : nullptr;
+        float* __restrict__ gv = ADAM ? f.v1 + (size_t)base_it * H : nullptr;
+        const int head = (((uintptr_t)gp) & 15) ? 2 : 0;
+        int e = head + 4 * tid;
+        int row = e / H, col = e - row * H;
+        const int step_r = 1024 / H, step_c = 1024 - step_r * H;
+        f32x4_t P[AV], M[AV], V[AV];
+        int E[AV], RC[AV], NV[AV];
+#define ROUND_LOAD()                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < AV; ++u) {                                                   \
+            E[u] = e; RC[u] = (row << 16) | col;                                                           \
+            NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);                                         \
+            if (NV[u] == 2) {                                                                              \
+                P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e); \
+            } else if (NV[u] == 1) {                                                                       \
+                const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e); \
+                P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f}; \
+            }                                                                                              \
+            e += 1024; row += step_r; col += step_c;                                                       \
+            if (col >= H) { col -= H; ++row; }                                                             \
+        }
+        if (ADAM) { ROUND_LOAD(); }
+        if (ADAM) lds_only_barrier(); else __syncthreads();
         if ((wave >> 1) == half) {
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
@@ -448,8 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                 }
             }
         }
-        __syncthreads();
-        const int base_it = tile0 + half * 64;
+        if (ADAM) lds_only_barrier(); else __syncthreads();
         if (!ADAM) {
             for (int idx = tid; idx < 64 * HH; idx += 256) {
                 const int row = idx / HH, c2 = idx - row * HH;
@@ -476,18 +507,12 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                     F_l[(id - id_lo) * fs + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
                 }
             }
-            __syncthreads();
+            lds_only_barrier();
             // Adam on the half-tile.  Its rows are ONE contiguous block of 64*H floats in theta / m / v (and in F_l): it is
             // walked as 16-byte vectors (the block starts 0 or 8 bytes past a 16-byte boundary: `head` floats are peeled),
             // all loads of a round issued before any math or store; (row, col) of a vector -- needed only for the bf16
             // shadow row -- is stepped without divisions.
-            const int rows_valid = min(64, N - base_it);
-            const int n_el = rows_valid > 0 ? rows_valid * H : 0;
-            float* __restrict__ gp = f.emb1 + (size_t)base_it * H;
-            float* __restrict__ gm = f.m1 + (size_t)base_it * H;
-            float* __restrict__ gv = f.v1 + (size_t)base_it * H;
             bf16* __restrict__ psh = f.sh1w + (size_t)base_it * LDR;
-            const int head = (((uintptr_t)gp) & 15) ? 2 : 0;
 #define ADAM1(p_, m_, v_, g_)                                                                              \
             { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
             if (head && tid == 0 && n_el > 0) {                   // elements 0,1 (row 0, columns 0,1)
@@ -498,27 +523,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                 bf16x2 sb; sb[0] = (bf16)p[0]; sb[1] = (bf16)p[1];
                 *(bf16x2*)psh = sb;
             }
-#define AV 3
-            int e = head + 4 * tid;
-            int row = e / H, col = e - row * H;
-            const int step_r = 1024 / H, step_c = 1024 - step_r * H;
 #pragma unroll 1
-            for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160
-                f32x4_t P[AV], M[AV], V[AV];
-                int E[AV], RC[AV], NV[AV];
-#pragma unroll
-                for (int u = 0; u < AV; ++u) {
-                    E[u] = e; RC[u] = (row << 16) | col;
-                    NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);
-                    if (NV[u] == 2) {
-                        P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e);
-                    } else if (NV[u] == 1) {
-                        const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e);
-                        P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f};
-                    }
-                    e += 1024; row += step_r; col += step_c;
-                    if (col >= H) { col -= H; ++row; }
-                }
+            for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160; round 0 is already in flight
+                if (k0) { ROUND_LOAD(); }
 #pragma unroll
                 for (int u = 0; u < AV; ++u) {
                     if (NV[u] == 0) continue;
@@ -545,7 +552,6 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                     }
                 }
             }
-#undef AV
 #undef ADAM1
         }
     }
