@@ -49,6 +49,11 @@ _SIGS = {
     "ader_lbf_ranges": [I, I],
     "ader_lbf_shadow_refresh": [P, P, Z, I, P],
     "ader_lbf_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_lbf_prep": [P, P, I, I, I, P],
+    "ader_lbf_merge_parts": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    "ader_gather_owned": [P, P, I, I, I, I, P, P],
+    "ader_scatter_owned": [P, P, I, I, I, I, I, P, P, P],
+    "ader_lbf_fwd_shard": [P, P, I, I, I, I, I, I, P, P, P, P, P],
     "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P],
     "ader_fused_bucket_gran": [],

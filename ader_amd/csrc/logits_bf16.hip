@@ -284,6 +284,102 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
     }
 }
 
+// Catalog-sharded data parallelism: this rank streamed only ITS items.  Per batch row, merge the range partials into one
+// (M, L, O[H]) triple -- running max (log2 domain), sum of 2^(s - M), sum of 2^(s - M) * E -- for the cross-rank merge
+// (same fixed-order sums as k_lbf_combine).  part: [Bp][PART_LD] = {M, L, O[0..H)}.
+#define PART_LD 152
+__global__ __launch_bounds__(640) void k_lbf_combine_partial(LbfArgs a, float* __restrict__ part) {
+    __shared__ float sc[1024];
+    __shared__ float red[640];
+    __shared__ float sM;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = a.ranges, H = a.H;
+    float m = -INFINITY;
+    for (int i = tid; i < R; i += 640) m = fmaxf(m, a.pm[(size_t)i * a.Bp + b]);
+    red[tid] = m;
+    __syncthreads();
+    if (tid < 64) {
+        float v = red[tid];
+        for (int k = tid + 64; k < 640; k += 64) v = fmaxf(v, red[k]);
+        v = wave_max(v);
+        if (tid == 0) sM = v;
+    }
+    __syncthreads();
+    const float M = sM;
+    float l = 0.0f;
+    for (int i = tid; i < R; i += 640) {
+        const float pm = a.pm[(size_t)i * a.Bp + b];
+        const float s_ = (pm != -INFINITY) ? __builtin_amdgcn_exp2f(pm - M) : 0.0f;
+        sc[i] = s_;
+        l += a.pl[(size_t)i * a.Bp + b] * s_;
+    }
+    red[tid] = l;
+    __syncthreads();
+    if (tid == 0) {
+        float v = 0.0f;
+        for (int k = 0; k < 640; ++k) v += red[k];
+        part[(size_t)b * PART_LD + 0] = M;
+        part[(size_t)b * PART_LD + 1] = v;
+    }
+    const int g = tid / 160, h = tid - g * 160;
+    float oh = 0.0f;
+    if (h < H) {
+#pragma unroll 8
+        for (int i = g; i < R; i += 4) oh += a.pO[((size_t)i * a.Bp + b) * HP + h] * sc[i];
+    }
+    __syncthreads();
+    red[tid] = oh;
+    __syncthreads();
+    if (tid < H) part[(size_t)b * PART_LD + 2 + tid] = ((red[tid] + red[160 + tid]) + red[320 + tid]) + red[480 + tid];
+}
+
+// Cross-rank merge for one batch row of THIS rank: parts [W][Bp][PART_LD] (slice i = the partials rank i computed over its
+// items) -> lse (natural log), backward offset, loss row, dRep row.  e_lab: fp32 table row of the label (fetched from its
+// owner); it enters as bf16(e_lab), i.e. exactly the shadow row the MFMA path multiplies.  One wave per row.
+__global__ __launch_bounds__(256) void k_lbf_merge_parts(const float* __restrict__ parts, int W, int Bp, int B, int H,
+                                                         const float* __restrict__ e_lab, const bf16* __restrict__ rep_bf,
+                                                         const float* __restrict__ wrow, float* __restrict__ lse,
+                                                         float* __restrict__ off, float* __restrict__ rowloss,
+                                                         float* __restrict__ drep) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= Bp) return;
+    if (b >= B) {
+        if (lane == 0) { lse[b] = 0.0f; rowloss[b] = 0.0f; off[b] = -INFINITY; }
+        return;
+    }
+    float M = -INFINITY;
+    for (int i = 0; i < W; ++i) M = fmaxf(M, parts[((size_t)i * Bp + b) * PART_LD]);
+    float L = 0.0f, o[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < W; ++i) {                                   // fixed order: deterministic
+        const float* pr = parts + ((size_t)i * Bp + b) * PART_LD;
+        const float m = pr[0];
+        const float sc = (m != -INFINITY) ? __builtin_amdgcn_exp2f(m - M) : 0.0f;
+        L += pr[1] * sc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int c = lane + 64 * k; if (c < H) o[k] += pr[2 + c] * sc; }
+    }
+    const float lse2 = M + log2f(L);
+    const float w = wrow[b];
+    float dot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = lane + 64 * k;
+        if (c < H) {
+            const float et = (float)(bf16)e_lab[(size_t)b * H + c];
+            dot += (float)rep_bf[(size_t)b * LDR + c] * et;
+            drep[(size_t)b * H + c] = w * (o[k] / L - et);
+        }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        const float z = lse2 / LOG2E;
+        lse[b] = z;
+        rowloss[b] = w * (z - dot);
+        off[b] = (w > 0.0f) ? log2f(w) - lse2 : -INFINITY;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, int n, float* __restrict__ out) {
     __shared__ float red[256];
     float acc = 0.0f;
@@ -618,6 +714,57 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep);
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// rep fp32 [B,H] -> rep_bf [Bp,168] bf16 (zero padded): the operand layout of the bf16 logit kernels
+int ader_lbf_prep(const float* rep, void* rep_bf, int B, int Bp, int H, void* stream) {
+    if (Bp <= 0) return 0;
+    if (B > Bp || H > HP) return -2;
+    hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, (hipStream_t)stream, rep, (bf16*)rep_bf, B, Bp, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Softmax partials of ALL Bp batch rows over the item shard [item_begin+1, item_begin+item_count] (clipped to N): the
+// forward of a catalog-sharded rank.  part [Bp][152] = {M (log2 domain), L, O[0..H)} per row; rows whose shard is empty get
+// {-inf, 0, 0}.  Scratch pm/pl/pO sized with ader_lbf_ranges(item_count, Bp).
+int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int Bp, int H, int N, int item_begin, int item_count,
+                       float* pm, float* pl, float* pO, float* part, void* stream) {
+    if (Bp <= 0) return 0;
+    if (Bp % 128 != 0 || H > HP || (H & 1) || H < 2 || N > item_num || item_begin < 0) return -2;
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int n_loc = N - item_begin;
+    if (n_loc > item_count) n_loc = item_count;
+    if (n_loc < 0) n_loc = 0;
+    LbfArgs a;
+    a.sh1 = (const bf16*)shadow + (size_t)LDR * (1 + item_begin); a.vrows = item_num - item_begin; a.tile_off = 0;
+    a.rep_bf = (const bf16*)rep_bf; a.B = Bp; a.Bp = Bp; a.H = H; a.N = n_loc;
+    a.ranges = n_loc > 0 ? ader_lbf_ranges(n_loc, Bp) : 0;
+    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    if (a.ranges > 0) hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
+    hipLaunchKernelGGL(k_lbf_combine_partial, dim3(Bp), dim3(640), 0, st, a, part);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Merge of the W ranks' partials (ader_lbf_fwd_shard, exchanged so that slice i holds rank i's partials of THIS rank's rows)
+// into lse / off / rowloss [Bp], loss [1] and drep [B,H]; e_lab [B,H]: fp32 table rows of the labels.
+int ader_lbf_merge_parts(const float* parts, int world, int Bp, int B, int H, const float* e_lab, const void* rep_bf,
+                         const float* wrow, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+    if (Bp <= 0) return 0;
+    if (B > Bp || H > 192 || world < 1) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_lbf_merge_parts, dim3((Bp + 3) / 4), dim3(256), 0, st, parts, world, Bp, B, H, e_lab, (const bf16*)rep_bf,
+                       wrow, lse, off, rowloss, drep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;

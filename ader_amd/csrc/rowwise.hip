@@ -450,3 +450,59 @@ int ader_fill(float* p, size_t n, float val, void* stream) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Catalog-sharded data parallelism (engine._train_step_catalog): the table rows a step's inputs need travel between ranks.
+// k_gather_owned : out[p][:] = table[ids[p]][:] if lo < ids[p] <= hi (this rank owns the row) else 0      (sender side)
+// k_scatter_owned: position p of MY inputs holds id = ids[p], owned by rank (id-1)/shard: take that rank's slice of the
+//                  received buffer recv[owner][p][:] and write it to table[id] (p < n_tab) or to extra[p - n_tab] (labels)
+__global__ __launch_bounds__(256) void k_gather_owned(const float* __restrict__ table, const int* __restrict__ ids, int n, int H,
+                                                      int lo, int hi, float* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= n) return;
+    const int id = ids[p];
+    const bool own = id > lo && id <= hi;
+    const float* src = table + (size_t)id * H;
+    float* dst = out + (size_t)p * H;
+    for (int c = lane; c < H; c += 64) dst[c] = own ? src[c] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_owned(const float* __restrict__ recv, const int* __restrict__ ids, int n, int n_tab,
+                                                       int H, int shard, int world, float* __restrict__ table,
+                                                       float* __restrict__ extra) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= n) return;
+    const int id = ids[p];
+    if (id <= 0) {                                                  // padding position: nothing to place; label rows read zeros
+        if (p >= n_tab) for (int c = lane; c < H; c += 64) extra[(size_t)(p - n_tab) * H + c] = 0.0f;
+        return;
+    }
+    int owner = (id - 1) / shard;
+    if (owner >= world) owner = world - 1;
+    const float* src = recv + ((size_t)owner * n + p) * H;
+    float* dst = (p < n_tab) ? table + (size_t)id * H : extra + (size_t)(p - n_tab) * H;
+    for (int c = lane; c < H; c += 64) dst[c] = src[c];
+}
+
+extern "C" {
+
+int ader_gather_owned(const float* table, const int* ids, int n, int H, int lo, int hi, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gather_owned, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, n, H, lo, hi, out);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_scatter_owned(const float* recv, const int* ids, int n, int n_tab, int H, int shard, int world, float* table, float* extra,
+                       void* stream) {
+    if (n <= 0) return 0;
+    if (shard <= 0 || world <= 0 || n_tab > n) return -2;
+    hipLaunchKernelGGL(k_scatter_owned, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, recv, ids, n, n_tab, H, shard, world,
+                       table, extra);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

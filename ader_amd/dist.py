@@ -7,7 +7,10 @@ its local loss terms by the GLOBAL sub-batch sizes (1/B_train,global and lambda/
 SUM-reduced; every rank then applies the identical Adam update.  Dropout counters are keyed by the global row index
 (Engine.row0) so the masks do not depend on the number of ranks.
 
-Two exchange schemes (both give the same update as a single process on the global batch):
+Exchange schemes (all give the same update as a single process on the global batch):
+  * catalog-sharded table (Engine.dp_mode = "catalog", Engine._train_step_catalog; bench.py --gpus N): every rank OWNS 1/W of the
+    table rows; only the rows the inputs touch, the bf16 representations, per-row softmax partials and the per-position
+    gradient rows travel.  Nothing proportional to the table size is exchanged.
   * sharded table update (default with bf16 logits, Engine._fused_table_adam_sharded): the 600 MB dense table gradient is
     never exchanged.  Ranks all-gather the INPUTS of the table-gradient product (~16 MB each), each updates its row shard
     of the table for the global batch inside the fused gradient+Adam kernel, and the updated rows are all-gathered

@@ -202,6 +202,11 @@ class Engine:
         # is never written to memory); needs the complete gradient locally, so it is off whenever a grad_hook is set
         self.fuse_adam = True
         self.dp_sharded = True   # dp_world > 1 with bf16 logits: row-sharded table update instead of a dense all-reduce
+        # dp_world > 1, vanilla bf16 steps: "catalog" = every rank OWNS 1/W of the table rows (parameters, Adam state, shadow),
+        # streams only those in the logit kernels and never receives the other ranks' rows except the few its inputs need
+        # (_train_step_catalog); "replicated" = every rank holds the whole table (the two schemes of dist.py)
+        self.dp_mode = "replicated"
+        self._table_stale = False
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -257,6 +262,7 @@ class Engine:
         return {k: self.param(k).detach().cpu().clone() for k in self.layout}
 
     def state_dict(self):
+        self.sync_table()
         return {"theta": self.theta.detach().cpu().clone(), "m": self.adam_m.detach().cpu().clone(),
                 "v": self.adam_v.detach().cpu().clone(), "b1p": float(self.b1p), "b2p": float(self.b2p),
                 "global_step": self.global_step}
@@ -576,6 +582,20 @@ class Engine:
                 call("ader_logits_bwd_drep", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), st)
             with self._sec("logits_bwd_demb"):
                 call("ader_logits_bwd_demb", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
+        dx = self._blocks_backward(seq, drep, defer, demb)
+        if defer:
+            self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)
+        return self.loss
+
+
+    def _blocks_backward(self, seq, drep, defer, demb):
+        """Backward of the final LayerNorm, the blocks and the prologue from drep [B,H] (gradient of the loss w.r.t. the
+        representation).  Fills the gradients of every non-table parameter; the table's sparse term goes into demb (dense
+        path) or, with `defer`, stays as per-position rows in the returned dx [B*T,H] for the fused table update."""
+        A = self._act
+        B, T, H, L = A["B"], self.T, self.H, self.L
+        rows = B * T
+        st = self._stream()
         tb = self._sec("blocks_bwd")
         tb.__enter__()
         wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))
@@ -659,12 +679,11 @@ class Engine:
                 self._late_call("ader_embed_bwd_rows", None, ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args())
             else:
                 call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
-            self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)
         else:
             call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)
         self._late_on = False
-        return self.loss
+        return dx
 
     def _bwd_block_fused(self, l, S, seq, dxo, dxn, M, B, emb_bwd, d_emb):
         """Backward of block l with the session-tiled chains (seq_bwd.hip) around the attention backward; queues the five
@@ -857,10 +876,125 @@ class Engine:
         self._deferred = None
         self._advance_adam()
 
+    # ---------------------------------------------------------------------------------------- catalog-sharded data parallelism
+    def _ag(self, t):
+        """all-gather -> [W, *t.shape]; moved as raw bytes (any dtype, any backend)."""
+        import torch.distributed as dist
+        t = t.contiguous()
+        out = torch.empty((self.dp_world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(torch.uint8).view(-1), t.view(torch.uint8).view(-1), group=self.dp_group)
+        return out
+
+    def _a2a(self, t):
+        """t [W, ...]: slice j goes to rank j; returns [W, ...] with slice i received from rank i."""
+        import torch.distributed as dist
+        t = t.contiguous()
+        if dist.get_backend(self.dp_group) == "nccl":
+            out = torch.empty_like(t)
+            dist.all_to_all_single(out.view(torch.uint8).view(-1), t.view(torch.uint8).view(-1), group=self.dp_group)
+            return out
+        return self._ag(t)[:, self.dp_rank].contiguous()        # backends without all-to-all on device tensors (tests)
+
+    def _train_step_catalog(self, seq, pos, max_item, lr, rate=0.0, n_train_global=None, **_unused):
+        """Vanilla train step with the item catalog sharded across the ranks (dense Adam touches every table row
+        every step, so a replicated table costs (W-1)/W x 600 MB of xGMI traffic per rank per step; a sharded one costs only
+        the rows the inputs touch).  Rank r owns table rows [1 + r*S, (r+1)*S]: theta / m / v / shadow of other rows are
+        not maintained locally.  Per step:
+          1. ids of all ranks are all-gathered; every rank gathers the fp32 rows it owns for everybody's input positions and
+             labels and an all-to-all delivers them (each position has exactly one owner); they are written into the local
+             table so the unchanged forward kernel can read them;
+          2. forward on the local rows; representations all-gathered (bf16 operand rows);
+          3. softmax partials {max, sum, weighted row sum} of ALL global rows over the local item shard
+             (ader_lbf_fwd_shard), exchanged so every rank merges the W partials of its own rows -> loss, dRep, offsets;
+          4. local backward; per-position gradient rows, labels, weights and offsets all-gathered;
+          5. fused gradient + Adam + shadow on the local shard for the global batch (ader_lbf_bwd_adam); nothing is sent back.
+        Same update as a single process on the global batch (sum over rows; tests/test_gpu_dp.py)."""
+        import torch.distributed as dist
+        W, r, grp = self.dp_world, self.dp_rank, self.dp_group
+        seq, pos = self._dev_i32(seq), self._dev_i32(pos)
+        B, T, H, S = seq.shape[0], self.T, self.H, self.shard_items
+        N = int(max_item)
+        Bp = (B + 127) // 128 * 128
+        assert pos.shape[0] == B and B <= self.MAX_ROWS and 1 <= N <= self.item_num
+        st = self._stream()
+        step = self.global_step
+        n_pos, n_all = B * T, B * T + B
+        with self._sec("grad_exchange"):
+            ids_l = torch.cat([seq.reshape(-1), pos])                          # my input positions, then my labels
+            ids_g = self._ag(ids_l)                                            # [W, n_all]
+            send = self.buf("cs_send", (W, n_all, H))
+            call("ader_gather_owned", self._pp["emb"], ptr(ids_g), W * n_all, H, r * S, (r + 1) * S, ptr(send), st)
+            recv = self._a2a(send)                                             # slice i: rows rank i owns among MY positions
+            e_lab = self.buf("cs_elab", (B, H))
+            call("ader_scatter_owned", ptr(recv), ptr(ids_l), n_all, n_pos, H, S, W, self._pp["emb"], ptr(e_lab), st)
+        self._table_stale = True
+        seq_g = ids_g[:, :n_pos]
+        with self._sec("blocks_fwd"):
+            rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
+        rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
+        w_row = 1.0 / float(n_train_global if n_train_global is not None else B)
+        meta = self.buf("cs_meta", (3, Bp), torch.int32)                       # rows: off (f32 bits), wrow (f32 bits), label
+        off, wrow, lab = meta[0].view(torch.float32), meta[1].view(torch.float32), meta[2]
+        wrow.zero_()
+        wrow[:B] = w_row
+        lab.zero_()
+        lab[:B] = pos
+        drep = self.buf("drep", (B, H))
+        lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
+        with self._sec("logits_fwd"):
+            call("ader_lbf_prep", ptr(rep), ptr(rep_bf), B, Bp, H, st)
+            rep_g = self._ag(rep_bf)                                           # [W, Bp*168]
+            R = call("ader_lbf_ranges", S, W * Bp)
+            pm, pl = self.buf("lbf_pm", (R * W * Bp,)), self.buf("lbf_pl", (R * W * Bp,))
+            pO = self.buf("lbf_pO", (R * W * Bp * 160,))
+            part = self.buf("lbf_part", (W * Bp * 152,))
+            call("ader_lbf_fwd_shard", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, H, N, r * S, S, ptr(pm), ptr(pl),
+                 ptr(pO), ptr(part), st)
+            pr = self._a2a(part.view(W, Bp, 152))                              # partials of MY rows from every rank
+            call("ader_lbf_merge_parts", ptr(pr), W, Bp, B, H, ptr(e_lab), ptr(rep_bf), ptr(wrow), ptr(lse), ptr(off), ptr(rowloss),
+                 ptr(self.loss), ptr(drep), st)
+        dx = self._blocks_backward(seq, drep, True, None)
+        lr_t = self._lr_t(lr)
+        span = self.layout["pos"][0]
+        with self._sec("grad_exchange"):
+            meta_g, g_g = self._ag(meta), self._ag(dx)                         # [W,3,Bp], [W,B*T,H]
+            off_g = meta_g[:, 0].contiguous().view(torch.float32)
+            w_g = meta_g[:, 1].contiguous().view(torch.float32)
+            lab_g = meta_g[:, 2].contiguous()
+            dist.all_reduce(self.grad[span:], group=grp)
+            dist.all_reduce(self.loss, group=grp)
+        ids, order, sp_start, tids, torder, tg_start = self._sparse_lists(seq_g, lab_g, N)
+        tiles = S // 128
+        with self._sec("logits_bwd_adam"):
+            call("ader_lbf_bwd_adam", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+                 ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
+                 ptr(torder), ptr(tg_start), tids.numel(), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
+                 self.beta1, self.beta2, self.eps, r * tiles, tiles, st)
+        with self._sec("adam"):
+            call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
+                 self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
+                 self.eps, None, 0, H, st)
+        self._advance_adam()
+        return self.loss
+
+    def sync_table(self):
+        """Catalog-sharded mode: make the parameter rows of the whole table (and their bf16 shadow) valid on every rank again
+        -- before evaluation, herding, checkpointing or a step that needs the replicated table."""
+        if not self._table_stale:
+            return
+        import torch.distributed as dist
+        H, S = self.H, self.shard_items * self.H
+        tab = self.theta[H:H + self.dp_world * S]
+        own = tab[self.dp_rank * S:(self.dp_rank + 1) * S].clone()
+        dist.all_gather_into_tensor(tab, own, group=self.dp_group)
+        self._table_stale = False
+        self.refresh_shadow()
+
     def gather_table_state(self):
         """Sharded mode: make adam_m / adam_v of the table complete on every rank (before checkpointing)."""
-        if self.dp_world > 1 and self.dp_sharded:
+        if self.dp_world > 1 and (self.dp_sharded or self.dp_mode == "catalog"):
             import torch.distributed as dist
+            self.sync_table()
             H, S = self.H, self.shard_items * self.H
             for buf in (self.adam_m, self.adam_v):
                 table = buf[H:H + self.dp_world * S]
@@ -870,6 +1004,10 @@ class Engine:
     def train_step(self, seq, pos, max_item, lr, **kw):
         """One `sess.run(train_op)` (main.py:233-256): forward, loss, backward, [gradient exchange], Adam.
         Returns the loss as a 1-element device tensor (no host sync)."""
+        if (self.dp_world > 1 and self.dp_mode == "catalog" and self.shadow is not None and self.seq_fused
+                and kw.get("teacher") is None and kw.get("ex_pos") is None):
+            return self._train_step_catalog(seq, pos, max_item, lr, **kw)
+        self.sync_table()
         sharded = self.dp_world > 1 and self.dp_sharded
         fuse = self.fuse_adam and (self.grad_hook is None or sharded)
         loss = self.loss_and_grad(seq, pos, max_item, _defer_table=fuse, **kw)
@@ -894,6 +1032,7 @@ class Engine:
     # ---------------------------------------------------------------------------------------- inference paths
     def encode(self, seq):
         """Eval-mode representation (is_training=False): rep [n,H] for any n (chunks of MAX_ROWS)."""
+        self.sync_table()
         seq = self._dev_i32(seq)
         n = seq.shape[0]
         out = torch.empty((n, self.H), dtype=torch.float32, device=self.device)
@@ -910,6 +1049,7 @@ class Engine:
 
     def logits_from_rep(self, rep, max_item, out=None):
         """Dense logits [n, N] = rep . E[1..N]^T  (ADER.py:92)."""
+        self.sync_table()
         n, N = rep.shape[0], int(max_item)
         if out is None:
             out = torch.empty((n, N), dtype=torch.float32, device=self.device)
@@ -930,6 +1070,7 @@ class Engine:
 
     def rank_targets(self, seq, pos, max_item):
         """0-based rank of pos[b] among items 1..N for every row (Evaluator path, util.py:323-325) -> int32 numpy [n]."""
+        self.sync_table()
         seq = self._dev_i32(seq)
         pos = self._dev_i32(pos)
         n, N = seq.shape[0], int(max_item)

@@ -92,6 +92,8 @@ def main():
                     help="synthetic id/length law (SURVEY 8d); the headline number is the dense regime")
     ap.add_argument("--exemplars", type=int, default=0,
                     help="ADER-mode variant: append this many exemplar rows distilled against N(0,1) teacher logits over 0.9 N items")
+    ap.add_argument("--dp-mode", choices=["catalog", "replicated"], default="catalog",
+                    help="N > 1: table rows owned by one rank each (catalog) or replicated with a row-sharded update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -100,7 +102,9 @@ def main():
     from ader_amd.engine import Engine, SectionTimer
     import torch.distributed as dist
 
-    rank, world, local = adist.init("nccl")
+    # ADER_DIST_BACKEND=gloo lets several ranks share one GPU (functional check of the N > 1 path without an 8-GPU node)
+    rank, world, local = adist.init(os.environ.get("ADER_DIST_BACKEND", "nccl"))
+    local = local % max(torch.cuda.device_count(), 1)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -109,6 +113,8 @@ def main():
     eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits,
                  dp_rank=rank, dp_world=world)
     dp = adist.DataParallel(eng, rank, world)
+    if world > 1 and args.logits == "bf16" and not args.exemplars:
+        eng.dp_mode = args.dp_mode
     dp.set_rows(rank * B, N)
     nbatch = 4
     E = args.exemplars
@@ -218,8 +224,10 @@ def main():
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam",
                        "exchange": ("none" if world == 1 else
-                                    ("row-sharded table update + all-gather" if (eng.dp_sharded and eng.shadow is not None)
-                                     else "dense gradient all-reduce")),
+                                    ("catalog-sharded table: input rows all-to-all + softmax partials + gradient rows all-gather"
+                                     if eng.dp_mode == "catalog" else
+                                     ("row-sharded table update + all-gather" if (eng.dp_sharded and eng.shadow is not None)
+                                      else "dense gradient all-reduce"))),
                        "precision": ("logit GEMMs bf16 operands / fp32 accumulate+softmax; blocks, optimizer, master weights fp32"
                                      if args.logits == "bf16" else "fp32 throughout"), "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,

@@ -201,6 +201,24 @@ int ader_lbf_ranges(int N, int Bp);
 int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
                  const float* wrow, void* rep_bf, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss,
                  float* loss, float* drep, void* stream);
+/* Pieces of ader_lbf_fwd for catalog-sharded data parallelism (each rank holds 1/W of the table rows and streams only
+ * those; ADER.py:91-93 with the item axis split across ranks): ader_lbf_prep builds the bf16 operand rows [Bp,168] of the
+ * (all-gathered) representations; ader_lbf_fwd_shard returns per batch row the softmax partials {max (log2 domain), sum,
+ * weighted table-row sum[H]} over the items [item_begin+1, item_begin+item_count] (clipped to N) in part [Bp][152]; the
+ * ranks' partials are merged on the host side of the ABI (ader_amd/engine.py). */
+int ader_lbf_prep(const float* rep, void* rep_bf, int B, int Bp, int H, void* stream);
+/* merge of the ranks' partials of THIS rank's rows (parts [world][Bp][152], slice i from rank i) -> lse/off/rowloss [Bp],
+ * loss [1], drep [B,H]; e_lab [B,H] = fp32 table rows of the labels (ADER.py:88-93 evaluated over a sharded item axis) */
+int ader_lbf_merge_parts(const float* parts, int world, int Bp, int B, int H, const float* e_lab, const void* rep_bf,
+                         const float* wrow, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream);
+/* table rows travelling between ranks: out[p] = table[ids[p]] if lo < ids[p] <= hi else 0;  and the receiving side:
+ * recv [world][n][H] (slice i from rank i) -> table[ids[p]] for p < n_tab, extra[p - n_tab] for the rest (label rows);
+ * the owner of id is (id-1)/shard; padding ids (0) are skipped (tf.nn.embedding_lookup of modules.py:127 across shards) */
+int ader_gather_owned(const float* table, const int* ids, int n, int H, int lo, int hi, float* out, void* stream);
+int ader_scatter_owned(const float* recv, const int* ids, int n, int n_tab, int H, int shard, int world, float* table,
+                       float* extra, void* stream);
+int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int Bp, int H, int N, int item_begin,
+                       int item_count, float* pm, float* pl, float* pO, float* part, void* stream);
 /* demb rows 1..N overwritten (each row written once, then the sparse one-hot term is added with float atomics) */
 int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
                       const float* wrow, const float* off, float* demb, void* stream);

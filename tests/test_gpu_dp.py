@@ -45,12 +45,15 @@ def _worker(rank, world, port, out, logits, sharded):
     from ader_amd import dist as adist
     seq, pos = _data()
     eng = _engine(logits, rank, world)
-    eng.dp_sharded = sharded
+    eng.dp_sharded = bool(sharded)
     dp = adist.DataParallel(eng, rank, world)
+    if sharded == "catalog":
+        eng.dp_mode = "catalog"
     lo, hi = adist.shard_bounds(B, world, rank)
     for step in range(2):
         dp.set_rows(lo, N)
         eng.train_step(seq[lo:hi], pos[lo:hi], N, 5e-4, rate=0.3, n_train_global=B)
+    eng.sync_table()       # catalog mode: the other ranks' rows come back only on request
     torch.cuda.synchronize()
     if rank == 1:          # the last rank: its own table shard and the gathered ones must both be right
         torch.save(eng.theta.cpu()[:(ITEMS + 1) * H], out)
@@ -58,7 +61,7 @@ def _worker(rank, world, port, out, logits, sharded):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("logits,sharded", [("f32", False), ("bf16", False), ("bf16", True)])
+@pytest.mark.parametrize("logits,sharded", [("f32", False), ("bf16", False), ("bf16", True), ("bf16", "catalog")])
 def test_two_ranks_match_single_process(logits, sharded):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
