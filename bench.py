@@ -177,7 +177,8 @@ def main():
             "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
             "adam": ("hbm", 7.0 * P * 4, HBM_PEAK_GBS),
             # fused table update: theta/m/v of rows 1..N in and out + bf16 shadow row in and out (dE never hits memory)
-            "logits_bwd_adam": ("hbm", 6.0 * N * H * 4 + 2.0 * N * 336, HBM_PEAK_GBS),
+            # (catalog-sharded N > 1: a rank updates only its N / world rows)
+            "logits_bwd_adam": ("hbm", (6.0 * N * H * 4 + 2.0 * N * 336) / (world if eng.dp_mode == "catalog" else 1), HBM_PEAK_GBS),
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
             "param_allgather": ("hbm", 0.0, HBM_PEAK_GBS),
         }
