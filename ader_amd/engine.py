@@ -928,7 +928,7 @@ class Engine:
             e_lab = self.buf("cs_elab", (B, H))
             call("ader_scatter_owned", ptr(recv), ptr(ids_l), n_all, n_pos, H, S, W, self._pp["emb"], ptr(e_lab), st)
         self._table_stale = True
-        seq_g = ids_g[:, :n_pos]
+        self._lists_async(ids_g[:, :n_pos], ids_g[:, n_pos:], N)              # id-sorted lists of the GLOBAL batch, side stream
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
@@ -960,10 +960,9 @@ class Engine:
             meta_g, g_g = self._ag(meta), self._ag(dx)                         # [W,3,Bp], [W,B*T,H]
             off_g = meta_g[:, 0].contiguous().view(torch.float32)
             w_g = meta_g[:, 1].contiguous().view(torch.float32)
-            lab_g = meta_g[:, 2].contiguous()
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
-        ids, order, sp_start, tids, torder, tg_start = self._sparse_lists(seq_g, lab_g, N)
+        ids, order, sp_start, tids, torder, tg_start = self._lists_wait()
         tiles = S // 128
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
