@@ -928,7 +928,10 @@ class Engine:
             e_lab = self.buf("cs_elab", (B, H))
             call("ader_scatter_owned", ptr(recv), ptr(ids_l), n_all, n_pos, H, S, W, self._pp["emb"], ptr(e_lab), st)
         self._table_stale = True
-        self._lists_async(ids_g[:, :n_pos], ids_g[:, n_pos:], N)              # id-sorted lists of the GLOBAL batch, side stream
+        lab_all = self.buf("cs_lab_all", (W, Bp), torch.int32)                 # labels in the padded row numbering of rep_g
+        lab_all.zero_()
+        lab_all[:, :B] = ids_g[:, n_pos:]
+        self._lists_async(ids_g[:, :n_pos], lab_all, N)                       # id-sorted lists of the GLOBAL batch, side stream
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
