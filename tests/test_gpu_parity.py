@@ -297,6 +297,83 @@ def test_session_tiled_step_equals_per_op_step(shape, prune):
         assert nerr(out[0][1][k], out[1][1][k], floor=1e-4) < 6e-4, (k, nerr(out[0][1][k], out[1][1][k], floor=1e-4))
 
 
+@pytest.mark.parametrize("N,shards", [(4321, 2), (4321, 3), (650, 8)])
+def test_sharded_logits_forward_equals_unsharded(N, shards):
+    """Catalog-sharded softmax (ader_lbf_fwd_shard per item shard + ader_lbf_merge_parts) against ader_lbf_fwd over the whole
+    catalog on the same bf16 operands: lse, backward offsets, loss rows and dRep.  Shards beyond N are empty partials."""
+    from ader_amd._lib import call, ptr
+    item_num, H, B = 5000, 150, 200
+    Bp = 256
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(N)
+    emb = (torch.randn(item_num + 1, H, generator=g) * 0.05).to(dev)
+    rep = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    lab = torch.zeros(Bp, dtype=torch.int32, device=dev)
+    lab[:B] = torch.randint(1, N + 1, (B,), generator=g).to(dev)
+    wrow = torch.zeros(Bp, device=dev)
+    wrow[:B] = 1.0 / B
+    shadow = torch.zeros((item_num + 1) * 168, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    call("ader_lbf_shadow_refresh", ptr(emb), ptr(shadow), item_num + 1, H, st)
+    rep_bf = torch.zeros(Bp * 168, dtype=torch.bfloat16, device=dev)
+    R = call("ader_lbf_ranges", N, Bp)
+    pm, pl, pO = torch.empty(R * Bp, device=dev), torch.empty(R * Bp, device=dev), torch.empty(R * Bp * 160, device=dev)
+    ref = {k: torch.zeros(Bp, device=dev) for k in ("lse", "off", "rowloss")}
+    loss, drep = torch.zeros(1, device=dev), torch.zeros(B, H, device=dev)
+    call("ader_lbf_fwd", ptr(rep), ptr(shadow), item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO),
+         ptr(ref["lse"]), ptr(ref["off"]), ptr(ref["rowloss"]), ptr(loss), ptr(drep), st)
+    S = -(-item_num // (128 * shards)) * 128
+    parts = torch.empty(shards, Bp, 152, device=dev)
+    call("ader_lbf_prep", ptr(rep), ptr(rep_bf), B, Bp, H, st)
+    Rs = call("ader_lbf_ranges", S, Bp)
+    pm2, pl2, pO2 = torch.empty(Rs * Bp, device=dev), torch.empty(Rs * Bp, device=dev), torch.empty(Rs * Bp * 160, device=dev)
+    for r in range(shards):
+        call("ader_lbf_fwd_shard", ptr(rep_bf), ptr(shadow), item_num, Bp, H, N, r * S, S, ptr(pm2), ptr(pl2), ptr(pO2),
+             ptr(parts[r]), st)
+    e_lab = emb[lab[:B].long()].contiguous()
+    got = {k: torch.zeros(Bp, device=dev) for k in ("lse", "off", "rowloss")}
+    loss2, drep2 = torch.zeros(1, device=dev), torch.zeros(B, H, device=dev)
+    call("ader_lbf_merge_parts", ptr(parts), shards, Bp, B, H, ptr(e_lab), ptr(rep_bf), ptr(wrow), ptr(got["lse"]), ptr(got["off"]),
+         ptr(got["rowloss"]), ptr(loss2), ptr(drep2), st)
+    torch.cuda.synchronize()
+    for k in ref:      # same bf16 products, fp32 sums in a different grouping
+        a, b = got[k][:B].cpu().numpy(), ref[k][:B].cpu().numpy()
+        assert nerr(a, b) < 2e-6, (k, nerr(a, b))
+    assert np.all(np.isneginf(got["off"][B:].cpu().numpy()))
+    assert abs(float(loss2) - float(loss)) < 2e-6 * abs(float(loss))
+    assert nerr(drep2.cpu().numpy(), drep.cpu().numpy()) < 2e-5
+
+
+def test_owned_rows_travel_between_shards():
+    """ader_gather_owned / ader_scatter_owned: every input position's table row is produced by exactly one shard and lands in
+    the receiver's table (labels in the side buffer); padding ids are skipped.  Index work: exact."""
+    from ader_amd._lib import call, ptr
+    V, H, W, S, n_tab, n_lab = 1025, 6, 4, 256, 300, 20
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(V, H, generator=g).to(dev)
+    ids = torch.randint(0, V, (n_tab + n_lab,), generator=g, dtype=torch.int32)
+    ids[:7] = 0
+    ids = ids.to(dev)
+    n = n_tab + n_lab
+    st = torch.cuda.current_stream().cuda_stream
+    recv = torch.empty(W, n, H, device=dev)
+    for r in range(W):                       # what rank r would send for these positions
+        call("ader_gather_owned", ptr(table), ptr(ids), n, H, r * S, (r + 1) * S, ptr(recv[r]), st)
+    assert torch.equal(recv.sum(0), table[ids.long()] * (ids > 0).unsqueeze(-1))
+    dst = torch.full((V, H), -1.0, device=dev)
+    extra = torch.full((n_lab, H), -1.0, device=dev)
+    call("ader_scatter_owned", ptr(recv), ptr(ids), n, n_tab, H, S, W, ptr(dst), ptr(extra), st)
+    torch.cuda.synchronize()
+    t_ids = ids[:n_tab].long()
+    live = t_ids[t_ids > 0]
+    assert torch.equal(dst[live], table[live])
+    untouched = torch.ones(V, dtype=torch.bool, device=dev)
+    untouched[live] = False
+    assert torch.all(dst[untouched] == -1.0)
+    assert torch.equal(extra, table[ids[n_tab:].long()] * (ids[n_tab:] > 0).unsqueeze(-1))
+
+
 @pytest.mark.parametrize("cfg", [BF16_CFGS[0], BF16_CFGS[1]])
 def test_fused_table_adam_equals_unfused_step(cfg):
     """Engine.fuse_adam applies Adam to the item table inside the table-gradient kernel (dE never written to memory,
