@@ -210,7 +210,7 @@ def main():
                     "ms": sections[dom],
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 leg only
             try:
                 cpu = cpu_baseline(N, B, T, H, L, heads, rate, lr)
             except Exception as e:  # report, never fake
