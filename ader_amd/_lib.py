@@ -56,6 +56,7 @@ _SIGS = {
     "ader_lbf_fwd_shard": [P, P, I, I, I, I, I, I, P, P, P, P, P],
     "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P],
+    "ader_lbf_bwd_adam_ex": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P][:-1] + [P, P],
     "ader_fused_bucket_gran": [],
     "ader_fused_bucket_id0": [],
     "ader_embed_bwd_rows": [P, P, P, I, I, I, I] + _DROP + [P],

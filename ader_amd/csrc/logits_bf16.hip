@@ -401,6 +401,7 @@ struct FuseArgs {
     const int* sp_start; const int* tg_start;   // bucket offsets into the two lists: bucket j = ids [gran*j + id0, gran*(j+1) + id0)
     float* emb1; float* m1; float* v1; bf16* sh1w;                                           // row of item 1 of theta/m/v/shadow
     float lr_t, omb1, omb2, eps;
+    const float* extra1;        // EXTRA: dense gradient rows to add (row of item 1; [.,H] fp32), e.g. distilled rows' term
 };
 
 __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, int key) {
@@ -418,7 +419,7 @@ __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n,
 // workgroup barrier that orders LDS traffic only (__syncthreads also drains every outstanding global access of the wave)
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool ADAM>
+template <bool ADAM, bool EXTRA = false>
 __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
@@ -549,7 +550,8 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
         int e = head + 4 * tid;
         int row = e / H, col = e - row * H;
         const int step_r = 1024 / H, step_c = 1024 - step_r * H;
-        f32x4_t P[AV], M[AV], V[AV];
+        f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
+        const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)base_it * H : nullptr;
         int E[AV], RC[AV], NV[AV];
 #define ROUND_LOAD()                                                                                       \
         _Pragma("unroll") for (int u = 0; u < AV; ++u) {                                                   \
@@ -557,7 +559,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
             NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);                                         \
             if (NV[u] == 2) {                                                                              \
                 P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e); \
+                if (EXTRA) G[u] = __builtin_nontemporal_load((const f32x4_t*)(gx + e));                    \
             } else if (NV[u] == 1) {                                                                       \
+                if (EXTRA) { const f32x2_t g_ = *(const f32x2_t*)(gx + e); G[u] = (f32x4_t){g_[0], g_[1], 0.f, 0.f}; } \
                 const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e); \
                 P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f}; \
             }                                                                                              \
@@ -613,7 +617,8 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
             { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
             if (head && tid == 0 && n_el > 0) {                   // elements 0,1 (row 0, columns 0,1)
                 f32x2_t p = *(const f32x2_t*)gp, m = *(const f32x2_t*)gm, v = *(const f32x2_t*)gv;
-                const float2 g2 = *(const float2*)F_l;
+                float2 g2 = *(const float2*)F_l;
+                if (EXTRA) { g2.x += gx[0]; g2.y += gx[1]; }
                 ADAM1(p[0], m[0], v[0], g2.x); ADAM1(p[1], m[1], v[1], g2.y);
                 *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
                 bf16x2 sb; sb[0] = (bf16)p[0]; sb[1] = (bf16)p[1];
@@ -625,8 +630,9 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
 #pragma unroll
                 for (int u = 0; u < AV; ++u) {
                     if (NV[u] == 0) continue;
-                    const float2 ga = *(const float2*)(F_l + E[u]);
-                    const float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
+                    float2 ga = *(const float2*)(F_l + E[u]);
+                    float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
+                    if (EXTRA) { ga.x += G[u][0]; ga.y += G[u][1]; gb.x += G[u][2]; gb.y += G[u][3]; }
                     f32x4_t p = P[u], m = M[u], v = V[u];
                     ADAM1(p[0], m[0], v[0], ga.x); ADAM1(p[1], m[1], v[1], ga.y);
                     ADAM1(p[2], m[2], v[2], gb.x); ADAM1(p[3], m[3], v[3], gb.y);
@@ -800,18 +806,38 @@ int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int 
 // sp_ids/sp_rows: the B*T input positions sorted by item id (pads = id 0 first) and their row index into sp_src [B*T,H]
 // (the masked/dropout-scaled gradient rows left by ader_embed_bwd_rows); sp_scale = sqrt(H).
 // tg_ids/tg_rows: the B labels sorted by id and their batch row.  emb/adam_m/adam_v: fp32 [item_num+1, H].
+int ader_lbf_bwd_adam_ex(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
+                         const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
+                         float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                         int tile_count, const float* extra_grad, void* stream);
+
 int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
                       const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
                       const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
                       float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
                       int tile_count, void* stream) {
+    return ader_lbf_bwd_adam_ex(rep_bf, shadow, item_num, B, Bp, H, N, off, sp_ids, sp_rows, sp_start, n_sp, sp_src, sp_scale, tg_ids,
+                                tg_rows, tg_start, n_tg, wrow, emb, adam_m, adam_v, lr_t, beta1, beta2, eps, tile_begin, tile_count,
+                                nullptr, stream);
+}
+
+// As ader_lbf_bwd_adam, plus a dense gradient extra_grad [item_num+1, H] (fp32, table layout; NULL = none) added row by row
+// before the update -- the table gradient of rows that did not go through the bf16 logit path (distilled exemplar rows).
+int ader_lbf_bwd_adam_ex(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
+                         const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
+                         float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                         int tile_count, const float* extra_grad, void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num) return -2;
     static bool f = false;
     static int lds_set = 0;
     const size_t lds = bwd_lds(Bp);
     if (!f || (int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         f = true; lds_set = (int)lds;
     }
@@ -825,6 +851,7 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
     fa.sp_start = sp_start; fa.tg_start = tg_start;
     fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = (bf16*)shadow + LDR;
     fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
+    fa.extra1 = extra_grad ? extra_grad + H : nullptr;
     {   // tiles [tile_begin, tile_begin + tile_count) of the ceil(N/128) item tiles (tile_count < 0: all)
         const int all = (N + 127) / 128;
         int tb = tile_begin < 0 ? 0 : tile_begin;
@@ -832,7 +859,8 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
         if (te > all) te = all;
         if (te <= tb) return 0;
         a.tile_off = tb;
-        hipLaunchKernelGGL(k_lbf_bwd_de<true>, dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
+        if (extra_grad) hipLaunchKernelGGL((k_lbf_bwd_de<true, true>), dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
+        else hipLaunchKernelGGL((k_lbf_bwd_de<true, false>), dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
     }
     HIP_LAUNCH_CHECK();
     return 0;

@@ -206,6 +206,7 @@ class Engine:
         # streams only those in the logit kernels and never receives the other ranks' rows except the few its inputs need
         # (_train_step_catalog); "replicated" = every rank holds the whole table (the two schemes of dist.py)
         self.dp_mode = "replicated"
+        self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self._table_stale = False
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -485,14 +486,14 @@ class Engine:
         return rep
 
     # ---------------------------------------------------------------------------------------- loss rows
-    def _rowinfo(self, B, pos, n_train, ex_pos, ex_trow, N, Np, w_train, w_ex, teacher):
+    def _rowinfo(self, B, pos, n_train, ex_pos, ex_trow, N, Np, w_train, w_ex, teacher, tag="ri_"):
         Bp = (B + 63) // 64 * 64
         st = self._stream()
-        lab = self.buf("ri_lab", (Bp,), torch.int32)
-        ncol = self.buf("ri_ncol", (Bp,), torch.int32)
-        wrow = self.buf("ri_w", (Bp,))
-        trow = self.buf("ri_trow", (Bp,), torch.int32)
-        tlse = self.buf("ri_tlse", (Bp,))
+        lab = self.buf(tag + "lab", (Bp,), torch.int32)
+        ncol = self.buf(tag + "ncol", (Bp,), torch.int32)
+        wrow = self.buf(tag + "w", (Bp,))
+        trow = self.buf(tag + "trow", (Bp,), torch.int32)
+        tlse = self.buf(tag + "tlse", (Bp,))
         n_ex = B - n_train
         call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos), ptr(ex_trow), n_ex, N, Np, float(w_train), float(w_ex), Bp,
              ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
@@ -533,7 +534,11 @@ class Engine:
         step = self.global_step
         st = self._stream()
         rows = B * T
-        use_bf16 = self.shadow is not None and teacher is None
+        # distilled steps with a bf16 shadow: the train rows take the bf16 flash path and the fused table update, the (few)
+        # exemplar rows the exact-f32 kernels; their table gradient enters the fused update as a dense extra term
+        split_kd = bool(self.shadow is not None and teacher is not None and n_ex > 0 and n_train > 0 and _defer_table
+                        and N >= self._grad_hi and self.dp_world == 1 and self.kd_split)
+        use_bf16 = self.shadow is not None and (teacher is None or split_kd)
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
         self._deferred = None
         with self._sec("blocks_fwd"):
@@ -541,7 +546,7 @@ class Engine:
         if defer and self.dp_world == 1:
             # the id-bucketed lists of the fused table update need only the inputs: build them on a side stream, under the
             # logit kernels (the one-launch forward owns every CU's LDS; the logit kernels leave room for it)
-            labs = pos if n_ex == 0 else torch.cat([pos, ex_pos])
+            labs = pos if (n_ex == 0 or split_kd) else torch.cat([pos, ex_pos])
             self._lists_async(seq, labs, N)
         A = self._act
         emb = self._pp["emb"]
@@ -550,20 +555,38 @@ class Engine:
             demb[N + 1:self._grad_hi + 1].zero_()
         self._grad_hi = max(self._grad_hi, N)
         drep = self.buf("drep", (B, H))
+        extra = None
         if use_bf16:
-            Bp = (B + 127) // 128 * 128
+            Bb = n_train if split_kd else B            # rows of the bf16 path
+            Bp = (Bb + 127) // 128 * 128
             lab, ncol = self.buf("ri_lab", (Bp,), torch.int32), self.buf("ri_ncol", (Bp,), torch.int32)
             wrow, trow = self.buf("ri_w", (Bp,)), self.buf("ri_trow", (Bp,), torch.int32)
-            call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos), None, n_ex, N, 0, float(w_train), float(w_ex), Bp,
-                 ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
+            call("ader_build_rowinfo", ptr(pos), n_train, None if split_kd else ptr(ex_pos), None, 0 if split_kd else n_ex, N, 0,
+                 float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
             R = call("ader_lbf_ranges", N, Bp)
             rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
             pm, pl = self.buf("lbf_pm", (R * Bp,)), self.buf("lbf_pl", (R * Bp,))
             pO = self.buf("lbf_pO", (R * Bp * 160,))
             lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
             with self._sec("logits_fwd"):
-                call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
+                call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
                      ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
+            if split_kd:
+                rep_x, drep_x = rep[n_train:], drep[n_train:]
+                Bpx, rix = self._rowinfo(n_ex, None, 0, None, ex_trow, N, Np, w_train, w_ex, teacher, tag="kd_")
+                parts = call("ader_logits_parts", N)
+                part = self.buf("lg_part", (parts * Bpx * 3,))
+                lse_x, rowloss_x = self.buf("kd_lse", (Bpx,)), self.buf("kd_rowloss", (Bpx,))
+                loss_x = self.buf("kd_loss", (1,))
+                with self._sec("kd_rows"):
+                    call("ader_logits_loss_fwd", ptr(rep_x), emb, n_ex, Bpx, H, N, *rix, ptr(part), ptr(lse_x), ptr(rowloss_x),
+                         ptr(loss_x), st)
+                    ranges = call("ader_logits_ranges", N, Bpx)
+                    slab = self.buf("lg_slab", (ranges * Bpx * 160,))
+                    call("ader_logits_bwd_drep", ptr(rep_x), emb, n_ex, Bpx, H, N, *rix, ptr(lse_x), ptr(slab), ptr(drep_x), st)
+                    call("ader_logits_bwd_demb", ptr(rep_x), emb, n_ex, Bpx, H, N, *rix, ptr(lse_x), ptr(demb), st)
+                    self.loss.add_(loss_x)
+                extra = demb
             if not defer:
                 with self._sec("logits_bwd_demb"):
                     call("ader_lbf_bwd_demb", ptr(rep_bf), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow),
@@ -584,7 +607,8 @@ class Engine:
                 call("ader_logits_bwd_demb", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
         dx = self._blocks_backward(seq, drep, defer, demb)
         if defer:
-            self._deferred = dict(seq=seq, g=dx, B=B, Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab, wrow=wrow)
+            self._deferred = dict(seq=seq, g=dx, B=(n_train if split_kd else B), Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab,
+                                  wrow=wrow, extra=extra)
         return self.loss
 
 
@@ -817,10 +841,10 @@ class Engine:
             with torch.cuda.stream(self._side):
                 small_update()
         with self._sec("logits_bwd_adam"):
-            call("ader_lbf_bwd_adam", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
+            call("ader_lbf_bwd_adam_ex", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
                  ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                  ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
-                 self.beta1, self.beta2, self.eps, 0, -1, st)
+                 self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
         if overlap:
             main.wait_stream(self._side)
         else:

@@ -179,6 +179,8 @@ def main():
             # fused table update: theta/m/v of rows 1..N in and out + bf16 shadow row in and out (dE never hits memory)
             # (catalog-sharded N > 1: a rank updates only its N / world rows)
             "logits_bwd_adam": ("hbm", (6.0 * N * H * 4 + 2.0 * N * 336) / (world if eng.dp_mode == "catalog" else 1), HBM_PEAK_GBS),
+            # distilled exemplar rows on the exact-f32 kernels: logits + dRep + dE over the 0.9 N teacher columns
+            "kd_rows": ("mfma", 3 * 2.0 * E * int(0.9 * N) * H, F32_MFMA_PEAK_TFLOPS),
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
             "param_allgather": ("hbm", 0.0, HBM_PEAK_GBS),
         }

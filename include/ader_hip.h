@@ -233,6 +233,13 @@ int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int
                       float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
                       const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
                       float eps, int tile_begin, int tile_count, void* stream);
+/* ... plus a dense fp32 gradient extra_grad [item_num+1, H] (table layout, NULL = none) added row by row before the update:
+ * the table gradient of rows that did not go through the bf16 logit path (distilled exemplar rows, ADER.py:132-137) */
+int ader_lbf_bwd_adam_ex(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src,
+                         float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
+                         const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
+                         float eps, int tile_begin, int tile_count, const float* extra_grad, void* stream);
 /* tile_begin/tile_count: restrict the update to 128-item tiles [tile_begin, tile_begin+tile_count) (row-sharded table
  * update under data parallelism; tile_count < 0 = all tiles).  B/Bp then describe the GLOBAL batch. */
 int ader_fused_bucket_gran(void);

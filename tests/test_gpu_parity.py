@@ -412,6 +412,32 @@ def test_fused_table_adam_equals_unfused_step(cfg):
     assert nerr(a2[1], b2[1]) < 1e-2 and np.abs(a2[0] - b2[0]).max() < 2.5e-3
 
 
+def test_split_kd_step_matches_all_f32_kd_step():
+    """Distilled step with a bf16 shadow (Engine.kd_split): train rows go through the bf16 flash logits + fused table update,
+    the exemplar rows through the exact-f32 KD kernels whose table gradient enters the fused update as a dense term.  One
+    step must leave the Adam state of the all-f32 KD step up to the bf16 rounding of the train rows' logit operands."""
+    item_num, T, H, L, heads, B, N = BF16_CFGS[1]
+    n_ex, Np = 37, 4000
+    rs = np.random.RandomState(12)
+    seq = _seqs(rs, B + n_ex, T, N)
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    teacher = torch.from_numpy(rs.standard_normal((50, Np)).astype(np.float32)).cuda()
+    trow = rs.randint(0, 50, size=n_ex).astype(np.int32)
+    out = []
+    for split in (True, False):
+        eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
+        eng.kd_split = split
+        loss = eng.train_step(seq, pos, N, 5e-4, rate=0.3, teacher=teacher, ex_trow=trow, lambda_=0.7)
+        torch.cuda.synchronize()
+        out.append((float(loss.item()), eng.adam_m.cpu().numpy().copy(), eng.theta.cpu().numpy().copy()))
+    (la, ma, ta), (lb, mb, tb) = out
+    assert abs(la - lb) < 5e-3 * abs(lb)
+    span = (item_num + 1) * H
+    assert nerr(ma[:span], mb[:span]) < 3e-2              # table gradient (m = 0.1 g after one step)
+    assert nerr(ma[span:], mb[span:], floor=1e-6) < 3e-2  # every other parameter
+    assert np.abs(ta - tb).max() < 1.1e-3                 # one Adam step moves a parameter by at most lr
+
+
 def test_adam_keeps_bf16_shadow_in_sync():
     eng = _engine(301, 20, 64, 1, 2, logits_dtype="bf16")          # odd row count: float4 groups straddle table rows
     g = torch.Generator().manual_seed(9)
