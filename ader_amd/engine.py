@@ -498,7 +498,17 @@ class Engine:
         call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos), ptr(ex_trow), n_ex, N, Np, float(w_train), float(w_ex), Bp,
              ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
         if teacher is not None and n_ex > 0:
-            call("ader_row_lse", ptr(teacher), teacher.stride(0), Np, ptr(trow), Bp, ptr(tlse), st)
+            # log-sum-exp of the teacher rows: the teacher logits of an exemplar are fixed for a whole period, so the LSE of
+            # every stored row is computed once per teacher tensor and gathered per step
+            key = (teacher.data_ptr(), tuple(teacher.shape), teacher._version)
+            if getattr(self, "_tlse_key", None) != key:
+                E_all = teacher.shape[0]
+                allrows = torch.arange(E_all, dtype=torch.int32, device=self.device)
+                self._tlse_all = torch.empty(E_all, dtype=torch.float32, device=self.device)
+                call("ader_row_lse", ptr(teacher), teacher.stride(0), Np, ptr(allrows), E_all, ptr(self._tlse_all), st)
+                self._tlse_key = key
+            tlse.zero_()
+            tlse[n_train:n_train + n_ex] = self._tlse_all[trow[n_train:n_train + n_ex].long()]
             tptr, ldt = ptr(teacher), teacher.stride(0)
         else:
             tlse.zero_()
