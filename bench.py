@@ -208,7 +208,9 @@ def main():
             else:
                 ach, unit = amount / sec / 1e9, "GB/s"
             roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                    "traffic": (pmc.get(pmc_kernel.get(dom, ""), {}).get("hbm_bytes") if unit == "GB/s" else None),
+                    "traffic": (next((v.get("hbm_bytes") for k_, v in pmc.items()
+                                      if pmc_kernel.get(dom) and k_.startswith(pmc_kernel[dom].rstrip(">"))), None)
+                                if unit == "GB/s" else None),
                     "ms": sections[dom],
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
         cpu = None
