@@ -72,11 +72,13 @@ class SectionTimer:
     """HIP-event timing of named launch groups on the stream the kernels are launched on (bench.py roofline leg).
     Events are recorded around each section; elapsed times are read back after a sync with collect()."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, every=1):
         self.pending = []
         self.totals = {}
         self.counts = {}
-        self.only = only          # restrict the event pairs to these sections (each pair costs a few us of stream time)
+        self.only = only          # restrict the event pairs to these sections (each pair costs stream time)
+        self.every = max(1, int(every))   # ... and to every n-th occurrence of a section
+        self.seen = {}
 
     class _Ctx:
         def __init__(self, owner, name):
@@ -93,6 +95,10 @@ class SectionTimer:
 
     def section(self, name):
         if self.only is not None and name not in self.only:
+            return _NULL
+        k = self.seen.get(name, 0)
+        self.seen[name] = k + 1
+        if k % self.every:
             return _NULL
         return SectionTimer._Ctx(self, name)
 
