@@ -455,6 +455,18 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
         for (int i = 0; i < 8 && k0 + i < k1; ++i) { mt[2 + 2 * i] = ids[k0 + i]; mt[3 + 2 * i] = rows[k0 + i]; }
     }
     __syncthreads();
+    // ADAM: the first SPV input-embedding gradient rows of each half-tile (thread c holds column c), requested now and
+    // consumed after the GEMM phase
+#define SPV 3
+    float spv0[SPV], spv1[SPV];
+    if (ADAM) {
+#pragma unroll
+        for (int i = 0; i < SPV; ++i) {
+            const int* m0 = meta_l, * m1 = meta_l + 2 * 18;
+            spv0[i] = (tid < H && m0[0] + i < m0[1]) ? f.sp_src[(size_t)m0[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
+            spv1[i] = (tid < H && m1[0] + i < m1[1]) ? f.sp_src[(size_t)m1[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
+        }
+    }
     bf16x8 efrag[10];                                   // lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) efrag[ks] = *(const bf16x8*)(R_l + (wave * 32 + r) * LDR + 16 * ks + 8 * hh);
@@ -594,7 +606,15 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
                 // entries of bucket base_it >> 6 (ids [base_it+1, base_it+65): exactly this half-tile), (id, row)-ordered
                 const int* ms = meta_l + (half * 2 + 0) * 18;
                 const int* mg = meta_l + (half * 2 + 1) * 18;
-                for (int k = ms[0], k1 = ms[1], i = 0; k < k1; ++k, ++i) {
+                const int k0s = ms[0], k1s = ms[1];
+#pragma unroll
+                for (int i = 0; i < SPV; ++i) {                  // rows already in registers (same (id, row) order)
+                    if (k0s + i < k1s) {
+                        const int id = ms[2 + 2 * i];
+                        if (id < id_hi) F_l[(id - id_lo) * fs + tid] += half ? spv1[i] : spv0[i];
+                    }
+                }
+                for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
                     const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
                     if (id >= id_hi) break;
                     const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
