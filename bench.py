@@ -82,8 +82,8 @@ def cpu_baseline(N, B, T, H, L, heads, rate, lr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--logits", choices=["bf16", "f32"], default="bf16",
