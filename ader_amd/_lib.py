@@ -7,7 +7,7 @@ import os
 from ctypes import c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libader_hip.so")
+LIB_PATH = os.environ.get("ADER_HIP_LIB") or os.path.join(_HERE, "libader_hip.so")      # (override: A/B runs of two builds)
 
 P, I, U, F, L, Z = c_void_p, c_int, c_uint, c_float, c_long, c_size_t
 _DROP = [U, U, F, U]
