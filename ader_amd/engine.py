@@ -212,6 +212,7 @@ class Engine:
         # streams only those in the logit kernels and never receives the other ranks' rows except the few its inputs need
         # (_train_step_catalog); "replicated" = every rank holds the whole table (the two schemes of dist.py)
         self.dp_mode = "replicated"
+        self.dp_pack = os.environ.get("ADER_DP_PACK", "1") == "1"   # catalog mode: only owned rows travel (one host sync per step)
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self._table_stale = False
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
@@ -935,6 +936,43 @@ class Engine:
             return out
         return self._ag(t)[:, self.dp_rank].contiguous()        # backends without all-to-all on device tensors (tests)
 
+    @staticmethod
+    def _group_order(key, G):
+        """Stable grouping permutation: indices of `key` (int64 [n], values in [0, G)) ordered by key, original order inside a
+        group -- a counting sort with a prefix sum (a handful of small launches instead of a radix sort)."""
+        n = key.numel()
+        oh = torch.zeros(n, G, dtype=torch.int32, device=key.device)
+        oh.scatter_(1, key.view(-1, 1), 1)
+        csum = oh.cumsum(0, dtype=torch.int32)
+        rank = csum.gather(1, key.view(-1, 1)).view(-1) - 1
+        cnt = csum[-1].long()
+        off = cnt.cumsum(0) - cnt
+        out = torch.empty(n, dtype=torch.int64, device=key.device)
+        out[off[key] + rank.long()] = torch.arange(n, device=key.device)
+        return out
+
+    def _a2a_rows(self, rows, counts):
+        """Uneven all-to-all of rows [K, H]: counts [W, W] (host ints), counts[i][j] = rows rank i sends to rank j; the local
+        rows are ordered by destination.  Returns the received rows ordered by source."""
+        import torch.distributed as dist
+        W, r = self.dp_world, self.dp_rank
+        ins = [int(c) for c in counts[r]]
+        outs = [int(counts[i][r]) for i in range(W)]
+        out = torch.empty((sum(outs),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        if dist.get_backend(self.dp_group) == "nccl":
+            dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=outs, input_split_sizes=ins, group=self.dp_group)
+            return out
+        # backends without all-to-all on device tensors (tests): padded all-gather, then cut my segments out
+        kmax = max(int(sum(counts[i])) for i in range(W))
+        pad = torch.zeros((kmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        pad[:rows.shape[0]] = rows
+        allr = self._ag(pad)
+        segs = []
+        for i in range(W):
+            o = int(sum(counts[i][:r]))
+            segs.append(allr[i, o:o + outs[i]])
+        return torch.cat(segs) if segs else out
+
     def _train_step_catalog(self, seq, pos, max_item, lr, rate=0.0, n_train_global=None, **_unused):
         """Vanilla train step with the item catalog sharded across the ranks (dense Adam touches every table row
         every step, so a replicated table costs (W-1)/W x 600 MB of xGMI traffic per rank per step; a sharded one costs only
@@ -959,19 +997,65 @@ class Engine:
         st = self._stream()
         step = self.global_step
         n_pos, n_all = B * T, B * T + B
+        pack = self.dp_pack
         with self._sec("grad_exchange"):
             ids_l = torch.cat([seq.reshape(-1), pos])                          # my input positions, then my labels
             ids_g = self._ag(ids_l)                                            # [W, n_all]
-            send = self.buf("cs_send", (W, n_all, H))
-            call("ader_gather_owned", self._pp["emb"], ptr(ids_g), W * n_all, H, r * S, (r + 1) * S, ptr(send), st)
-            recv = self._a2a(send)                                             # slice i: rows rank i owns among MY positions
             e_lab = self.buf("cs_elab", (B, H))
-            call("ader_scatter_owned", ptr(recv), ptr(ids_l), n_all, n_pos, H, S, W, self._pp["emb"], ptr(e_lab), st)
+            if not pack:
+                # dense exchange: every rank sends a full [n_all, H] block to every peer (zeros where it is not the owner)
+                send = self.buf("cs_send", (W, n_all, H))
+                call("ader_gather_owned", self._pp["emb"], ptr(ids_g), W * n_all, H, r * S, (r + 1) * S, ptr(send), st)
+                recv = self._a2a(send)                                         # slice i: rows rank i owns among MY positions
+                call("ader_scatter_owned", ptr(recv), ptr(ids_l), n_all, n_pos, H, S, W, self._pp["emb"], ptr(e_lab), st)
+            else:
+                # packed exchange: only owned rows travel.  Every rank derives the same owner map and the [owner, destination]
+                # row counts from the gathered ids; the counts go to the host (the one sync of the step: split sizes)
+                own = torch.where(ids_g > 0, torch.clamp((ids_g - 1) // S, max=W - 1), torch.full_like(ids_g, -1)).long()
+                dst = torch.arange(W, device=self.device).view(W, 1).expand(W, n_all)
+                key = torch.where(own >= 0, own * W + dst, torch.full_like(own, W * W))
+                cnt = torch.zeros(2, W * W + 1, dtype=torch.int64, device=self.device)
+                one = torch.ones_like(key)
+                cnt[0].scatter_add_(0, key.reshape(-1), one.reshape(-1))                       # all positions (inputs + labels)
+                cnt[1].scatter_add_(0, key[:, :n_pos].reshape(-1), one[:, :n_pos].reshape(-1))  # input positions only
+                C = cnt[:, :W * W].view(2, W, W).cpu().tolist()
+                C_all, C_pos = C[0], C[1]
+                table = self.theta[:self.V_alloc * H].view(self.V_alloc, H)
+                # rows I own, ordered by (destination, position): stable sort of the destination index, non-owned last
+                ksend = torch.where(own == r, dst, torch.full_like(own, W)).reshape(-1)
+                K = sum(C_all[r])
+                idx_send = self._group_order(ksend, W + 1)[:K]
+                rows = table[ids_g.reshape(-1)[idx_send].long()]
+                got = self._a2a_rows(rows, C_all)                              # ordered by owner, then by my position index
+                perm = self._group_order(own[r] + 1, W + 1)                    # my positions: padding first, then by owner
+                n_pad = n_all - got.shape[0]
+                full = self.buf("cs_full", (n_all, H))
+                full.zero_()
+                full.index_copy_(0, perm[n_pad:], got)
+                row0 = table[0].clone()                                        # padding positions carry id 0: row 0 stays as it is
+                table.index_copy_(0, ids_l[:n_pos].long(), full[:n_pos])
+                table[0].copy_(row0)
+                e_lab.copy_(full[n_pos:])
+                # the same bookkeeping for the gradient rows that travel back after the backward pass
+                # (inside a destination / owner group the positions are in order, so the labels -- the last B positions of a
+                #  rank -- are the tail of every group: the input-position part of a group is its first C_pos entries)
+                o, segs = 0, []
+                for j in range(W):
+                    segs.append(idx_send[o:o + C_pos[r][j]])
+                    o += C_all[r][j]
+                ids_back = ids_g.reshape(-1)[torch.cat(segs)]                  # ids of the gradient rows I will receive
+                o, segs = n_pad, []
+                for i in range(W):
+                    segs.append(perm[o:o + C_pos[i][r]])
+                    o += C_all[i][r]
+                back_src = torch.cat(segs)                                     # my input positions, grouped by owner
         self._table_stale = True
         lab_all = self.buf("cs_lab_all", (W, Bp), torch.int32)                 # labels in the padded row numbering of rep_g
         lab_all.zero_()
         lab_all[:, :B] = ids_g[:, n_pos:]
-        self._lists_async(ids_g[:, :n_pos], lab_all, N)                       # id-sorted lists of the GLOBAL batch, side stream
+        # id-sorted lists of the sparse terms of the GLOBAL batch (side stream): positions of the all-gathered gradient rows, or,
+        # packed, of the rows this rank will receive
+        self._lists_async(ids_back if pack else ids_g[:, :n_pos], lab_all, N)
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
@@ -1000,7 +1084,11 @@ class Engine:
         lr_t = self._lr_t(lr)
         span = self.layout["pos"][0]
         with self._sec("grad_exchange"):
-            meta_g, g_g = self._ag(meta), self._ag(dx)                         # [W,3,Bp], [W,B*T,H]
+            meta_g = self._ag(meta)                                            # [W,3,Bp]
+            if pack:    # gradient rows go only to the owner of their id: counts transposed with respect to the fetch
+                g_g = self._a2a_rows(dx[back_src], [[C_pos[j][i] for j in range(W)] for i in range(W)])
+            else:
+                g_g = self._ag(dx)                                             # [W,B*T,H]
             off_g = meta_g[:, 0].contiguous().view(torch.float32)
             w_g = meta_g[:, 1].contiguous().view(torch.float32)
             dist.all_reduce(self.grad[span:], group=grp)
