@@ -212,7 +212,10 @@ class Engine:
         # streams only those in the logit kernels and never receives the other ranks' rows except the few its inputs need
         # (_train_step_catalog); "replicated" = every rank holds the whole table (the two schemes of dist.py)
         self.dp_mode = "replicated"
-        self.dp_pack = os.environ.get("ADER_DP_PACK", "1") == "1"   # catalog mode: only owned rows travel (one host sync per step)
+        # catalog mode: only owned rows travel (one host sync per step + ~20 small launches of bookkeeping) instead of a dense
+        # 15 MB block per peer; pays off once the peers' blocks add up (default: 4 ranks or more; ADER_DP_PACK=0/1 overrides)
+        _p = os.environ.get("ADER_DP_PACK")
+        self.dp_pack = (self.dp_world >= 4) if _p is None else (_p == "1")
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self._table_stale = False
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
@@ -1021,10 +1024,9 @@ class Engine:
                 C = cnt[:, :W * W].view(2, W, W).cpu().tolist()
                 C_all, C_pos = C[0], C[1]
                 table = self.theta[:self.V_alloc * H].view(self.V_alloc, H)
-                # rows I own, ordered by (destination, position): stable sort of the destination index, non-owned last
-                ksend = torch.where(own == r, dst, torch.full_like(own, W)).reshape(-1)
-                K = sum(C_all[r])
-                idx_send = self._group_order(ksend, W + 1)[:K]
+                # rows I own, ordered by (destination, position): the gathered ids are already laid out [destination][position],
+                # so this is a plain compaction of the owned entries
+                idx_send = torch.nonzero(own.reshape(-1) == r).view(-1)
                 rows = table[ids_g.reshape(-1)[idx_send].long()]
                 got = self._a2a_rows(rows, C_all)                              # ordered by owner, then by my position index
                 perm = self._group_order(own[r] + 1, W + 1)                    # my positions: padding first, then by owner
