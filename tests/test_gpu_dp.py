@@ -47,8 +47,9 @@ def _worker(rank, world, port, out, logits, sharded):
     eng = _engine(logits, rank, world)
     eng.dp_sharded = bool(sharded)
     dp = adist.DataParallel(eng, rank, world)
-    if sharded == "catalog":
+    if sharded in ("catalog", "catalog_packed"):
         eng.dp_mode = "catalog"
+        eng.dp_pack = sharded == "catalog_packed"      # dense blocks per peer / only the owned rows (uneven all-to-all)
     lo, hi = adist.shard_bounds(B, world, rank)
     for step in range(2):
         dp.set_rows(lo, N)
@@ -61,7 +62,8 @@ def _worker(rank, world, port, out, logits, sharded):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("logits,sharded", [("f32", False), ("bf16", False), ("bf16", True), ("bf16", "catalog")])
+@pytest.mark.parametrize("logits,sharded", [("f32", False), ("bf16", False), ("bf16", True), ("bf16", "catalog"),
+                                            ("bf16", "catalog_packed")])
 def test_two_ranks_match_single_process(logits, sharded):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
