@@ -183,6 +183,8 @@ class Engine:
         self.lists_side_stream = True      # build the sparse lists under the block kernels
         self.late_side_stream = True       # small-parameter gradients / Adam run beside the (HBM-bound) fused table update
         self._late, self._late_on = [], False
+        self._st_ptr = None
+        self._pin = {}
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
         self._atb_q = []
         self.attn_x3 = gemm == "x3" and (hidden_units // num_heads) % 2 == 0      # bf16x3 attention core (attn_x3.hip)
@@ -236,6 +238,7 @@ class Engine:
 
     def init_params(self, seed):
         """TF defaults at the reference call sites: Glorot-uniform tables/kernels, zero biases, LN gamma=1 beta=0."""
+        self._refresh_stream()
         g = torch.Generator().manual_seed(seed)
         for name, (off, shp) in self.layout.items():
             base = name.split(".")[-1]
@@ -256,11 +259,13 @@ class Engine:
     def refresh_shadow(self):
         """Rebuild the bf16 copies derived from the fp32 master parameters (after init / load / any direct write):
         the shadow item table of the bf16 logit GEMMs and the hi/lo weight planes of the bf16x3 block GEMMs."""
+        self._refresh_stream()
         if self.shadow is not None:
             call("ader_lbf_shadow_refresh", self._pp["emb"], ptr(self.shadow), self.V, self.H, self._stream())
         self.refresh_weights()
 
     def refresh_weights(self):
+        self._refresh_stream()
         if self.wbf is not None:
             call("ader_wprep", ptr(self.theta), ptr(self._woffs), len(self._wnames), self.H, ptr(self.wbf), self._stream())
 
@@ -279,6 +284,7 @@ class Engine:
                 "global_step": self.global_step}
 
     def load_state_dict(self, sd):
+        self._refresh_stream()
         self.theta.copy_(sd["theta"])
         self.adam_m.copy_(sd["m"])
         self.adam_v.copy_(sd["v"])
@@ -294,17 +300,55 @@ class Engine:
             self._ws[name] = t
         return t
 
-    @staticmethod
-    def _stream():
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self):
+        """Raw handle of the stream the launchers enqueue on: torch's current stream, looked up once per public entry point
+        (_refresh_stream) and switched explicitly around the side-stream blocks -- torch.cuda.current_stream() costs ~10 us
+        and is needed ~30 times per step."""
+        return self._st_ptr if self._st_ptr is not None else torch.cuda.current_stream().cuda_stream
+
+    def _refresh_stream(self):
+        self._st_ptr = torch.cuda.current_stream().cuda_stream
+
+    class _OnStream:
+        """with torch.cuda.stream(s), keeping Engine._stream() in step."""
+
+        def __init__(self, eng, stream):
+            self.eng, self.stream, self.ctx = eng, stream, torch.cuda.stream(stream)
+
+        def __enter__(self):
+            self.ctx.__enter__()
+            self.prev, self.eng._st_ptr = self.eng._st_ptr, self.stream.cuda_stream
+
+        def __exit__(self, *exc):
+            self.eng._st_ptr = self.prev
+            return self.ctx.__exit__(*exc)
 
     def _sec(self, name):
         return self.timer.section(name) if self.timer is not None else _NULL
 
     def _dev_i32(self, x):
+        """int32 device tensor of a host array / tensor.  Host arrays go through a small ring of pinned staging buffers and an
+        asynchronous copy: a pageable .to(device) would block the host until the GPU has drained (one sync per step)."""
         if isinstance(x, torch.Tensor):
+            if x.device == self.device and x.dtype == torch.int32 and x.is_contiguous():
+                return x
             return x.to(device=self.device, dtype=torch.int32).contiguous()
-        return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32)).to(self.device)
+        a = np.ascontiguousarray(x, dtype=np.int32)
+        ring = self._pin.setdefault(a.shape, {"bufs": [], "evs": [], "i": 0})
+        if len(ring["bufs"]) < 8:
+            ring["bufs"].append(torch.empty(a.shape, dtype=torch.int32).pin_memory())
+            ring["evs"].append(None)
+            k = len(ring["bufs"]) - 1
+        else:
+            k = ring["i"] = (ring["i"] + 1) % 8
+            if ring["evs"][k] is not None:
+                ring["evs"][k].synchronize()          # the copy that last used this buffer (8 transfers ago) is long done
+        ring["bufs"][k].numpy()[...] = a
+        out = ring["bufs"][k].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["evs"][k] = ev
+        return out
 
     # ---------------------------------------------------------------------------------------- forward
     _ND = (0, 0, 1.0, 0)
@@ -354,6 +398,7 @@ class Engine:
         """seq int32 [B,T] (device).  Returns rep [B,H]; with save=True keeps activations for backward.
         The final block computes only position T-1 of its query / FFN path (Engine.prune_last): the representation is
         x[:, -1, :] (ADER.py:85) and rows interact only through K/V, so the other T-1 rows of that block are dead work."""
+        self._refresh_stream()
         if self.seq_fused:
             return self._forward_fused(seq, training, rate, step, save)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
@@ -532,6 +577,7 @@ class Engine:
         after (main.py:229); pos [n_train]; exemplars are either distilled (teacher [*,Np] + ex_trow [n_ex] row indices,
         ADER.py:132-137) or one-hot (ex_pos [n_ex], ADER.py:126-131).  Leaves the loss in self.loss (device scalar) and
         the gradient of every parameter in self.grad."""
+        self._refresh_stream()
         seq = self._dev_i32(seq)
         pos = self._dev_i32(pos)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
@@ -786,6 +832,7 @@ class Engine:
 
     def adam(self, lr):
         """tf.train.AdamOptimizer step on every variable (dense, incl. the whole table; ADER.py:96)."""
+        self._refresh_stream()
         with self._sec("adam"):
             call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, self._lr_t(lr),
                  self.beta1, self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
@@ -816,7 +863,7 @@ class Engine:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device, priority=-1)
         self._side.wait_stream(main)         # inputs ready; also orders reuse of last step's list memory after its reader
-        with torch.cuda.stream(self._side):
+        with Engine._OnStream(self, self._side):
             self._lists = self._sparse_lists(seq, lab, N)
         self._lists_seq = (seq, lab)         # keep the inputs alive until the side stream has consumed them
 
@@ -858,7 +905,7 @@ class Engine:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=self.device, priority=-1)
             self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
+            with Engine._OnStream(self, self._side):
                 small_update()
         with self._sec("logits_bwd_adam"):
             call("ader_lbf_bwd_adam_ex", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
@@ -1136,6 +1183,7 @@ class Engine:
     def train_step(self, seq, pos, max_item, lr, **kw):
         """One `sess.run(train_op)` (main.py:233-256): forward, loss, backward, [gradient exchange], Adam.
         Returns the loss as a 1-element device tensor (no host sync)."""
+        self._refresh_stream()
         if (self.dp_world > 1 and self.dp_mode == "catalog" and self.shadow is not None and self.seq_fused
                 and kw.get("teacher") is None and kw.get("ex_pos") is None):
             return self._train_step_catalog(seq, pos, max_item, lr, **kw)
@@ -1164,6 +1212,7 @@ class Engine:
     # ---------------------------------------------------------------------------------------- inference paths
     def encode(self, seq):
         """Eval-mode representation (is_training=False): rep [n,H] for any n (chunks of MAX_ROWS)."""
+        self._refresh_stream()
         self.sync_table()
         seq = self._dev_i32(seq)
         n = seq.shape[0]
@@ -1181,6 +1230,7 @@ class Engine:
 
     def logits_from_rep(self, rep, max_item, out=None):
         """Dense logits [n, N] = rep . E[1..N]^T  (ADER.py:92)."""
+        self._refresh_stream()
         self.sync_table()
         n, N = rep.shape[0], int(max_item)
         if out is None:
@@ -1198,10 +1248,12 @@ class Engine:
         return self.logits_from_rep(self.encode(seq), max_item)
 
     def teacher_logits(self, seq, max_item):
+        self._refresh_stream()
         return self.logits(seq, max_item)
 
     def rank_targets(self, seq, pos, max_item):
         """0-based rank of pos[b] among items 1..N for every row (Evaluator path, util.py:323-325) -> int32 numpy [n]."""
+        self._refresh_stream()
         self.sync_table()
         seq = self._dev_i32(seq)
         pos = self._dev_i32(pos)
@@ -1225,6 +1277,7 @@ class Engine:
     def herding_select(self, seq_rows, offs, quota, max_item):
         """Segmented herding over label groups (util.py:436-461).  seq_rows [n,T] candidates in group order, offs [G+1],
         quota [G] = min(m, n_g).  Returns (sel [n] local indices per group span, sel_cnt [G]) as numpy."""
+        self._refresh_stream()
         from .exemplar import herding_max_steps
         rep = self.encode(seq_rows)
         n, G = rep.shape[0], len(quota)
