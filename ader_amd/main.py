@@ -38,40 +38,35 @@ def str2bool(v):
     raise argparse.ArgumentTypeError('Boolean value expected.')
 
 
+# The reference's command line (main.py:76-107): (flag, default, type).  Booleans go through str2bool.
+_REFERENCE_FLAGS = (
+    ("dataset", "DIGINETICA", str), ("save_dir", "ADER", str), ("exemplar_size", 30000, int), ("lambda_", 0.8, float),
+    ("finetune", False, bool), ("dropout", False, bool), ("joint", False, bool), ("selection", "herding", str),
+    ("disable_distillation", False, bool), ("equal_exemplar", False, bool), ("fix_lambda", False, bool),
+    ("num_epochs", 100, int), ("batch_size", 256, int), ("test_batch", 64, int), ("device_num", 0, int), ("lr", 0.0005, float),
+    ("num_blocks", 2, int), ("num_heads", 1, int), ("stop", 5, int), ("random_seed", 0, int), ("hidden_units", 150, int),
+    ("maxlen", 50, int), ("dropout_rate", 0.3, float), ("l2_emb", 0.0, float),
+)
+# Flags of this build only: (flag, default, type, help / choices)
+_BUILD_FLAGS = (
+    ("logits_dtype", "f32", str, ("f32", "bf16")), ("max_periods", 0, int, None), ("data_root", None, str, None),
+    ("results_root", "results", str, None), ("save_ckpt", False, bool, None),
+    ("dist_backend", "nccl", str, "torch.distributed backend when WORLD_SIZE > 1"),
+    ("eval_batch", 1024, int, "rows per evaluation launch (results do not depend on it)"),
+)
+
+
 def build_parser():
     p = argparse.ArgumentParser()
-    p.add_argument('--dataset', default='DIGINETICA', type=str)
-    p.add_argument('--save_dir', default='ADER', type=str)
-    p.add_argument('--exemplar_size', default=30000, type=int)
-    p.add_argument('--lambda_', default=0.8, type=float)
-    p.add_argument('--finetune', default=False, type=str2bool)
-    p.add_argument('--dropout', default=False, type=str2bool)
-    p.add_argument('--joint', default=False, type=str2bool)
-    p.add_argument('--selection', default='herding', type=str)
-    p.add_argument('--disable_distillation', default=False, type=str2bool)
-    p.add_argument('--equal_exemplar', default=False, type=str2bool)
-    p.add_argument('--fix_lambda', default=False, type=str2bool)
-    p.add_argument('--num_epochs', default=100, type=int)
-    p.add_argument('--batch_size', default=256, type=int)
-    p.add_argument('--test_batch', default=64, type=int)
-    p.add_argument('--device_num', default=0, type=int)
-    p.add_argument('--lr', default=0.0005, type=float)
-    p.add_argument('--num_blocks', default=2, type=int)
-    p.add_argument('--num_heads', default=1, type=int)
-    p.add_argument('--stop', default=5, type=int)
-    p.add_argument('--random_seed', default=0, type=int)
-    p.add_argument('--hidden_units', default=150, type=int)
-    p.add_argument('--maxlen', default=50, type=int)
-    p.add_argument('--dropout_rate', default=0.3, type=float)
-    p.add_argument('--l2_emb', default=0.0, type=float)
-    # build-specific
-    p.add_argument('--logits_dtype', default='f32', choices=['f32', 'bf16'])
-    p.add_argument('--max_periods', default=0, type=int)
-    p.add_argument('--data_root', default=None, type=str)
-    p.add_argument('--results_root', default='results', type=str)
-    p.add_argument('--save_ckpt', default=False, type=str2bool)
-    p.add_argument('--dist_backend', default='nccl', type=str, help="torch.distributed backend when WORLD_SIZE > 1")
-    p.add_argument('--eval_batch', default=1024, type=int, help="rows per evaluation launch (results do not depend on it)")
+    for name, default, typ in _REFERENCE_FLAGS:
+        p.add_argument("--" + name, default=default, type=str2bool if typ is bool else typ)
+    for name, default, typ, extra in _BUILD_FLAGS:
+        kw = {"default": default, "type": str2bool if typ is bool else typ}
+        if isinstance(extra, tuple):
+            kw["choices"] = extra
+        elif extra:
+            kw["help"] = extra
+        p.add_argument("--" + name, **kw)
     return p
 
 
