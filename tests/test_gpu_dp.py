@@ -84,3 +84,63 @@ def test_two_ranks_match_single_process(logits, sharded):
     # same masks (dropout keyed by global row), same math; differences: summation order of the row reductions, Adam's
     # eps-scale sensitivity for ~zero gradients, and (second step) ReLU branch flips -- see test_gpu_parity
     assert np.mean(d < 5e-6) > 0.995 and d.max() < 2.5e-3
+
+
+# ---------------------------------------------------------------------------------------------- distilled steps under DP
+N_EX, NP = 24, 700
+
+
+def _kd_data():
+    rs = np.random.RandomState(9)
+    seq, pos = _data()
+    ex_seq = np.zeros((N_EX, T), dtype=np.int32)
+    for b in range(N_EX):
+        ln = rs.randint(1, T + 1)
+        ex_seq[b, T - ln:] = rs.randint(1, NP + 1, size=ln)
+    teacher = rs.standard_normal((40, NP)).astype(np.float32)
+    trow = rs.randint(0, 40, size=N_EX).astype(np.int32)
+    return seq, pos, ex_seq, teacher, trow
+
+
+def _kd_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ader_amd import dist as adist
+    seq, pos, ex_seq, teacher, trow = _kd_data()
+    eng = _engine("f32", rank, world)
+    dp = adist.DataParallel(eng, rank, world)
+    lo, hi = adist.shard_bounds(B, world, rank)
+    elo, ehi = adist.shard_bounds(N_EX, world, rank)
+    tch = torch.from_numpy(teacher).cuda()
+    for step in range(2):
+        dp.set_rows(lo, N)
+        eng.train_step(np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]), pos[lo:hi], N, 5e-4, rate=0.0, teacher=tch,
+                       ex_trow=trow[elo:ehi], lambda_=0.6, n_train_global=B, n_ex_global=N_EX)
+    torch.cuda.synchronize()
+    if rank == 1:
+        torch.save(eng.theta.cpu(), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_distilled_step_matches_single_process():
+    """ADER-mode step under data parallelism (main.py:223-256 with the rows of BOTH sub-batches sharded, losses scaled by the
+    global sub-batch sizes, dense gradient all-reduce): two ranks == one process on the whole batch.  Dropout off so the
+    exemplar rows' masks (keyed by the local row numbering) do not enter."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "theta.pt")
+        mp.spawn(_kd_worker, args=(2, port, out), nprocs=2, join=True)
+        got = torch.load(out).numpy()
+    seq, pos, ex_seq, teacher, trow = _kd_data()
+    eng = _engine("f32")
+    tch = torch.from_numpy(teacher).cuda()
+    for step in range(2):
+        eng.train_step(np.concatenate([seq, ex_seq]), pos, N, 5e-4, rate=0.0, teacher=tch, ex_trow=trow, lambda_=0.6)
+    torch.cuda.synchronize()
+    ref = eng.theta.cpu().numpy()
+    d = np.abs(got - ref)
+    assert np.mean(d < 5e-6) > 0.995 and d.max() < 2.5e-3
