@@ -63,12 +63,13 @@ __device__ __forceinline__ void ln_bwd_rows(float* Xf, const Out& ox, const Out&
         const float mean = bload(omean, (uint32_t)t * 4u);
         float sd = bload(ostd, (uint32_t)t * 4u);
         if (!valid) sd = 1.0f;
+        const float rsd = 1.0f / sd;                        // one reciprocal per row instead of 20 divisions
         float xh[10], dxh[10], s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int c = sub + 16 * i;
             const float g = (valid && c < H) ? Xf[t * XS + c] : 0.0f;
-            xh[i] = (valid && c < H) ? (xv[i] - mean) / sd : 0.0f;
+            xh[i] = (valid && c < H) ? (xv[i] - mean) * rsd : 0.0f;
             dxh[i] = g * gam[i];
             s1 += dxh[i];
             s2 += dxh[i] * xh[i];
@@ -80,7 +81,7 @@ __device__ __forceinline__ void ln_bwd_rows(float* Xf, const Out& ox, const Out&
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int c = sub + 16 * i;
-            const float o = (valid && c < H) ? (dxh[i] - s1 - xh[i] * s2) / sd : 0.0f;
+            const float o = (valid && c < H) ? (dxh[i] - s1 - xh[i] * s2) * rsd : 0.0f;
             Xf[t * XS + c] = o;
             if (STORE) bstore(odx, (c < H) ? bo + 64u * i : OOB, o);
         }

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                     }
                     q = row16_sum(q);
                     const float sd = sqrtf(q / (float)H + LN_EPS);
+                    const float rsd = 1.0f / sd;
                     float ys = 0.0f;
                     bf16* T0 = R0 + t * LDR + sub;
                     bf16* T1 = R1 + t * LDR + sub;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
 #pragma unroll
                     for (int i = 0; i < 10; ++i) {
                         const int c = sub + 16 * i;
-                        const float y = (valid && c < H) ? g1[i] * ((x[i] - mean) / sd) + be1[i] : 0.0f;
+                        const float y = (valid && c < H) ? g1[i] * ((x[i] - mean) * rsd) + be1[i] : 0.0f;
                         ys += y;
                         put_split(T0, T0 + TR * LDR, 16 * i, x[i]);
                         put_split(T1, T1 + TR * LDR, 16 * i, y);
@@ -353,12 +354,13 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                     }
                     q = row16_sum(q);
                     const float sd = sqrtf(q / (float)H + LN_EPS);
+                    const float rsd = 1.0f / sd;
                     bf16* T0 = R0 + t * LDR + sub;
                     const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
 #pragma unroll
                     for (int i = 0; i < 10; ++i) {
                         const int c = sub + 16 * i;
-                        const float y = (valid && c < H) ? g2[i] * ((x[i] - mean) / sd) + be2[i] : 0.0f;
+                        const float y = (valid && c < H) ? g2[i] * ((x[i] - mean) * rsd) + be2[i] : 0.0f;
                         put_split(T0, T0 + TR * LDR, 16 * i, y);
                         Xf[t * XS + c] = y;
                         bstore(oy, (c < H) ? bo + 64u * i : OOB, y);

@@ -293,8 +293,10 @@ def test_session_tiled_step_equals_per_op_step(shape, prune):
     assert abs(out[0][0] - out[1][0]) < 2e-5 * max(1.0, abs(out[1][0]))
     assert nerr(out[0][2], out[1][2], floor=1e-6) < 2e-3        # per-position input-gradient rows
     for k in out[0][1]:
-        # differences: fp32 summation order, ReLU branch flips of ~zero pre-activations (cf. the x3 oracle test: 6e-4)
-        assert nerr(out[0][1][k], out[1][1][k], floor=1e-4) < 6e-4, (k, nerr(out[0][1][k], out[1][1][k], floor=1e-4))
+        # differences: fp32 summation order, ReLU branch flips of ~zero pre-activations (cf. the x3 oracle test: 6e-4).
+        # The key bias has an exactly-zero true gradient (softmax is shift invariant): both paths hold ~1e-8 rounding noise
+        fl = 1e-3 if k.endswith(".bk") else 1e-4
+        assert nerr(out[0][1][k], out[1][1][k], floor=fl) < 6e-4, (k, nerr(out[0][1][k], out[1][1][k], floor=fl))
 
 
 @pytest.mark.parametrize("N,shards", [(4321, 2), (4321, 3), (650, 8)])
