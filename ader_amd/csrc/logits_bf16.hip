@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
     const int fs = ADAM ? H : FLD;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#define AV 3
+#define AV 6
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         // ADAM: the first round of theta/m/v vectors of this half-tile is requested BEFORE the dE staging and the sparse
