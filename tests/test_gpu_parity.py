@@ -440,6 +440,31 @@ def test_split_kd_step_matches_all_f32_kd_step():
     assert np.abs(ta - tb).max() < 1.1e-3                 # one Adam step moves a parameter by at most lr
 
 
+def test_fused_train_step_is_bitwise_reproducible():
+    """Determinism: the default training path (one-launch forward, session-tiled backward, batched weight
+    gradients, id-sorted sparse lists, fused table update on two streams) has no float atomics and fixed-order reductions:
+    two engines stepping the same batches from the same state end bit-identical."""
+    item_num, T, H, L, heads, B, N = BF16_CFGS[1]
+    rs = np.random.RandomState(77)
+    batches = []
+    for _ in range(3):
+        seq = _seqs(rs, B, T, N)
+        seq[1, -4:] = seq[0, -1]                       # repeated ids: several sparse rows per table row
+        pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+        pos[5] = pos[6]
+        batches.append((seq, pos))
+    finals = []
+    for _ in range(2):
+        eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
+        for seq, pos in batches:
+            eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+        torch.cuda.synchronize()
+        finals.append((eng.theta.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.shadow.clone(), float(eng.loss.item())))
+    for x, y in zip(finals[0][:4], finals[1][:4]):
+        assert torch.equal(x, y)
+    assert finals[0][4] == finals[1][4]
+
+
 def test_adam_keeps_bf16_shadow_in_sync():
     eng = _engine(301, 20, 64, 1, 2, logits_dtype="bf16")          # odd row count: float4 groups straddle table rows
     g = torch.Generator().manual_seed(9)
