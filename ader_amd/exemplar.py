@@ -51,6 +51,28 @@ class ExemplarStore:
         """Sessions in the reference's stored form: non-zero inputs followed by the label (util.py:433)."""
         return [r[r != 0].tolist() for r in np.asarray(self.rows)]
 
+    # The reference keeps the exemplars in memory only (main.py:312): a crash loses them.  Here they can be written next to
+    # the period's checkpoint and read back (rows + teacher logits + the catalog size they were computed for).
+    def save(self, path):
+        import torch
+        lg = self.logits.detach().cpu() if hasattr(self.logits, "detach") else torch.as_tensor(np.asarray(self.logits))
+        torch.save({"rows": np.asarray(self.rows), "logits": lg, "max_item": int(self.max_item)}, path)
+        return path
+
+    @classmethod
+    def load(cls, path, device=None):
+        import torch
+        d = torch.load(path, weights_only=False)
+        lg = d["logits"].to(device) if device is not None else d["logits"]
+        return cls(d["rows"], lg, d["max_item"])
+
+    def by_label(self):
+        """{item: [[session, logits_row], ...]} -- the reference's `fast_exemplar` view (util.py:433), rows in store order."""
+        out = defaultdict(list)
+        for i, r in enumerate(np.asarray(self.rows)):
+            out[int(r[-1])].append([r[r != 0].tolist(), self.logits[i]])
+        return out
+
 
 class ExemplarGenerator:
     """Same constructor arguments as the reference (util.py:366-374)."""

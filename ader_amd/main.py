@@ -220,6 +220,10 @@ def run(args, log=print):
                 logs.write(info + '\n')
                 fast_exemplar = exemplar.exemplars
                 store = exemplar.store
+                if args.save_ckpt and rank == 0:                         # (the reference keeps exemplars in memory only)
+                    d = os.path.join(out_dir, 'model', 'period%d' % period)
+                    os.makedirs(d, exist_ok=True)
+                    store.save(os.path.join(d, 'exemplars.pt'))
                 del exemplar
             item_num_prev = max_item
         logs.flush()

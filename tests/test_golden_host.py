@@ -137,3 +137,18 @@ def test_dataloader_periods(golden_dir, dataset):
         assert _crc(te) == row["test_crc"]
         assert info == row["test_info"]
         assert dl.max_item() == row["max_item"]
+
+
+def test_exemplar_store_round_trip(tmp_path):
+    """Exemplars written next to a checkpoint come back identical, and the {item: [[session, logits]]} view (reference
+    util.py:433: non-zero inputs followed by the label) is rebuilt from the rows."""
+    import torch
+    from ader_amd.exemplar import ExemplarStore
+    rows = np.array([[0, 0, 5, 9, 3], [0, 7, 7, 2, 9], [1, 2, 3, 4, 3]], dtype=np.int32)      # [inputs(4) | label]
+    logits = torch.arange(3 * 6, dtype=torch.float32).view(3, 6)
+    st = ExemplarStore(rows, logits, 6)
+    back = ExemplarStore.load(st.save(str(tmp_path / "exemplars.pt")))
+    assert np.array_equal(back.rows, rows) and torch.equal(back.logits, logits) and back.max_item == 6 and len(back) == 3
+    view = back.by_label()
+    assert sorted(view) == [3, 9] and [e[0] for e in view[3]] == [[5, 9, 3], [1, 2, 3, 4, 3]] and view[9][0][0] == [7, 7, 2, 9]
+    assert torch.equal(view[9][0][1], logits[1])
