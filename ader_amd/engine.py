@@ -214,10 +214,10 @@ class Engine:
         # streams only those in the logit kernels and never receives the other ranks' rows except the few its inputs need
         # (_train_step_catalog); "replicated" = every rank holds the whole table (the two schemes of dist.py)
         self.dp_mode = "replicated"
-        # catalog mode: only owned rows travel (one host sync per step + ~20 small launches of bookkeeping) instead of a dense
-        # 15 MB block per peer; pays off once the peers' blocks add up (default: 4 ranks or more; ADER_DP_PACK=0/1 overrides)
-        _p = os.environ.get("ADER_DP_PACK")
-        self.dp_pack = (self.dp_world >= 4) if _p is None else (_p == "1")
+        # catalog mode: dp_pack = only owned rows travel (uneven all-to-all; costs one host sync per step -- the host cannot run
+        # ahead of the GPU any more -- and ~20 small bookkeeping launches) instead of a dense 15 MB block per peer.  Off by
+        # default: the dense exchange keeps the step free of host synchronisation (ADER_DP_PACK=1 turns it on).
+        self.dp_pack = os.environ.get("ADER_DP_PACK", "0") == "1"
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self._table_stale = False
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
