@@ -1,0 +1,27 @@
+"""Host enqueue time of one train step (no synchronisation inside the loop) vs its GPU time (dev tool)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ader_amd.engine import Engine
+from bench import synth_batch
+N, B, T = 1_000_000, 512, 50
+dev = torch.device("cuda", 0)
+eng = Engine(N, maxlen=T, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device=dev, logits_dtype="bf16")
+batches = [synth_batch(B, T, N, 1000 * s, dev) for s in range(4)]
+for i in range(8):
+    eng.train_step(*batches[i % 4], N, 5e-4, rate=0.3)
+torch.cuda.synchronize()
+for K in (4, 8):
+    t0 = time.perf_counter()
+    for i in range(K):
+        eng.train_step(*batches[i % 4], N, 5e-4, rate=0.3)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("K=%d  host enqueue %.3f ms/step   total %.3f ms/step" % (K, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3))
+import cProfile, pstats, io
+pr = cProfile.Profile(); pr.enable()
+for i in range(8):
+    eng.train_step(*batches[i % 4], N, 5e-4, rate=0.3)
+pr.disable(); torch.cuda.synchronize()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14); print(s.getvalue()[:3500])
