@@ -74,9 +74,21 @@ def cpu_baseline(N, B, T, H, L, heads, rate, lr):
     t0 = time.perf_counter()
     R.train_step(params, opt, seq, pos, N, L, heads, lr, training=True, rate=rate, seed=0, step=1)
     dt = time.perf_counter() - t0
-    return {"value": Bs / dt, "unit": "sessions/s", "cores": cores, "kind": "port",
-            "sample": "1 step of B=%d rows x T=%d at the full N=%d catalog (%.1f s), torch-CPU float32 restatement, %d threads"
-                      % (Bs, T, N, dt, cores)}
+    out = {"value": Bs / dt, "unit": "sessions/s", "cores": cores, "kind": "port",
+           "sample": "1 step of B=%d rows x T=%d at the full N=%d catalog (%.1f s), torch-CPU float32 restatement, %d threads"
+                     % (Bs, T, N, dt, cores)}
+    # single-thread figure on a smaller sample of the same workload: 16 rows at the full catalog
+    try:
+        torch.set_num_threads(1)
+        B1 = 16
+        t0 = time.perf_counter()
+        R.train_step(params, opt, seq[:B1], pos[:B1], N, L, heads, lr, training=True, rate=rate, seed=0, step=2)
+        dt1 = time.perf_counter() - t0
+        out["value_1thread"] = B1 / dt1
+        out["sample_1thread"] = "1 step of B=%d rows at N=%d (%.1f s), 1 thread" % (B1, N, dt1)
+    finally:
+        torch.set_num_threads(cores)
+    return out
 
 
 def main():
