@@ -215,9 +215,11 @@ class Engine:
         # (_train_step_catalog); "replicated" = every rank holds the whole table (the two schemes of dist.py)
         self.dp_mode = "replicated"
         # catalog mode: dp_pack = only owned rows travel (uneven all-to-all; costs one host sync per step -- the host cannot run
-        # ahead of the GPU any more -- and ~20 small bookkeeping launches) instead of a dense 15 MB block per peer.  Off by
-        # default: the dense exchange keeps the step free of host synchronisation (ADER_DP_PACK=1 turns it on).
-        self.dp_pack = os.environ.get("ADER_DP_PACK", "0") == "1"
+        # ahead of the GPU any more -- and ~20 small bookkeeping launches) instead of a dense 15 MB block per peer.  Default:
+        # from 8 ranks on, where the dense blocks add up to ~210 MB received per rank and step against ~26 MB packed; below
+        # that the dense exchange keeps the step free of host synchronisation (ADER_DP_PACK=0/1 overrides).
+        _p = os.environ.get("ADER_DP_PACK")
+        self.dp_pack = (self.dp_world >= 8) if _p is None else (_p == "1")
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self._table_stale = False
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
