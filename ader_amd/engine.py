@@ -1075,7 +1075,13 @@ class Engine:
                 table = self.theta[:self.V_alloc * H].view(self.V_alloc, H)
                 # rows I own, ordered by (destination, position): the gathered ids are already laid out [destination][position],
                 # so this is a plain compaction of the owned entries
-                idx_send = torch.nonzero(own.reshape(-1) == r).view(-1)
+                # (prefix sum + scatter with a trash slot: K is known from the counts, so no second host sync as nonzero() needs)
+                K = sum(C_all[r])
+                mine_f = own.reshape(-1) == r
+                slot_f = torch.where(mine_f, torch.cumsum(mine_f, 0) - 1, torch.full_like(own.reshape(-1), K))
+                idx_send = torch.empty(K + 1, dtype=torch.int64, device=self.device)
+                idx_send.scatter_(0, slot_f, torch.arange(W * n_all, device=self.device))
+                idx_send = idx_send[:K]
                 rows = table[ids_g.reshape(-1)[idx_send].long()]
                 got = self._a2a_rows(rows, C_all)                              # ordered by owner, then by my position index
                 perm = self._group_order(own[r] + 1, W + 1)                    # my positions: padding first, then by owner
