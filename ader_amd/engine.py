@@ -182,7 +182,7 @@ class Engine:
         self.seq_fused = (self.gemm_x3 and num_heads == 1 and maxlen <= 64 and num_blocks <= _lib.SEQ_MAXL)
         self.lists_side_stream = True      # build the sparse lists under the block kernels
         self.late_side_stream = True       # small-parameter gradients / Adam run beside the (HBM-bound) fused table update
-        self._late, self._late_on = [], False
+        self._late, self._late_on, self._late_force = [], False, False
         self._st_ptr = None
         self._pin = {}
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
@@ -705,7 +705,7 @@ class Engine:
                  ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
         last_map = (T, T - 1)
         fused_emb = False
-        self._late_on = bool(defer and self.dp_world == 1 and self.seq_fused and self.late_side_stream)
+        self._late_on = bool(defer and (self.dp_world == 1 or self._late_force) and self.seq_fused and self.late_side_stream)
         for l in reversed(range(L)):
             p = "b%d." % l
             S = A[l]
@@ -1137,7 +1137,21 @@ class Engine:
             pr = self._a2a(part.view(W, Bp, 152))                              # partials of MY rows from every rank
             call("ader_lbf_merge_parts", ptr(pr), W, Bp, B, H, ptr(e_lab), ptr(rep_bf), ptr(wrow), ptr(lse), ptr(off), ptr(rowloss),
                  ptr(self.loss), ptr(drep), st)
-        dx = self._blocks_backward(seq, drep, True, None)
+        self._late_force = True            # weight-gradient products and small reductions are queued ...
+        try:
+            dx = self._blocks_backward(seq, drep, True, None)
+        finally:
+            self._late_force = False
+        main = torch.cuda.current_stream()
+        if self._late or self._atb_q:      # ... and run on the side stream under the row exchange below (the CUs are idle there)
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.device, priority=-1)
+            self._side.wait_stream(main)
+            with Engine._OnStream(self, self._side):
+                for name, args in self._late:
+                    call(name, *args, self._stream())
+                self._late = []
+                self._atb_flush()
         lr_t = self._lr_t(lr)
         span = self.layout["pos"][0]
         with self._sec("grad_exchange"):
@@ -1148,6 +1162,7 @@ class Engine:
                 g_g = self._ag(dx)                                             # [W,B*T,H]
             off_g = meta_g[:, 0].contiguous().view(torch.float32)
             w_g = meta_g[:, 1].contiguous().view(torch.float32)
+            main.wait_stream(self._side) if getattr(self, "_side", None) is not None else None   # small gradients complete
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
         ids, order, sp_start, tids, torder, tg_start = self._lists_wait()
