@@ -142,6 +142,7 @@ class Sampler:
     # -- internal
     def _repack(self):
         self._rows, self._valid = pack_rows(self.prepared_data, self.maxlen)
+        self._rows_dev = None
         self._logit_mat = None
         self.data_indices = list(range(len(self.prepared_data)))
         random.shuffle(self.data_indices)
@@ -180,18 +181,32 @@ class Sampler:
         self._repack()
         return (valid_data, train_data) if return_train else valid_data
 
+    def to_device(self, device):
+        """GPU-resident feeder: the packed [n, maxlen+1] rows live on the device; a batch is then an index_select
+        by the host-shuffled indices (same `random` stream as the reference) -- 2 KB of indices cross PCIe instead of the rows.
+        Call again after split_data / add_exemplar (they repack)."""
+        import torch
+        self._rows_dev = torch.from_numpy(self._rows).to(device)
+        return self
+
+    def _rows_of(self, idx):
+        if getattr(self, "_rows_dev", None) is None:
+            rows = self._rows[idx]
+            return np.ascontiguousarray(rows[:, :self.maxlen]), np.ascontiguousarray(rows[:, self.maxlen])
+        import torch
+        rows = self._rows_dev.index_select(0, torch.from_numpy(idx).to(self._rows_dev.device, non_blocking=True))
+        return rows[:, :self.maxlen].contiguous(), rows[:, self.maxlen].contiguous()
+
     def next_batch(self):
-        """Fast path: (seq [b, maxlen] int32, pos [b] int32) as contiguous arrays."""
-        idx = self._next_indices()
-        rows = self._rows[idx]
-        return np.ascontiguousarray(rows[:, :self.maxlen]), np.ascontiguousarray(rows[:, self.maxlen])
+        """Fast path: (seq [b, maxlen] int32, pos [b] int32), contiguous; numpy arrays, or device tensors after to_device()."""
+        return self._rows_of(self._next_indices())
 
     def next_exemplar_batch(self):
         """Fast path: (seq, pos, row indices into the exemplar list) -- teacher logits stay wherever
         the caller keeps them (e.g. one [E, Np] device tensor) and are gathered by index."""
         idx = self._next_indices()
-        rows = self._rows[idx]
-        return np.ascontiguousarray(rows[:, :self.maxlen]), np.ascontiguousarray(rows[:, self.maxlen]), idx
+        seq, pos = self._rows_of(idx)
+        return seq, pos, idx
 
     def sampler(self):
         seq, pos = self.next_batch()

@@ -52,6 +52,7 @@ _BUILD_FLAGS = (
     ("logits_dtype", "f32", str, ("f32", "bf16")), ("max_periods", 0, int, None), ("data_root", None, str, None),
     ("results_root", "results", str, None), ("save_ckpt", False, bool, None),
     ("dist_backend", "nccl", str, "torch.distributed backend when WORLD_SIZE > 1"),
+    ("device_feed", True, bool, "keep the packed training rows on the GPU and gather batches there"),
     ("eval_batch", 1024, int, "rows per evaluation launch (results do not depend on it)"),
 )
 
@@ -128,6 +129,8 @@ def run(args, log=print):
                 train_sess.extend(pre)
         train_sampler = Sampler(train_sess, args.maxlen, args.batch_size)
         valid_subseq, train_subseq = train_sampler.split_data(valid_portion=0.1, return_train=True)
+        if args.device_feed:
+            train_sampler.to_device(model.engine.device)
         batch_num = train_sampler.batch_num()
         test_sess, info = dataloader.evaluate_loader(period)
         logs.write(info + '\n')
@@ -140,6 +143,8 @@ def run(args, log=print):
             exemplar_batch = int(exemplar_size / batch_num)             # main.py:187
             exemplar_sampler = Sampler([], args.maxlen, exemplar_batch)
             exemplar_sampler.add_exemplar(exemplar_data_logits)
+            if args.device_feed:
+                exemplar_sampler.to_device(model.engine.device)
             if args.fix_lambda:
                 lambda_ = args.lambda_
             else:                                                        # main.py:200
@@ -167,7 +172,11 @@ def run(args, log=print):
                         elo, ehi = adist.shard_bounds(len(ex_seq), world, rank)  # ... and exemplar rows (main.py:229 order kept)
                         if world > 1:
                             kw.update(n_ex_global=len(ex_seq))
-                        seq_l = np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]) if ehi > elo else seq[lo:hi]
+                        if ehi > elo:
+                            cat = torch.cat if isinstance(seq, torch.Tensor) else np.concatenate
+                            seq_l = cat([seq[lo:hi], ex_seq[elo:ehi]])
+                        else:
+                            seq_l = seq[lo:hi]
                         if args.disable_distillation:
                             model.train_step(seq_l, pos[lo:hi], max_item, args.lr, args.dropout_rate, ex_pos=ex_pos[elo:ehi], **kw)
                         else:

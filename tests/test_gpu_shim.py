@@ -131,3 +131,27 @@ def test_saver_round_trip_restores_parameters_and_optimizer_state():
         m.engine.train_step(seq, pos, N, 5e-4, rate=0.3)
         d = (m.engine.theta - first).abs().cpu().numpy()
         assert np.mean(d < 2e-6) > 0.999 and d.max() < 1.1e-3
+
+
+def test_device_feeder_yields_the_host_feeder_batches():
+    """Sampler.to_device (GPU-resident feeder): same shuffled index stream, batches gathered on the device."""
+    import random
+    from ader_amd.data import Sampler
+    rs = np.random.RandomState(4)
+    sessions = [rs.randint(1, 90, size=rs.randint(2, 30)).tolist() for _ in range(57)]
+    out = []
+    for dev in (False, True):
+        random.seed(11)
+        smp = Sampler(sessions, T, 16)
+        if dev:
+            smp.to_device(torch.device("cuda"))
+        got = []
+        for _ in range(2 * smp.batch_num() + 1):             # across a reshuffle
+            seq, pos = smp.next_batch()
+            if dev:
+                assert seq.is_cuda and seq.dtype == torch.int32 and seq.is_contiguous() and pos.is_contiguous()
+                seq, pos = seq.cpu().numpy(), pos.cpu().numpy()
+            got.append((seq.copy(), pos.copy()))
+        out.append(got)
+    for (sa, pa), (sb, pb) in zip(*out):
+        assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
