@@ -116,7 +116,8 @@ __global__ __launch_bounds__(512) void k_logits_tile(LogitArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int it = item0 + r;
-                        if (it < nc) cnt += (acc[j][r] > tl) || (acc[j][r] == tl && it < tgt);
+                        // the target never counts itself, even if k_target_logit's rounding ever differed from the tile's
+                        if (it < nc && it != tgt) cnt += (acc[j][r] > tl) || (acc[j][r] == tl && it < tgt);
                     }
                     cnt += __shfl_xor(cnt, 16, 64);
                     cnt += __shfl_xor(cnt, 32, 64);
@@ -180,12 +181,13 @@ __global__ __launch_bounds__(256) void k_build_rowinfo(const int* __restrict__ p
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp) return;
     int l = 0, nc = 0, tr = -1; float w = 0.0f;
-    if (i < n_train) { l = pos[i]; nc = N; w = w_train; }
+    // A label / teacher row of 0 / -1 marks a PADDING row (data-parallel shards are padded to equal row counts): weight 0,
+    // so it adds nothing to the loss or to any gradient.  Real labels are item ids >= 1 (util.py:161-171).
+    if (i < n_train) { l = pos[i]; nc = N; w = (l > 0) ? w_train : 0.0f; }
     else if (i < n_train + n_ex) {
         const int e = i - n_train;
-        w = w_ex;
-        if (ex_trow) { nc = Np; tr = ex_trow[e]; }
-        else { nc = N; l = ex_pos[e]; }
+        if (ex_trow) { nc = Np; tr = ex_trow[e]; w = (tr >= 0) ? w_ex : 0.0f; if (tr < 0) tr = 0; }
+        else { nc = N; l = ex_pos[e]; w = (l > 0) ? w_ex : 0.0f; }
     }
     lab[i] = l; ncol[i] = nc; wrow[i] = w; trow[i] = tr;
 }

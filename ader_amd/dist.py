@@ -51,6 +51,26 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_rows(x, world, rank, fill=0):
+    """Rank `rank`'s slice of the rows of x (numpy array or torch tensor, first dimension = rows), padded with `fill` to
+    ceil(n / world) rows: every rank of a step holds the SAME number of rows (>= 1 when n >= 1), so gathered tensors have equal
+    shapes on every rank and no rank skips a collective.  Padding rows are id-0 sessions with label 0 (ex_trow -1): the loss
+    kernels give them weight 0 (csrc/logits.hip:k_build_rowinfo)."""
+    n = len(x)
+    lo, hi = shard_bounds(n, world, rank)
+    per = -(-n // world)
+    part = x[lo:hi]
+    pad = per - (hi - lo)
+    if pad <= 0:
+        return part
+    if isinstance(x, torch.Tensor):
+        filler = torch.full((pad,) + tuple(x.shape[1:]), fill, dtype=x.dtype, device=x.device)
+        return torch.cat([part, filler])
+    import numpy as np
+    x = np.asarray(x)
+    return np.concatenate([x[lo:hi], np.full((pad,) + x.shape[1:], fill, dtype=x.dtype)])
+
+
 def bucket_ranges(total, table_elems, bucket_elems):
     """[(lo, hi)] covering [0, total): the used table rows in large buckets, then everything after the table."""
     out, lo = [], 0

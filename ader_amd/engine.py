@@ -222,6 +222,7 @@ class Engine:
         self.dp_pack = (self.dp_world >= 8) if _p is None else (_p == "1")
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self._table_stale = False
+        self._mv_sharded = False   # dp: Adam m/v of the table are current only for the rank's own rows (see _gather_if_sharded)
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
         self._gp = {k: self.grad.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -279,19 +280,51 @@ class Engine:
     def export_params(self):
         return {k: self.param(k).detach().cpu().clone() for k in self.layout}
 
-    def state_dict(self):
+    def _gather_if_sharded(self):
+        """Data-parallel sharded / catalog steps update Adam m/v (and, in catalog mode, theta) of the rank's OWN table rows only.
+        Before anything that needs the whole optimiser state on every rank -- a checkpoint, or a dense Adam step (distilled
+        periods) -- the shards are all-gathered.  A collective: every rank reaches these points together (state_dict / adam)."""
+        if self.dp_world > 1 and self._mv_sharded:
+            self.gather_table_state()
+            self._mv_sharded = False
+
+    def state_dict(self, to_cpu=False):
+        """Per-variable tensors of theta / Adam m / Adam v (the reference's Saver stores per-variable tensors too, main.py:209):
+        the item table is trimmed to its item_num+1 real rows, so a state written with W ranks loads with any other W.
+        Tensors stay on the device unless `to_cpu` (Saver.save)."""
         self.sync_table()
-        return {"theta": self.theta.detach().cpu().clone(), "m": self.adam_m.detach().cpu().clone(),
-                "v": self.adam_v.detach().cpu().clone(), "b1p": float(self.b1p), "b2p": float(self.b2p),
-                "global_step": self.global_step}
+        self._gather_if_sharded()
+
+        def pack(buf):
+            out = {}
+            for k in self.layout:
+                t = self.view(buf, k).detach().clone()
+                out[k] = t.cpu() if to_cpu else t
+            return out
+
+        return {"format": 2, "theta": pack(self.theta), "m": pack(self.adam_m), "v": pack(self.adam_v),
+                "b1p": float(self.b1p), "b2p": float(self.b2p), "global_step": self.global_step}
 
     def load_state_dict(self, sd):
         self._refresh_stream()
-        self.theta.copy_(sd["theta"])
-        self.adam_m.copy_(sd["m"])
-        self.adam_v.copy_(sd["v"])
+        if isinstance(sd["theta"], dict):
+            for buf, key in ((self.theta, "theta"), (self.adam_m, "m"), (self.adam_v, "v")):
+                missing = set(self.layout) - set(sd[key])
+                if missing:
+                    raise KeyError("state_dict[%r] lacks %s" % (key, sorted(missing)))
+                for k in self.layout:
+                    dst, src = self.view(buf, k), sd[key][k]
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise ValueError("state_dict[%r][%r]: shape %s, expected %s" % (key, k, tuple(src.shape), tuple(dst.shape)))
+                    dst.copy_(src)
+        else:       # flat buffers of an earlier build (valid only for the same number of ranks)
+            self.theta.copy_(sd["theta"])
+            self.adam_m.copy_(sd["m"])
+            self.adam_v.copy_(sd["v"])
         self.b1p, self.b2p = np.float32(sd["b1p"]), np.float32(sd["b2p"])
         self.global_step = int(sd["global_step"])
+        self._mv_sharded = False
+        self._table_stale = False
         self.refresh_shadow()
 
     # ---------------------------------------------------------------------------------------- workspaces
@@ -835,6 +868,7 @@ class Engine:
     def adam(self, lr):
         """tf.train.AdamOptimizer step on every variable (dense, incl. the whole table; ADER.py:96)."""
         self._refresh_stream()
+        self._gather_if_sharded()
         with self._sec("adam"):
             call("ader_adam_step", ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grad), self.P, self._lr_t(lr),
                  self.beta1, self.beta2, self.eps, ptr(self.shadow), self.V * self.H, self.H, self._stream())
@@ -967,6 +1001,7 @@ class Engine:
                  self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
                  self.eps, None, 0, H, st)
         self._deferred = None
+        self._mv_sharded = True
         self._advance_adam()
 
     # ---------------------------------------------------------------------------------------- catalog-sharded data parallelism
@@ -1120,7 +1155,7 @@ class Engine:
         meta = self.buf("cs_meta", (3, Bp), torch.int32)                       # rows: off (f32 bits), wrow (f32 bits), label
         off, wrow, lab = meta[0].view(torch.float32), meta[1].view(torch.float32), meta[2]
         wrow.zero_()
-        wrow[:B] = w_row
+        wrow[:B] = (pos > 0).to(torch.float32) * w_row          # label 0 = padding row of an equal-size shard: weight 0
         lab.zero_()
         lab[:B] = pos
         drep = self.buf("drep", (B, H))
@@ -1176,6 +1211,7 @@ class Engine:
             call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
                  self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
                  self.eps, None, 0, H, st)
+        self._mv_sharded = True
         self._advance_adam()
         return self.loss
 

@@ -56,15 +56,16 @@ class ExemplarStore:
     def save(self, path):
         import torch
         lg = self.logits.detach().cpu() if hasattr(self.logits, "detach") else torch.as_tensor(np.asarray(self.logits))
-        torch.save({"rows": np.asarray(self.rows), "logits": lg, "max_item": int(self.max_item)}, path)
+        rows = torch.as_tensor(np.ascontiguousarray(np.asarray(self.rows), dtype=np.int32))
+        torch.save({"rows": rows, "logits": lg, "max_item": int(self.max_item)}, path)
         return path
 
     @classmethod
     def load(cls, path, device=None):
         import torch
-        d = torch.load(path, weights_only=False)
+        d = torch.load(path, weights_only=True)        # tensors and plain numbers only: nothing is unpickled
         lg = d["logits"].to(device) if device is not None else d["logits"]
-        return cls(d["rows"], lg, d["max_item"])
+        return cls(d["rows"].numpy(), lg, int(d["max_item"]))
 
     def by_label(self):
         """{item: [[session, logits_row], ...]} -- the reference's `fast_exemplar` view (util.py:433), rows in store order."""

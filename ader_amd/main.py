@@ -163,27 +163,34 @@ def run(args, log=print):
                 for _ in range(batch_num):
                     seq, pos = train_sampler.next_batch()
                     kw = {}
-                    lo, hi = adist.shard_bounds(len(pos), world, rank)       # this rank's train rows
                     if world > 1:
+                        # this rank's train rows, padded to ceil(n / W) rows with id-0 sessions of label 0 (weight 0 in the loss):
+                        # every rank issues collectives of identical sizes, and no rank ever has an empty batch
+                        lo, _ = adist.shard_bounds(len(pos), world, rank)
+                        seq_t, pos_t = adist.shard_rows(seq, world, rank), adist.shard_rows(pos, world, rank)
                         kw.update(n_train_global=len(pos))
                         dp.set_rows(lo, max_item)
+                    else:
+                        seq_t, pos_t = seq, pos
                     if use_ex:
                         ex_seq, ex_pos, idx = exemplar_sampler.next_exemplar_batch()
-                        elo, ehi = adist.shard_bounds(len(ex_seq), world, rank)  # ... and exemplar rows (main.py:229 order kept)
-                        if world > 1:
+                        idx = np.asarray(idx, dtype=np.int32)
+                        if world > 1:                                            # ... and exemplar rows (main.py:229 order kept)
                             kw.update(n_ex_global=len(ex_seq))
-                        if ehi > elo:
-                            cat = torch.cat if isinstance(seq, torch.Tensor) else np.concatenate
-                            seq_l = cat([seq[lo:hi], ex_seq[elo:ehi]])
+                            ex_seq, ex_pos = adist.shard_rows(ex_seq, world, rank), adist.shard_rows(ex_pos, world, rank)
+                            idx = adist.shard_rows(idx, world, rank, fill=-1)
+                        if len(ex_seq):
+                            cat = torch.cat if isinstance(seq_t, torch.Tensor) else np.concatenate
+                            seq_l = cat([seq_t, ex_seq])
                         else:
-                            seq_l = seq[lo:hi]
+                            seq_l = seq_t
                         if args.disable_distillation:
-                            model.train_step(seq_l, pos[lo:hi], max_item, args.lr, args.dropout_rate, ex_pos=ex_pos[elo:ehi], **kw)
+                            model.train_step(seq_l, pos_t, max_item, args.lr, args.dropout_rate, ex_pos=ex_pos, **kw)
                         else:
-                            model.train_step(seq_l, pos[lo:hi], max_item, args.lr, args.dropout_rate, teacher=store.logits,
-                                             ex_trow=idx[elo:ehi].astype(np.int32), **kw)
+                            model.train_step(seq_l, pos_t, max_item, args.lr, args.dropout_rate, teacher=store.logits,
+                                             ex_trow=idx, **kw)
                     else:
-                        model.train_step(seq[lo:hi], pos[lo:hi], max_item, args.lr, args.dropout_rate, **kw)
+                        model.train_step(seq_t, pos_t, max_item, args.lr, args.dropout_rate, **kw)
                 model.engine.check_status()
                 valid_evaluator = Evaluator(valid_subseq, True, args.maxlen, args.eval_batch, max_item, 'valid', model, sess, shard)
                 info = valid_evaluator.evaluate(epoch)

@@ -136,8 +136,8 @@ class Saver:
         self.model = model
 
     def save(self, sess, path):
-        torch.save((self.model or sess.model).engine.state_dict(), path)
+        torch.save((self.model or sess.model).engine.state_dict(to_cpu=True), path)
         return path
 
     def restore(self, sess, path):
-        (self.model or sess.model).engine.load_state_dict(torch.load(path))
+        (self.model or sess.model).engine.load_state_dict(torch.load(path, weights_only=True))

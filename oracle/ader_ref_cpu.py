@@ -179,6 +179,7 @@ def forward_rep(params, seq, L, num_heads, *, training=False, rate=0.0, seed=0, 
             else:
                 h1 = torch.cat([h1[:, :-1], (pre[:, -1] * mk.view(B, H)).unsqueeze(1)], 1)
         h1 = _dropout(h1, rate, training, seed, step, site_ffn1(l), row0)    # modules.py:257
+        inter["h1d%d" % l] = h1
         h2 = h1 @ params[p + "w2"] + params[p + "b2"]                        # modules.py:259-261
         h2 = _dropout(h2, rate, training, seed, step, site_ffn2(l), row0)    # modules.py:262
         x = (h2 + y) * mask                                                  # modules.py:266, ADER.py:80

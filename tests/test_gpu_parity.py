@@ -151,6 +151,62 @@ def test_loss_and_gradients_match_oracle(cfg, mode, gemm):
         assert e < (6e-4 if gemm == "x3" else 3e-4), (k, e)
     assert np.all(eng.gradient("emb")[0].cpu().numpy() == 0)        # row 0 never receives gradient (modules.py:124-126)
     assert np.all(eng.gradient("emb")[N + 1:].cpu().numpy() == 0)   # items beyond max_item are outside the softmax
+    if gemm == "x3":
+        _check_against_plain_oracle(eng, masks, seq, pos, N, L, heads, okw, float(loss.item()))
+
+
+def flipped_relu_fraction(dev_masks, inter, seq):
+    """Fraction of ReLU/dropout branch decisions (real positions only; row T-1 for a pruned block) on which the device and
+    the float64 oracle disagree."""
+    real = torch.from_numpy(np.asarray(seq) != 0)
+    bad = tot = 0
+    for l, (kind, mk) in dev_masks.items():
+        o = inter["h1d%d" % l] != 0
+        if kind == "all":
+            d = mk.view(o.shape)
+            sel = real
+        else:
+            o, d = o[:, -1], mk.view(o.shape[0], o.shape[2])
+            sel = real[:, -1]
+        bad += int((o[sel] != d[sel]).sum())
+        tot += int(o[sel].numel())
+    return bad / max(tot, 1)
+
+
+def _check_against_plain_oracle(eng, masks, seq, pos, N, L, heads, okw, got_loss, step=4, seed=3):
+    """The default (bf16x3) path against the PLAIN float64 oracle -- no branch decisions handed over.  Stated, looser
+    bounds: the device may take the other ReLU branch only where the pre-activation is within its ~2^-16 rounding of zero
+    (fraction of disagreeing decisions < 1e-3), and each such flip moves individual gradient entries by O(1e-3)
+    (every gradient tensor within 5e-3 normalised, loss within 2e-5).  A wrong mask (a real bug) violates the first bound
+    by orders of magnitude: tests/test_gpu_parity.py::test_plain_oracle_check_catches_a_wrong_mask."""
+    p64 = _params(eng, torch.float64)
+    _, inter = R.forward_rep(p64, seq, L, heads, training=True, rate=0.3, seed=seed, step=step, return_intermediates=True)
+    frac = flipped_relu_fraction(masks, inter, seq)
+    assert frac < 1e-3, ("ReLU/dropout decisions differ from the plain oracle", frac)
+    oloss, og = R.loss_and_grads(p64, seq, pos, N, L, heads, training=True, rate=0.3, seed=seed, step=step, **okw)
+    assert abs(got_loss - float(oloss)) < 2e-5 * max(1.0, abs(float(oloss)))
+    for k in eng.layout:
+        e = nerr(eng.gradient(k).cpu().numpy(), og[k].numpy(), floor=1e-4)
+        assert e < 5e-3, (k, "vs plain oracle", e)
+
+
+def test_plain_oracle_check_catches_a_wrong_mask():
+    """The plain-oracle assertion must fail when the device's branch decisions are wrong: invert one session's decisions."""
+    item_num, T, H, L, heads, B, N = CFGS[0]
+    eng = _engine(item_num, T, H, L, heads, seed=3, gemm="x3")
+    rs = np.random.RandomState(2)
+    seq = _seqs(rs, B, T, N, full=True)
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    eng.global_step = 4
+    loss = eng.loss_and_grad(seq, pos, N, rate=0.3)
+    torch.cuda.synchronize()
+    masks = relu_masks_of(eng)
+    _check_against_plain_oracle(eng, masks, seq, pos, N, L, heads, {}, float(loss.item()))     # the real masks pass
+    kind, mk = masks[0]
+    bad = mk.clone().view(B, -1)
+    bad[0] = ~bad[0]
+    with pytest.raises(AssertionError):
+        _check_against_plain_oracle(eng, {**masks, 0: (kind, bad.view(mk.shape))}, seq, pos, N, L, heads, {}, float(loss.item()))
 
 
 BF16_CFGS = [  # item_num, T, H, L, heads, B, N  (tail tiles, several ranges, B not a multiple of 128, empty ranges)
