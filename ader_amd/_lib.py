@@ -54,9 +54,13 @@ _SIGS = {
     "ader_gather_owned": [P, P, I, I, I, I, P, P],
     "ader_scatter_owned": [P, P, I, I, I, I, I, P, P, P],
     "ader_lbf_fwd_shard": [P, P, I, I, I, I, I, I, P, P, P, P, P],
-    "ader_lbf_bwd_demb": [P, P, I, I, I, I, I, P, P, P, P, P],
-    "ader_lbf_bwd_adam": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P],
-    "ader_lbf_bwd_adam_ex": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P][:-1] + [P, P],
+    "ader_lx3_prep": [P, P, P, I, I, I, P],
+    "ader_lx3_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_tab_grad": [P, P, P, I, I, I, I, I, P, P, P, P, P],
+    "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
+    "ader_tab_update_sh": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P, P],
+    "ader_tab_meta_ints": [I],
+    "ader_tab_tile_meta": [P, P, P, P, P, P, I, P, P],
     "ader_fused_bucket_gran": [],
     "ader_fused_bucket_id0": [],
     "ader_embed_bwd_rows": [P, P, P, I, I, I, I] + _DROP + [P],
@@ -102,7 +106,7 @@ class AderSeqBwdQkv(ctypes.Structure):
                 [("d_emb", AderDrop)] + [(k, c_int) for k in ("B", "T", "H", "pruned", "emb_bwd", "pad_")])
 
 
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0"}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints"}
 
 
 class AderHipError(RuntimeError):

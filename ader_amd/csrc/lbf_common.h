@@ -1,0 +1,59 @@
+// Shared pieces of the bf16-MFMA logit kernels (logits_bf16.hip, logits_x3.hip, table_update.hip).  gfx950 only.
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define HP 160
+#define LDR 168                 // bf16 elements per LDS / rep_bf row
+#define LOG2E 1.4426950408889634f
+#define RESCALE_THR 6.0f        // lazy online-softmax rescale threshold (log2 units): p <= 2^6
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// accumulator row of register `reg` for lane half hh (C/D layout of the 32x32 MFMA)
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// 4(k) x 16(n) transposed LDS read: lane (q = (lane&15)>>2, p = lane&3) supplies the address of row k0+q, cols n0+4p..;
+// lane i of the 16-lane group receives column n0+i of rows k0..k0+3.
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+}
+
+typedef __attribute__((address_space(3))) bf16 lds_bf16;
+__device__ __forceinline__ bf16x4 tr_read3(const lds_bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
+    return o;
+}
+
+
+// workgroup barrier that orders LDS traffic only (__syncthreads also drains every outstanding global access of the wave)
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// Sparse terms and optimiser constants of the fused table update (table_update.hip): when the whole gradient of a table row is
+// available inside the workgroup that owns it -- the dense logits term from the MFMAs, plus the sparse input-embedding rows and
+// one-hot target rows looked up in id-sorted lists -- the TF-Adam update of that row (ADER.py:96) is applied in place.
+struct FuseArgs {
+    const int* sp_ids; const int* sp_rows; int n_sp; const float* sp_src; float sp_scale;   // input-embedding rows (sorted by id)
+    const int* tg_ids; const int* tg_rows; int n_tg; const float* wrow;                      // one-hot targets (sorted by id)
+    const int* tile_meta;       // per 64-row tile: [2 lists][18] = {k0, k1, first 8 (id, row) entries} (ader_tab_tile_meta)
+    float* emb1; float* m1; float* v1; bf16* sh1w;   // row of item 1 of theta/m/v and of the bf16 shadow (NULL: no shadow)
+    float lr_t, omb1, omb2, eps;
+    const float* extra1;        // EXTRA: dense gradient rows to add (row of item 1; [.,H] fp32), e.g. distilled rows' term
+};

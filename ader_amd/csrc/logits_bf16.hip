@@ -12,44 +12,16 @@
 //              O/l is the softmax-weighted mean of item embeddings = d loss / d rep up to the target term, so the
 //              backward pass needs no second recompute for dRep.
 //   k_lbf_combine  merges the per-range partials: lse, loss, dRep, and the per-row exponent offset for the backward.
-//   k_lbf_bwd_de   dE tile = dlogit^T . rep per 128-item workgroup: S = rep.E^T recomputed (batch rows on the MFMA
+//   (table_update.hip) dE tile = dlogit^T . rep per item-tile workgroup: S = rep.E^T recomputed (batch rows on the MFMA
 //              rows), p = exp2(S*log2e + off_b) packed to bf16 in registers and fed back as the A operand of
 //              dE[item,:] += P^T . rep with rep read k-major by ds_read_b64_tr_b16.  Each dE row is written once.
 //   k_lbf_target_fix  the sparse one-hot term: dE[label_b] -= w_b * rep_b.
 //
 // LDS tiles are row-major bf16 with a 168-element (336 B) row stride: ds_read_b128 operand reads are conflict-free
 // (20 r mod 64 covers 16 distinct 4-bank slots).  gfx950 only.
-#include "common.h"
+#include <stdlib.h>
+#include "lbf_common.h"
 #include "../../include/ader_hip.h"
-
-typedef __bf16 bf16;
-typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-#define HP 160
-#define LDR 168                 // bf16 elements per LDS / rep_bf row
-#define LOG2E 1.4426950408889634f
-#define RESCALE_THR 6.0f        // lazy online-softmax rescale threshold (log2 units): p <= 2^6
-
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// accumulator row of register `reg` for lane half hh (C/D layout of the 32x32 MFMA)
-__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
-
-// 4(k) x 16(n) transposed LDS read: lane (q = (lane&15)>>2, p = lane&3) supplies the address of row k0+q, cols n0+4p..;
-// lane i of the 16-lane group receives column n0+i of rows k0..k0+3.
-__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
-}
-
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
-    return o;
-}
 
 // rep fp32 [B,H] -> rep_bf [Bp, LDR] bf16, zero padded (rows >= B, cols >= H)
 __global__ __launch_bounds__(256) void k_lbf_prep(const float* __restrict__ rep, bf16* __restrict__ rep_bf, int B, int Bp, int H) {
@@ -210,9 +182,12 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
 
 // One workgroup per batch row: merge range partials -> lse (natural log), loss row, dRep row, backward offset.
 // 640 threads: thread (g = tid/160, h = tid%160) sums ranges i = g mod 4 of channel h (fixed order: deterministic).
+// X3: the target logit and the target row come from the fp32 operands (emb1_f = table row of item 1, rep_f [B,H]).
+template <bool X3>
 __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __restrict__ lab, const float* __restrict__ wrow,
                                                      float* __restrict__ lse, float* __restrict__ off, float* __restrict__ rowloss,
-                                                     float* __restrict__ drep) {
+                                                     float* __restrict__ drep, const float* __restrict__ emb1_f,
+                                                     const float* __restrict__ rep_f) {
     __shared__ float sc[1024];          // per-range scale 2^(pm - M) (0 for empty ranges)
     __shared__ float red[640];
     __shared__ float sM, sL;
@@ -266,8 +241,8 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
     if (tid < H) {
         oh = ((red[tid] + red[160 + tid]) + red[320 + tid]) + red[480 + tid];
         if (t >= 0) {                                // target logit with the same bf16-rounded operands as the MFMA path
-            et = (float)a.sh1[(size_t)t * LDR + tid];
-            part = (float)a.rep_bf[(size_t)b * LDR + tid] * et;
+            if (X3) { et = emb1_f[(size_t)t * H + tid]; part = rep_f[(size_t)b * H + tid] * et; }
+            else { et = (float)a.sh1[(size_t)t * LDR + tid]; part = (float)a.rep_bf[(size_t)b * LDR + tid] * et; }
         }
         drep[(size_t)b * H + tid] = w * (oh / L - et);
     }
@@ -390,310 +365,207 @@ __global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, in
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-// Optional fused optimiser ("the table gradient is never materialised"): when the whole gradient of a table row is
-// available inside the workgroup that owns it -- the dense logits term from the MFMAs, plus the sparse input-embedding
-// rows and one-hot target rows looked up in id-sorted lists -- the TF-Adam update of that row (ADER.py:96) is applied in
-// place from the LDS staging tile: theta/m/v are read and written once, dE is neither written nor re-read, and the
-// bf16 shadow row is refreshed on the way out.  Sparse terms are added in list order (deterministic, no atomics).
-struct FuseArgs {
-    const int* sp_ids; const int* sp_rows; int n_sp; const float* sp_src; float sp_scale;   // input-embedding rows (sorted by id)
-    const int* tg_ids; const int* tg_rows; int n_tg; const float* wrow;                      // one-hot targets (sorted by id)
-    const int* sp_start; const int* tg_start;   // bucket offsets into the two lists: bucket j = ids [gran*j + id0, gran*(j+1) + id0)
-    float* emb1; float* m1; float* v1; bf16* sh1w;                                           // row of item 1 of theta/m/v/shadow
-    float lr_t, omb1, omb2, eps;
-    const float* extra1;        // EXTRA: dense gradient rows to add (row of item 1; [.,H] fp32), e.g. distilled rows' term
-};
 
-__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, int key) {
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
-    return lo;
+// ============================================================================================= x3: float32-grade logits
+// The same flash forward with every product as three bf16 MFMAs (hi.hi + lo.hi + hi.lo, operands split into
+// bf16(x) + bf16(x - bf16(x)): ~2^-16 relative per product, fp32 accumulate) -- the reference's float32 logits
+// (ADER.py:91-93) on the bf16 matrix cores.  There is no bf16 shadow in this mode: the fp32 table rows are streamed
+// directly (600 B per item instead of 2 x 336 B) and split on the way into LDS.
+__global__ __launch_bounds__(256) void k_lx3_prep(const float* __restrict__ rep, bf16* __restrict__ rep_hi, bf16* __restrict__ rep_lo,
+                                                  int B, int Bp, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * LDR) return;
+    const int b = i / LDR, c = i - b * LDR;
+    const float x = (b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f;
+    const bf16 h = (bf16)x;
+    rep_hi[i] = h;
+    rep_lo[i] = (bf16)(x - (float)h);
 }
 
-// dE tile (128 items per workgroup, 32 per wave); loops over all batch rows in chunks of 64 staged through LDS.
-#define FLD 152                    // fp32 row stride of the dE staging tile
-#ifndef NT_STORES
-#define NT_STORES 1
-#endif
+struct Lx3Args {
+    const float* emb1;          // fp32 table, row of item 1
+    int vrows;                  // table rows available from emb1 (item_num)
+    const bf16* rep_hi; const bf16* rep_lo;     // [Bp][LDR]
+    int Bp, H, N, ranges;
+    float* pm; float* pl; float* pO;
+};
 
-// workgroup barrier that orders LDS traffic only (__syncthreads also drains every outstanding global access of the wave)
-__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <bool ADAM, bool EXTRA = false>
-__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs f) {
+#define XPPT 5                     // 16-byte fp32 vectors per thread per 32-item block (5 * 1024 floats >= 32 * 160)
+// XRD = register ring depth, OCC = workgroups per CU the register budget is sized for (256 / 512 registers per lane)
+template <int XRD, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
-    float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
-    int* meta_l = (int*)(off_l + a.Bp);      // ADAM: per (half, list): [k0, k1, 8 x (id, row)] = 18 ints, 4 lists (SP_PRE entries prefetched)
+    bf16* E_l = (bf16*)smem_raw;                       // [2 buffers][2 planes: hi, lo][FB][LDR]
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int H = a.H, N = a.N;
-    const int tile0 = (blockIdx.x + a.tile_off) * 128;
-    const int it0 = tile0 + wave * 32;
-    {   // table tile: 128 shadow rows, contiguous -> LDS (coalesced 16-B pieces) -> operand fragments in registers
-        const uint4* src = (const uint4*)(a.sh1 + (size_t)tile0 * LDR);
-        uint4* dst = (uint4*)R_l;
-        for (int idx = tid; idx < 128 * PCS_ROW; idx += 256) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (tile0 + idx / PCS_ROW < a.vrows) v = src[idx];
-            dst[idx] = v;
-        }
-    }
-    for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
-    if (ADAM && tid < 4) {
-        // the sparse lists of the two half-tiles (bucket bounds and the first entries) are fetched now, under the GEMM phase:
-        // three dependent global round trips less between the GEMM and the streaming update
-        const int half = tid >> 1, lst = tid & 1;
-        const int bkt = (tile0 + half * 64) >> 6;
-        const int* st = lst ? f.tg_start : f.sp_start;
-        const int* ids = lst ? f.tg_ids : f.sp_ids;
-        const int* rows = lst ? f.tg_rows : f.sp_rows;
-        int* mt = meta_l + tid * 18;
-        int k0 = 0, k1 = 0;
-        if (tile0 + half * 64 < N) { k0 = st[bkt]; k1 = st[bkt + 1]; }
-        mt[0] = k0; mt[1] = k1;
-        for (int i = 0; i < 8 && k0 + i < k1; ++i) { mt[2 + 2 * i] = ids[k0 + i]; mt[3 + 2 * i] = rows[k0 + i]; }
-    }
-    __syncthreads();
-    // ADAM: the first SPV input-embedding gradient rows of each half-tile (thread c holds column c), requested now and
-    // consumed after the GEMM phase
-#define SPV 3
-    float spv0[SPV], spv1[SPV];
-    if (ADAM) {
+    const int nchunk = a.Bp >> 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot / nchunk), bc = slot % nchunk;
+    if (range >= a.ranges) return;
+    const int N = a.N, H = a.H;
+    const int nblk = (N + FB - 1) / FB;
+    const int per = (nblk + a.ranges - 1) / a.ranges;
+    const int blk_begin = range * per, blk_end = min(nblk, blk_begin + per);
+    const int nb_blocks = max(0, blk_end - blk_begin);
+    const int b0 = bc * 128 + wave * 32;
+    // K padding (columns >= H) of both planes of both buffers stays zero: the block stores never touch it
+    for (int i = tid; i < 2 * 2 * FB * LDR / 8; i += 256) ((uint4*)E_l)[i] = make_uint4(0u, 0u, 0u, 0u);
+    bf16x8 bh_[10], bl_[10];
 #pragma unroll
-        for (int i = 0; i < SPV; ++i) {
-            const int* m0 = meta_l, * m1 = meta_l + 2 * 18;
-            spv0[i] = (tid < H && m0[0] + i < m0[1]) ? f.sp_src[(size_t)m0[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
-            spv1[i] = (tid < H && m1[0] + i < m1[1]) ? f.sp_src[(size_t)m1[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
-        }
+    for (int ks = 0; ks < 10; ++ks) {
+        bh_[ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
+        bl_[ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
     }
-    bf16x8 efrag[10];                                   // lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks) efrag[ks] = *(const bf16x8*)(R_l + (wave * 32 + r) * LDR + 16 * ks + 8 * hh);
-    __syncthreads();
-    f32x16 dE[5];
+    f32x16 O[5];
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dE[nb][j] = 0.0f;
-    const int nch = a.Bp >> 6;
-    const int n16 = 64 * LDR * 2 / 16;                  // 16-byte pieces per 64-row chunk (1344)
-    uint4 pf[6];
-#define LBF_RPREFETCH(c_)                                                                               \
-    {                                                                                                   \
-        const uint4* src_ = (const uint4*)(a.rep_bf + (size_t)(c_) * 64 * LDR);                          \
-        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                 \
-            const int idx = tid + 256 * j;                                                              \
-            pf[j] = (idx < n16) ? src_[idx] : make_uint4(0u, 0u, 0u, 0u);                               \
-        }                                                                                               \
+        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    // A block = FB consecutive table rows = one flat run of FB*H floats whose 16-byte phase is the table's (H even): vector j
+    // of thread t covers floats e = head + 4 t + 1024 j; its LDS position (row, col) does not depend on the block
+    const int ph = (int)(((uintptr_t)a.emb1 & 15) >> 2);
+    const int head = ph ? 4 - ph : 0;
+    const int nfl = FB * H;
+    int lo0[XPPT], lo1[XPPT];                           // LDS element offsets of floats (e, e+1) and (e+2, e+3); -1: outside
+#pragma unroll
+    for (int j = 0; j < XPPT; ++j) {
+        const int e = head + 4 * tid + 1024 * j;
+        const int row = e / H, col = e - row * H;
+        lo0[j] = (e < nfl) ? row * LDR + col : -1;
+        const int c1 = col + 2;
+        lo1[j] = (e + 2 < nfl) ? ((c1 >= H) ? (row + 1) * LDR + (c1 - H) : row * LDR + c1) : -1;
     }
-#define LBF_RSTAGE(buf_)                                                                                \
-    {                                                                                                   \
-        uint4* dst_ = (uint4*)(R_l + (buf_) * 64 * LDR);                                                 \
-        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                 \
-            const int idx = tid + 256 * j;                                                              \
-            if (idx < n16) dst_[idx] = pf[j];                                                           \
-        }                                                                                               \
+    f32x4_t ring[XRD][XPPT];
+    f32x2_t ringh[XRD];
+#define LX3_LOAD(slot_, blk_)                                                                            \
+    {                                                                                                    \
+        const float* src_ = a.emb1 + (size_t)(blk_) * FB * H;                                            \
+        const int nav_ = min(FB, a.vrows - (blk_) * FB) * H;                                             \
+        _Pragma("unroll") for (int j = 0; j < XPPT; ++j) {                                               \
+            const int e_ = head + 4 * tid + 1024 * j;                                                    \
+            f32x4_t v_ = (f32x4_t){0.f, 0.f, 0.f, 0.f};                                                  \
+            if (e_ + 3 < nav_) v_ = *(const f32x4_t*)(src_ + e_);                                        \
+            else if (e_ + 1 < nav_) { const f32x2_t t_ = *(const f32x2_t*)(src_ + e_); v_[0] = t_[0]; v_[1] = t_[1]; } \
+            ring[slot_][j] = v_;                                                                         \
+        }                                                                                                \
+        ringh[slot_] = (head && tid == 0 && nav_ > 0) ? *(const f32x2_t*)src_ : (f32x2_t){0.f, 0.f};     \
     }
-    LBF_RPREFETCH(0); LBF_RSTAGE(0);
-    __syncthreads();
-    int cur = 0;
+#define LX3_PUT2(dst_, off_, x0_, x1_)                                                                   \
+    {                                                                                                    \
+        const bf16 h0_ = (bf16)(x0_), h1_ = (bf16)(x1_);                                                 \
+        bf16x2 vh_, vl_;                                                                                 \
+        vh_[0] = h0_; vh_[1] = h1_; vl_[0] = (bf16)((x0_) - (float)h0_); vl_[1] = (bf16)((x1_) - (float)h1_); \
+        *(bf16x2*)((dst_) + (off_)) = vh_;                                                               \
+        *(bf16x2*)((dst_) + FB * LDR + (off_)) = vl_;                                                    \
+    }
+#define LX3_STORE(slot_, buf_)                                                                           \
+    {                                                                                                    \
+        bf16* dst_ = E_l + (buf_) * 2 * FB * LDR;                                                        \
+        _Pragma("unroll") for (int j = 0; j < XPPT; ++j) {                                               \
+            if (lo0[j] >= 0) LX3_PUT2(dst_, lo0[j], ring[slot_][j][0], ring[slot_][j][1]);               \
+            if (lo1[j] >= 0) LX3_PUT2(dst_, lo1[j], ring[slot_][j][2], ring[slot_][j][3]);               \
+        }                                                                                                \
+        if (head && tid == 0) LX3_PUT2(dst_, 0, ringh[slot_][0], ringh[slot_][1]);                       \
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < XRD; ++s_) if (s_ < nb_blocks) LX3_LOAD(s_, blk_begin + s_);
+    __syncthreads();                                    // zero fill done before the first block store
+    int cur = 0, i = 0;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    for (int c = 0; c < nch; ++c) {
-        const bool more = c + 1 < nch;
-        if (more) LBF_RPREFETCH(c + 1);
-        const bf16* Rb = R_l + cur * 64 * LDR;
-#pragma unroll 1
-        for (int bb = 0; bb < 2; ++bb) {
-            const int b0 = c * 64 + bb * 32;
+    while (i < nb_blocks) {
+#pragma unroll
+        for (int s_ = 0; s_ < XRD; ++s_) {
+            if (i >= nb_blocks) break;                  // workgroup-uniform
+            const int blk = blk_begin + i;
+            LX3_STORE(s_, cur);
+            if (i + XRD < nb_blocks) LX3_LOAD(s_, blk + XRD);
+            __syncthreads();
+            const bf16* Eh = E_l + cur * 2 * FB * LDR;
+            const bf16* El = Eh + FB * LDR;
+            const int i0 = blk * FB;
             f32x16 S;
 #pragma unroll
             for (int j = 0; j < 16; ++j) S[j] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 10; ++ks) {
-                const bf16x8 af = *(const bf16x8*)(Rb + (bb * 32 + r) * LDR + 16 * ks + 8 * hh);
-                S = mfma_bf16(af, efrag[ks], S);
+                const bf16x8 ah = *(const bf16x8*)(Eh + r * LDR + 16 * ks + 8 * hh);
+                const bf16x8 al = *(const bf16x8*)(El + r * LDR + 16 * ks + 8 * hh);
+                S = mfma_bf16(ah, bh_[ks], S);
+                S = mfma_bf16(al, bh_[ks], S);
+                S = mfma_bf16(ah, bl_[ks], S);
             }
-            // rows of S are batch rows: p = w_b * softmax = exp2(S*log2e + off_b)
+            if (i0 + FB > N) {                          // tail block: items >= N are outside the softmax
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 o4 = *(const float4*)(off_l + b0 + 8 * g + 4 * hh);
-                S[4 * g + 0] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 0], LOG2E, o4.x));
-                S[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 1], LOG2E, o4.y));
-                S[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 2], LOG2E, o4.z));
-                S[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 3], LOG2E, o4.w));
+                for (int j = 0; j < 16; ++j) if (i0 + acc_row(j, hh) >= N) S[j] = -INFINITY;
             }
+            float tmax = S[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, S[j]);
+            float t2 = tmax * LOG2E;
+            if (__any(t2 > m_run + RESCALE_THR)) {
+                t2 = fmaxf(t2, __shfl_xor(t2, 32, 64));
+                const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;
+                const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float ar = __shfl(alpha, acc_row(j, hh), 64);     // O rows are batch rows
+#pragma unroll
+                    for (int nb = 0; nb < 5; ++nb) O[nb][j] *= ar;
+                }
+            }
+            const float nm = -m_run;
+            float ls = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { S[j] = __builtin_amdgcn_exp2f(fmaf(S[j], LOG2E, nm)); ls += S[j]; }
+            l_run += ls;
             const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
+            bf16x8 pl0, pl1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pl0[j] = (bf16)(S[j] - (float)pa0[j]); pl1[j] = (bf16)(S[8 + j] - (float)pa1[j]); }
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
-                const bf16* base = Rb + (bb * 32 + 4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
+                const bf16* base = Eh + (4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
                 const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
                 const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
                 bf16x8 b0v, b1v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
-                dE[nb] = mfma_bf16(pa0, b0v, dE[nb]);
-                dE[nb] = mfma_bf16(pa1, b1v, dE[nb]);
-            }
-        }
-        if (more) LBF_RSTAGE(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    // dE acc (rows = items, col = channel) -> LDS [64 items][fs] -> coalesced row stores, two halves of 64 items.
-    // ADAM: fs = H, so the LDS tile is the same flat [64*H] block as the half-tile's rows of theta / m / v in memory.
-    float* F_l = (float*)smem_raw;
-    const int HH = H >> 1;
-    const int fs = ADAM ? H : FLD;
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#define AV 6
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        // ADAM: the first round of theta/m/v vectors of this half-tile is requested BEFORE the dE staging and the sparse
-        // terms (independent of both); the barriers in between order LDS only, so the loads stay in flight across them
-        const int base_it = tile0 + half * 64;
-        const int rows_valid = min(64, N - base_it);
-        const int n_el = rows_valid > 0 ? rows_valid * H : 0;
-        float* __restrict__ gp = ADAM ? f.emb1 + (size_t)base_it * H : nullptr;
-        float* __restrict__ gm = ADAM ? f.m1 + (size_t)base_it * H : nullptr;
-        float* __restrict__ gv = ADAM ? f.v1 + (size_t)base_it * H : nullptr;
-        const int head = (((uintptr_t)gp) & 15) ? 2 : 0;
-        int e = head + 4 * tid;
-        int row = e / H, col = e - row * H;
-        const int step_r = 1024 / H, step_c = 1024 - step_r * H;
-        f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
-        const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)base_it * H : nullptr;
-        int E[AV], RC[AV], NV[AV];
-#define ROUND_LOAD()                                                                                       \
-        _Pragma("unroll") for (int u = 0; u < AV; ++u) {                                                   \
-            E[u] = e; RC[u] = (row << 16) | col;                                                           \
-            NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);                                         \
-            if (NV[u] == 2) {                                                                              \
-                P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e); \
-                if (EXTRA) G[u] = __builtin_nontemporal_load((const f32x4_t*)(gx + e));                    \
-            } else if (NV[u] == 1) {                                                                       \
-                if (EXTRA) { const f32x2_t g_ = *(const f32x2_t*)(gx + e); G[u] = (f32x4_t){g_[0], g_[1], 0.f, 0.f}; } \
-                const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e); \
-                P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f}; \
-            }                                                                                              \
-            e += 1024; row += step_r; col += step_c;                                                       \
-            if (col >= H) { col -= H; ++row; }                                                             \
-        }
-        if (ADAM) { ROUND_LOAD(); }
-        if (ADAM) lds_only_barrier(); else __syncthreads();
-        if ((wave >> 1) == half) {
+                O[nb] = mfma_bf16(pa0, b0v, O[nb]);
+                O[nb] = mfma_bf16(pa1, b1v, O[nb]);
+                O[nb] = mfma_bf16(pl0, b0v, O[nb]);
+                O[nb] = mfma_bf16(pl1, b1v, O[nb]);
+                const bf16* bl = base + FB * LDR;
+                const bf16x4 m0 = tr_read(bl), n0 = tr_read(bl + 8 * LDR);
+                const bf16x4 m1 = tr_read(bl + 16 * LDR), n1 = tr_read(bl + 24 * LDR);
+                bf16x8 c0v, c1v;
 #pragma unroll
-            for (int nb = 0; nb < 5; ++nb) {
-                const int h = 32 * nb + r;
-                if (h < fs) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * fs + h] = dE[nb][j];
-                }
+                for (int j = 0; j < 4; ++j) { c0v[j] = m0[j]; c0v[4 + j] = n0[j]; c1v[j] = m1[j]; c1v[4 + j] = n1[j]; }
+                O[nb] = mfma_bf16(pa0, c0v, O[nb]);
+                O[nb] = mfma_bf16(pa1, c1v, O[nb]);
             }
-        }
-        if (ADAM) lds_only_barrier(); else __syncthreads();
-        if (!ADAM) {
-            for (int idx = tid; idx < 64 * HH; idx += 256) {
-                const int row = idx / HH, c2 = idx - row * HH;
-                if (base_it + row < N)
-                    *(float2*)(a.demb1 + (size_t)(base_it + row) * H + 2 * c2) = *(const float2*)(F_l + row * FLD + 2 * c2);
-            }
-        } else {
-            // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
-            const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
-            if (tid < H && id_lo < id_hi) {
-                // entries of bucket base_it >> 6 (ids [base_it+1, base_it+65): exactly this half-tile), (id, row)-ordered
-                const int* ms = meta_l + (half * 2 + 0) * 18;
-                const int* mg = meta_l + (half * 2 + 1) * 18;
-                const int k0s = ms[0], k1s = ms[1];
-#pragma unroll
-                for (int i = 0; i < SPV; ++i) {                  // rows already in registers (same (id, row) order)
-                    if (k0s + i < k1s) {
-                        const int id = ms[2 + 2 * i];
-                        if (id < id_hi) F_l[(id - id_lo) * fs + tid] += half ? spv1[i] : spv0[i];
-                    }
-                }
-                for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
-                    const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
-                    if (id >= id_hi) break;
-                    const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
-                    F_l[(id - id_lo) * fs + tid] += f.sp_src[(size_t)row * H + tid] * f.sp_scale;
-                }
-                for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
-                    const int id = (i < 8) ? mg[2 + 2 * i] : f.tg_ids[k];
-                    if (id >= id_hi) break;
-                    const int b = (i < 8) ? mg[3 + 2 * i] : f.tg_rows[k];
-                    F_l[(id - id_lo) * fs + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
-                }
-            }
-            lds_only_barrier();
-            // Adam on the half-tile.  Its rows are ONE contiguous block of 64*H floats in theta / m / v (and in F_l): it is
-            // walked as 16-byte vectors (the block starts 0 or 8 bytes past a 16-byte boundary: `head` floats are peeled),
-            // all loads of a round issued before any math or store; (row, col) of a vector -- needed only for the bf16
-            // shadow row -- is stepped without divisions.
-            bf16* __restrict__ psh = f.sh1w + (size_t)base_it * LDR;
-#define ADAM1(p_, m_, v_, g_)                                                                              \
-            { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
-            if (head && tid == 0 && n_el > 0) {                   // elements 0,1 (row 0, columns 0,1)
-                f32x2_t p = *(const f32x2_t*)gp, m = *(const f32x2_t*)gm, v = *(const f32x2_t*)gv;
-                float2 g2 = *(const float2*)F_l;
-                if (EXTRA) { g2.x += gx[0]; g2.y += gx[1]; }
-                ADAM1(p[0], m[0], v[0], g2.x); ADAM1(p[1], m[1], v[1], g2.y);
-                *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
-                bf16x2 sb; sb[0] = (bf16)p[0]; sb[1] = (bf16)p[1];
-                *(bf16x2*)psh = sb;
-            }
-#pragma unroll 1
-            for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160; round 0 is already in flight
-                if (k0) { ROUND_LOAD(); }
-#pragma unroll
-                for (int u = 0; u < AV; ++u) {
-                    if (NV[u] == 0) continue;
-                    float2 ga = *(const float2*)(F_l + E[u]);
-                    float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
-                    if (EXTRA) { ga.x += G[u][0]; ga.y += G[u][1]; gb.x += G[u][2]; gb.y += G[u][3]; }
-                    f32x4_t p = P[u], m = M[u], v = V[u];
-                    ADAM1(p[0], m[0], v[0], ga.x); ADAM1(p[1], m[1], v[1], ga.y);
-                    ADAM1(p[2], m[2], v[2], gb.x); ADAM1(p[3], m[3], v[3], gb.y);
-                    const int r0 = RC[u] >> 16, c0 = RC[u] & 0xffff;
-                    bf16x2 s0; s0[0] = (bf16)p[0]; s0[1] = (bf16)p[1];
-                    *(bf16x2*)(psh + r0 * LDR + c0) = s0;
-                    if (NV[u] == 2) {
-                        // theta/m/v of this block are not touched again this step: keep them out of the caches
-                        __builtin_nontemporal_store(p, (f32x4_t*)(gp + E[u]));
-                        __builtin_nontemporal_store(m, (f32x4_t*)(gm + E[u]));
-                        __builtin_nontemporal_store(v, (f32x4_t*)(gv + E[u]));
-                        const int c1 = c0 + 2;
-                        bf16x2 s1; s1[0] = (bf16)p[2]; s1[1] = (bf16)p[3];
-                        *(bf16x2*)(psh + ((c1 >= H) ? (r0 + 1) * LDR + (c1 - H) : r0 * LDR + c1)) = s1;
-                    } else {
-                        *(f32x2_t*)(gp + E[u]) = (f32x2_t){p[0], p[1]};
-                        *(f32x2_t*)(gm + E[u]) = (f32x2_t){m[0], m[1]};
-                        *(f32x2_t*)(gv + E[u]) = (f32x2_t){v[0], v[1]};
-                    }
-                }
-            }
-#undef ADAM1
+            cur ^= 1;
+            ++i;
         }
     }
-}
-
-// sparse one-hot term of dlogit: dE[label_b,:] -= w_b * rep_b  (one wave per batch row, float atomics)
-__global__ __launch_bounds__(256) void k_lbf_target_fix(const bf16* __restrict__ rep_bf, const int* __restrict__ lab,
-                                                        const float* __restrict__ wrow, float* __restrict__ demb1, int B, int H) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    const int t = lab[b] - 1;
-    if (t < 0) return;
-    const float w = wrow[b];
-    for (int c = lane; c < H; c += 64) atomicAdd(demb1 + (size_t)t * H + c, -w * (float)rep_bf[(size_t)b * LDR + c]);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (hh == 0) {
+        a.pm[(size_t)range * a.Bp + b0 + r] = m_run;
+        a.pl[(size_t)range * a.Bp + b0 + r] = l_tot;
+    }
+    float* o = a.pO + ((size_t)range * a.Bp + b0) * HP;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r] = O[nb][j];
 }
 
 // ============================================================================================= C ABI
 static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
-static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 4 * 18 * sizeof(int); }
 
 extern "C" {
 
@@ -739,7 +611,8 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
-    hipLaunchKernelGGL(k_lbf_combine, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep);
+    hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, (const float*)nullptr,
+                       (const float*)nullptr);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -796,99 +669,49 @@ int ader_lbf_merge_parts(const float* parts, int world, int Bp, int B, int H, co
     return 0;
 }
 
-// Table gradient rows 1..N (overwritten), including the sparse one-hot term.
-int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
-                      const float* wrow, const float* off, float* demb, void* stream) {
+// x3 operand rows of the representations: rep_hi = bf16(rep), rep_lo = bf16(rep - rep_hi), [Bp,168] each, zero padded
+int ader_lx3_prep(const float* rep, void* rep_hi, void* rep_lo, int B, int Bp, int H, void* stream) {
+    if (Bp <= 0) return 0;
+    if (B > Bp || H > HP) return -2;
+    hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, (hipStream_t)stream, rep, (bf16*)rep_hi, (bf16*)rep_lo,
+                       B, Bp, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Forward of the one-hot softmax CE over items 1..N at float32 grade (three bf16 MFMAs per product), streaming the fp32
+// table itself.  Same scratch and outputs as ader_lbf_fwd; rep_hi / rep_lo: Bp*168 bf16 each.
+int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                 void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
+                 float* drep, void* stream) {
     if (B <= 0) return 0;
-    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2) return -2;
+    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || ((uintptr_t)emb & 7)) return -2;
+    const size_t lds = (size_t)2 * 2 * FB * LDR * sizeof(bf16);
     static bool f = false;
-    static int lds_set = 0;
-    const size_t lds = bwd_lds(Bp);
-    if (!f || (int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static int variant = 0;
+    if (!f) {
+        const char* v = getenv("ADER_LX3_VARIANT");        // tuning switch: 0 = two workgroups per CU, 1 = one (deeper ring)
+        variant = (v && v[0] == '1') ? 1 : 0;
+        hipError_t e = hipFuncSetAttribute((const void*)k_lx3_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        f = true; lds_set = (int)lds;
+        e = hipFuncSetAttribute((const void*)k_lx3_fwd<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        f = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    Lx3Args x;
+    x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
+    x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
     LbfArgs a;
-    if (N > item_num) return -2;
-    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
-    a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
-    a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = demb + H;
-    FuseArgs fa = {};
-    hipLaunchKernelGGL(k_lbf_bwd_de<false>, dim3((N + 127) / 128), dim3(256), lds, st, a, fa);
-    hipLaunchKernelGGL(k_lbf_target_fix, dim3((B + 3) / 4), dim3(256), 0, st, (const bf16*)rep_bf, lab, wrow, demb + H, B, H);
+    a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
+    a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H);
+    if (variant) hipLaunchKernelGGL((k_lx3_fwd<3, 1>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
+    else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
+    hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;
 }
-
-// Fused: table-gradient GEMM + sparse terms + TF-Adam on table rows 1..N + shadow refresh, in one pass (single GPU).
-// sp_ids/sp_rows: the B*T input positions sorted by item id (pads = id 0 first) and their row index into sp_src [B*T,H]
-// (the masked/dropout-scaled gradient rows left by ader_embed_bwd_rows); sp_scale = sqrt(H).
-// tg_ids/tg_rows: the B labels sorted by id and their batch row.  emb/adam_m/adam_v: fp32 [item_num+1, H].
-int ader_lbf_bwd_adam_ex(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
-                         const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
-                         float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
-                         int tile_count, const float* extra_grad, void* stream);
-
-int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                      const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
-                      const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
-                      float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
-                      int tile_count, void* stream) {
-    return ader_lbf_bwd_adam_ex(rep_bf, shadow, item_num, B, Bp, H, N, off, sp_ids, sp_rows, sp_start, n_sp, sp_src, sp_scale, tg_ids,
-                                tg_rows, tg_start, n_tg, wrow, emb, adam_m, adam_v, lr_t, beta1, beta2, eps, tile_begin, tile_count,
-                                nullptr, stream);
-}
-
-// As ader_lbf_bwd_adam, plus a dense gradient extra_grad [item_num+1, H] (fp32, table layout; NULL = none) added row by row
-// before the update -- the table gradient of rows that did not go through the bf16 logit path (distilled exemplar rows).
-int ader_lbf_bwd_adam_ex(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
-                         const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
-                         float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
-                         int tile_count, const float* extra_grad, void* stream) {
-    if (B <= 0) return 0;
-    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num) return -2;
-    static bool f = false;
-    static int lds_set = 0;
-    const size_t lds = bwd_lds(Bp);
-    if (!f || (int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        f = true; lds_set = (int)lds;
-    }
-    LbfArgs a;
-    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
-    a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
-    a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = nullptr;
-    FuseArgs fa;
-    fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
-    fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
-    fa.sp_start = sp_start; fa.tg_start = tg_start;
-    fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = (bf16*)shadow + LDR;
-    fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
-    fa.extra1 = extra_grad ? extra_grad + H : nullptr;
-    {   // tiles [tile_begin, tile_begin + tile_count) of the ceil(N/128) item tiles (tile_count < 0: all)
-        const int all = (N + 127) / 128;
-        int tb = tile_begin < 0 ? 0 : tile_begin;
-        int te = tile_count < 0 ? all : tb + tile_count;
-        if (te > all) te = all;
-        if (te <= tb) return 0;
-        a.tile_off = tb;
-        if (extra_grad) hipLaunchKernelGGL((k_lbf_bwd_de<true, true>), dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
-        else hipLaunchKernelGGL((k_lbf_bwd_de<true, false>), dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
-    }
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
-// bucket layout the caller must use for sp_start / tg_start: granularity (ids per bucket) and first id of bucket 0
-// (a half-tile of the update covers item ids [64j + 1, 64j + 65))
-int ader_fused_bucket_gran(void) { return 64; }
-int ader_fused_bucket_id0(void) { return 1; }
 
 }  // extern "C"

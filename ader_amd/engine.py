@@ -156,10 +156,14 @@ class Engine:
         self.item_num, self.T, self.H, self.L, self.heads = item_num, maxlen, hidden_units, num_blocks, num_heads
         self.V = item_num + 1
         self.seed = seed
-        assert logits_dtype in ("f32", "bf16")
-        # "bf16": logits GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 master table, fp32 accumulate + softmax) for one-hot
-        # rows; distilled rows always take the float32 kernels
+        assert logits_dtype in ("f32", "bf16", "x3")
+        # "bf16": logit GEMMs on v_mfma_f32_32x32x16_bf16 with bf16-rounded operands (fp32 master table, fp32 accumulate and
+        # softmax); "x3": the same kernels at float32 grade -- every product as three bf16 MFMAs on hi/lo operand splits
+        # (~2^-16 relative, the reference's fp32 arithmetic of ADER.py:91-93 on the bf16 matrix cores), no bf16 shadow;
+        # "f32": the exact f32-MFMA kernels of logits.hip.  Distilled rows take the float32 kernels in every mode.
         self.logits_dtype = logits_dtype
+        self.lfast = logits_dtype in ("bf16", "x3") and hidden_units % 2 == 0      # flash forward + fused table update
+        self.lx3 = logits_dtype == "x3"
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         # data parallelism: the item table is split into `dp_world` equal shards of whole 128-item tiles (row 0 excluded)
@@ -637,9 +641,9 @@ class Engine:
         rows = B * T
         # distilled steps with a bf16 shadow: the train rows take the bf16 flash path and the fused table update, the (few)
         # exemplar rows the exact-f32 kernels; their table gradient enters the fused update as a dense extra term
-        split_kd = bool(self.shadow is not None and teacher is not None and n_ex > 0 and n_train > 0 and _defer_table
+        split_kd = bool(self.lfast and teacher is not None and n_ex > 0 and n_train > 0 and _defer_table
                         and N >= self._grad_hi and self.dp_world == 1 and self.kd_split)
-        use_bf16 = self.shadow is not None and (teacher is None or split_kd)
+        use_bf16 = self.lfast and (teacher is None or split_kd)
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
         self._deferred = None
         with self._sec("blocks_fwd"):
@@ -666,12 +670,17 @@ class Engine:
                  float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
             R = call("ader_lbf_ranges", N, Bp)
             rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
+            rep_lo = self.buf("lbf_rep_lo", (Bp * 168,), torch.bfloat16) if self.lx3 else None
             pm, pl = self.buf("lbf_pm", (R * Bp,)), self.buf("lbf_pl", (R * Bp,))
             pO = self.buf("lbf_pO", (R * Bp * 160,))
             lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
             with self._sec("logits_fwd"):
-                call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
-                     ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
+                if self.lx3:
+                    call("ader_lx3_fwd", ptr(rep), emb, self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(rep_lo),
+                         ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
+                else:
+                    call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
+                         ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
             if split_kd:
                 rep_x, drep_x = rep[n_train:], drep[n_train:]
                 Bpx, rix = self._rowinfo(n_ex, None, 0, None, ex_trow, N, Np, w_train, w_ex, teacher, tag="kd_")
@@ -690,7 +699,7 @@ class Engine:
                 extra = demb
             if not defer:
                 with self._sec("logits_bwd_demb"):
-                    call("ader_lbf_bwd_demb", ptr(rep_bf), ptr(self.shadow), self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow),
+                    call("ader_tab_grad", ptr(rep_bf), ptr(rep_lo), emb, self.item_num, B, Bp, H, N, ptr(lab), ptr(wrow),
                          ptr(off), ptr(demb), st)
         else:
             Bp, ri = self._rowinfo(B, pos, n_train, ex_pos if teacher is None else None, ex_trow if teacher is not None else None,
@@ -708,8 +717,8 @@ class Engine:
                 call("ader_logits_bwd_demb", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
         dx = self._blocks_backward(seq, drep, defer, demb)
         if defer:
-            self._deferred = dict(seq=seq, g=dx, B=(n_train if split_kd else B), Bp=Bp, N=N, rep_bf=rep_bf, off=off, lab=lab,
-                                  wrow=wrow, extra=extra)
+            self._deferred = dict(seq=seq, g=dx, B=(n_train if split_kd else B), Bp=Bp, N=N, rep_bf=rep_bf, rep_lo=rep_lo, off=off,
+                                  lab=lab, wrow=wrow, extra=extra)
         return self.loss
 
 
@@ -889,7 +898,12 @@ class Engine:
             self._bkt_bounds = torch.arange(id0, N + gran + 1, gran, dtype=torch.int32, device=self.device)
         sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
         tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
-        return ids, order, sp_start, tids, torder, tg_start
+        meta = None
+        if self.lx3:        # per-tile list records of the 64-row update kernel (table_update.hip)
+            meta = torch.empty(call("ader_tab_meta_ints", N), dtype=torch.int32, device=self.device)
+            call("ader_tab_tile_meta", ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), N, ptr(meta),
+                 self._stream())
+        return ids, order, sp_start, tids, torder, tg_start, meta
 
     def _lists_async(self, seq, lab, N):
         main = torch.cuda.current_stream()
@@ -919,7 +933,7 @@ class Engine:
         st = self._stream()
         H, T = self.H, self.T
         lr_t = self._lr_t(lr)
-        ids, order, sp_start, tids, torder, tg_start = self._lists_wait()
+        ids, order, sp_start, tids, torder, tg_start, tmeta = self._lists_wait()
         span = self.layout["pos"][0]
 
         def small_update():     # everything that feeds / is the update of the non-table parameters
@@ -944,10 +958,16 @@ class Engine:
             with Engine._OnStream(self, self._side):
                 small_update()
         with self._sec("logits_bwd_adam"):
-            call("ader_lbf_bwd_adam_ex", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"], ptr(D["off"]),
-                 ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
-                 ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
-                 self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
+            if self.lx3:
+                call("ader_tab_update", ptr(D["rep_bf"]), ptr(D["rep_lo"]), None, self.item_num, D["B"], D["Bp"], H, D["N"],
+                     ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
+                     ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
+                     self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
+            else:
+                call("ader_tab_update_sh", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"],
+                     ptr(D["off"]), ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))),
+                     ptr(tids), ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m),
+                     ptr(self.adam_v), lr_t, self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
         if overlap:
             main.wait_stream(self._side)
         else:
@@ -982,13 +1002,13 @@ class Engine:
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
         tiles = self.shard_items // 128
-        ids, order, sp_start, tids, torder, tg_start = self._sparse_lists(seq_g, lab_g, N)
+        ids, order, sp_start, tids, torder, tg_start, tmeta = self._sparse_lists(seq_g, lab_g, N)
         tiles = self.shard_items // 128
         with self._sec("logits_bwd_adam"):
-            call("ader_lbf_bwd_adam", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+            call("ader_tab_update_sh", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
                  ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
                  ptr(torder), ptr(tg_start), tids.numel(), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
-                 self.beta1, self.beta2, self.eps, r * tiles, tiles, st)
+                 self.beta1, self.beta2, self.eps, r * tiles, tiles, None, st)
         with self._sec("param_allgather"):
             S = self.shard_items * H
             table = self.theta[H:H + W * S]                       # rows 1 .. W*shard_items
@@ -1200,13 +1220,13 @@ class Engine:
             main.wait_stream(self._side) if getattr(self, "_side", None) is not None else None   # small gradients complete
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
-        ids, order, sp_start, tids, torder, tg_start = self._lists_wait()
+        ids, order, sp_start, tids, torder, tg_start, tmeta = self._lists_wait()
         tiles = S // 128
         with self._sec("logits_bwd_adam"):
-            call("ader_lbf_bwd_adam", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+            call("ader_tab_update_sh", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
                  ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
                  ptr(torder), ptr(tg_start), tids.numel(), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
-                 self.beta1, self.beta2, self.eps, r * tiles, tiles, st)
+                 self.beta1, self.beta2, self.eps, r * tiles, tiles, None, st)
         with self._sec("adam"):
             call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
                  self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
@@ -1247,7 +1267,7 @@ class Engine:
                 and kw.get("teacher") is None and kw.get("ex_pos") is None):
             return self._train_step_catalog(seq, pos, max_item, lr, **kw)
         self.sync_table()
-        sharded = self.dp_world > 1 and self.dp_sharded
+        sharded = self.dp_world > 1 and self.dp_sharded and self.shadow is not None      # (x3 / f32 logits: dense exchange)
         fuse = self.fuse_adam and (self.grad_hook is None or sharded)
         loss = self.loss_and_grad(seq, pos, max_item, _defer_table=fuse, **kw)
         if self._deferred is not None:

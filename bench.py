@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--logits", choices=["bf16", "f32"], default="bf16",
+    ap.add_argument("--logits", choices=["bf16", "x3", "f32"], default="bf16",
                     help="operand type of the logit GEMMs (fp32 master table, fp32 accumulate/softmax either way)")
     ap.add_argument("--regime", choices=["dense", "realistic"], default="dense",
                     help="synthetic id/length law (SURVEY 8d); the headline number is the dense regime")
@@ -182,10 +182,10 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         P = eng.P
-        lpeak = BF16_MFMA_PEAK_TFLOPS if args.logits == "bf16" else F32_MFMA_PEAK_TFLOPS
+        lpeak = BF16_MFMA_PEAK_TFLOPS if args.logits in ("bf16", "x3") else F32_MFMA_PEAK_TFLOPS
         # algorithmic work per launch (DESIGN.md "roofline accounting").  In bf16 mode the forward launch also
         # produces dRep (flash-style readout), so it is credited both GEMMs; recomputation is never credited.
-        fwd_flops = 2.0 * B * N * H * (2 if args.logits == "bf16" else 1)
+        fwd_flops = 2.0 * B * N * H * (2 if args.logits in ("bf16", "x3") else 1)
         work = {
             "logits_fwd": ("mfma", fwd_flops, lpeak),
             "logits_bwd_drep": ("mfma", 2.0 * B * N * H, lpeak),
@@ -193,9 +193,10 @@ def main():
             "blocks_fwd": ("mfma", L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
             "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
             "adam": ("hbm", 7.0 * P * 4, HBM_PEAK_GBS),
-            # fused table update: theta/m/v of rows 1..N in and out + bf16 shadow row in and out (dE never hits memory)
+            # fused table update: theta/m/v of rows 1..N in and out (+ bf16 shadow row in and out in bf16 mode; x3 mode has no shadow
+            # and counts ONE theta read although the kernel reads theta twice); dE never hits memory
             # (catalog-sharded N > 1: a rank updates only its N / world rows)
-            "logits_bwd_adam": ("hbm", (6.0 * N * H * 4 + 2.0 * N * 336) / (world if eng.dp_mode == "catalog" else 1), HBM_PEAK_GBS),
+            "logits_bwd_adam": ("hbm", (6.0 * N * H * 4 + (2.0 * N * 336 if args.logits == "bf16" else 0.0)) / (world if eng.dp_mode == "catalog" else 1), HBM_PEAK_GBS),
             # distilled exemplar rows on the exact-f32 kernels: logits + dRep + dE over the 0.9 N teacher columns
             "kd_rows": ("mfma", 3 * 2.0 * E * int(0.9 * N) * H, F32_MFMA_PEAK_TFLOPS),
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
@@ -240,7 +241,7 @@ def main():
             "metric": "train sessions/sec at batch=512 seq=50", "value": B * world * args.steps / dt, "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.logits == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "x3": "bf16x3", "f32": "f32"}[args.logits], "data": "synthetic",
             "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, %s regime%s (BASELINE.json configs[4])"
                                    % (args.regime, ", +%d distilled exemplar rows" % E if E else ""),
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,

@@ -219,27 +219,47 @@ int ader_scatter_owned(const float* recv, const int* ids, int n, int n_tab, int 
                        float* extra, void* stream);
 int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int Bp, int H, int N, int item_begin,
                        int item_count, float* pm, float* pl, float* pO, float* part, void* stream);
-/* demb rows 1..N overwritten (each row written once, then the sparse one-hot term is added with float atomics) */
-int ader_lbf_bwd_demb(const void* rep_bf, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
-                      const float* wrow, const float* off, float* demb, void* stream);
+/* float32-grade variant of ader_lbf_fwd ("x3": every product as three bf16 MFMAs on hi/lo operand splits, fp32 accumulate;
+ * ADER.py:91-93 is fp32 arithmetic).  Streams the fp32 table itself -- no bf16 shadow exists in this mode.  rep_hi/rep_lo:
+ * Bp*168 bf16 each (written here: bf16(rep), bf16(rep - hi)); the other scratch and the outputs as in ader_lbf_fwd. */
+int ader_lx3_prep(const float* rep, void* rep_hi, void* rep_lo, int B, int Bp, int H, void* stream);
+int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab,
+                 const float* wrow, void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off,
+                 float* rowloss, float* loss, float* drep, void* stream);
+/* Gradient of the one-hot softmax CE w.r.t. the item table (ADER.py:91-93 differentiated): demb rows 1..N overwritten
+ * (each row written once, then the sparse one-hot term is added with float atomics).  The GEMM operand is cut from the
+ * fp32 table `emb` inside the kernel (bf16, or hi/lo when rep_lo != NULL: x3 mode). */
+int ader_tab_grad(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int B, int Bp, int H, int N,
+                  const int* lab, const float* wrow, const float* off, float* demb, void* stream);
 
-/* Fused single-GPU table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both
- * sorted by item id) + TF-Adam on table rows 1..N of emb/adam_m/adam_v + shadow refresh.  The table gradient is never
- * written to memory.  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t). */
-/* sp_start / tg_start: offsets of id buckets in the sorted lists: bucket j covers ids [g*j + id0, g*(j+1) + id0) with
- * g = ader_fused_bucket_gran(), id0 = ader_fused_bucket_id0(); one entry per bucket up to the bucket containing N. */
-int ader_lbf_bwd_adam(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                      const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src,
-                      float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
-                      const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
-                      float eps, int tile_begin, int tile_count, void* stream);
-/* ... plus a dense fp32 gradient extra_grad [item_num+1, H] (table layout, NULL = none) added row by row before the update:
- * the table gradient of rows that did not go through the bf16 logit path (distilled exemplar rows, ADER.py:132-137) */
-int ader_lbf_bwd_adam_ex(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src,
-                         float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
-                         const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
-                         float eps, int tile_begin, int tile_count, const float* extra_grad, void* stream);
+/* Fused table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both sorted by
+ * item id) + tf.train.AdamOptimizer (ADER.py:96) on table rows 1..N of emb/adam_m/adam_v, one workgroup per 64-row tile.
+ * The table gradient is never written to memory and the item parameters are read ONCE (GEMM operand and Adam input come
+ * from the same LDS-resident tile in bf16 mode).  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t).
+ * rep_lo != NULL selects x3 mode.  shadow: bf16 [item_num+1][168] copy of the table, rows rewritten after the update
+ * (NULL: none; never written in x3 mode).  extra_grad: dense fp32 gradient [item_num+1, H] (table layout) added row by row
+ * before the update, or NULL -- the table gradient of rows that did not go through this path (distilled exemplar rows,
+ * ADER.py:132-137).
+ * Bucket layout of the sorted lists: bucket j covers ids [g*j + id0, g*(j+1) + id0) with g = ader_fused_bucket_gran(),
+ * id0 = ader_fused_bucket_id0(). */
+int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int item_num, int B, int Bp, int H, int N,
+                    const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                    const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, float* emb,
+                    float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                    int tile_count, const float* extra_grad, void* stream);
+/* The bf16-mode form over 128-row tiles: the GEMM operand is the tile's bf16 shadow rows (`shadow` is read AND rewritten) and the
+ * sorted lists are addressed through their 64-id bucket offsets sp_start / tg_start.  Faster than ader_tab_update(rep_lo = NULL) at
+ * H = 150 on MI355X although it reads 336 B more per row (measurements: DESIGN.md). */
+int ader_tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                       const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src,
+                       float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
+                       const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
+                       float eps, int tile_begin, int tile_count, const float* extra_grad, void* stream);
+/* tile_meta: per 64-row tile the list record {k0, k1, first 8 (id, row) entries} x 2 lists, ader_tab_meta_ints(N) ints, built
+ * by ader_tab_tile_meta from the bucket offsets sp_start / tg_start (one coalesced read per tile inside the update). */
+int ader_tab_meta_ints(int N);
+int ader_tab_tile_meta(const int* sp_ids, const int* sp_rows, const int* sp_start, const int* tg_ids, const int* tg_rows,
+                       const int* tg_start, int N, int* rec, void* stream);
 /* tile_begin/tile_count: restrict the update to 128-item tiles [tile_begin, tile_begin+tile_count) (row-sharded table
  * update under data parallelism; tile_count < 0 = all tiles).  B/Bp then describe the GLOBAL batch. */
 int ader_fused_bucket_gran(void);

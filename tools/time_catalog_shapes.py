@@ -1,5 +1,5 @@
 """Per-rank kernel times of the catalog-sharded step at W = 2, 4, 8 shapes, emulated on one GPU without communication:
-ader_lbf_fwd_shard over N/W items for W*512 batch rows, ader_lbf_bwd_adam over the N/W-row shard for W*512 rows (dev tool)."""
+ader_lbf_fwd_shard over N/W items for W*512 batch rows, ader_tab_update over the N/W-row shard for W*512 rows (dev tool)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -37,9 +37,9 @@ for W in (1, 2, 4, 8):
     seq = torch.randint(1, N + 1, (B * T // W,), generator=g, dtype=torch.int32).to(dev)     # rows this shard receives
     lab = torch.randint(1, N + 1, (B,), generator=g, dtype=torch.int32).to(dev)
     gsrc = torch.randn(seq.numel(), H, generator=g).to(dev) * 1e-3
-    ids, order, sp_start, tids, torder, tg_start = eng._sparse_lists(seq, lab, N)
+    ids, order, sp_start, tids, torder, tg_start, tmeta = eng._sparse_lists(seq, lab, N)
     tiles = S // 128
-    t_upd = timed(lambda: call("ader_lbf_bwd_adam", ptr(rep_bf), ptr(eng.shadow), N, B, B, H, N, ptr(off), ptr(ids), ptr(order),
+    t_upd = timed(lambda: call("ader_tab_update_sh", ptr(rep_bf), ptr(eng.shadow), N, B, B, H, N, ptr(off), ptr(ids), ptr(order),
                                ptr(sp_start), ids.numel(), ptr(gsrc), 12.2, ptr(tids), ptr(torder), ptr(tg_start), tids.numel(),
-                               ptr(wrow), ptr(eng.theta), ptr(eng.adam_m), ptr(eng.adam_v), 1e-4, 0.9, 0.999, 1e-8, 0, tiles, st))
+                               ptr(wrow), ptr(eng.theta), ptr(eng.adam_m), ptr(eng.adam_v), 1e-4, 0.9, 0.999, 1e-8, 0, tiles, None, st))
     print("W=%d  rows %4d  shard %7d items:  logits fwd %7.1f us   table update %7.1f us" % (W, B, S, t_fwd, t_upd))
