@@ -31,6 +31,32 @@ __global__ __launch_bounds__(256) void k_lbf_prep(const float* __restrict__ rep,
     rep_bf[i] = (bf16)((b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f);
 }
 
+// The same for the padded row layout of a distilled step: rows [0, n_train) then rows [kd_row0, kd_row0 + n_ex) of rep_bf come from
+// the compact rep [n_train + n_ex, H]; everything else is zero.  Also fills the per-row info of that layout: label (0 for KD and
+// padding rows), loss weight, teacher row (-1: none) and the teacher's log-sum-exp in the log2 domain.
+__global__ __launch_bounds__(256) void k_lbf_prep_kd(const float* __restrict__ rep, bf16* __restrict__ rep_bf, int n_train, int n_ex,
+                                                     int kd_row0, int Bp, int H, const int* __restrict__ pos,
+                                                     const int* __restrict__ ex_trow, const float* __restrict__ tlse_all, float w_train,
+                                                     float w_ex, int* __restrict__ lab, float* __restrict__ wrow, int* __restrict__ trow,
+                                                     float* __restrict__ tlse2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * LDR) return;
+    const int b = i / LDR, c = i - b * LDR;
+    int src = -1;
+    if (b < n_train) src = b;
+    else if (b >= kd_row0 && b - kd_row0 < n_ex) src = n_train + (b - kd_row0);
+    rep_bf[i] = (bf16)((src >= 0 && c < H) ? rep[(size_t)src * H + c] : 0.0f);
+    if (c == 0) {
+        int l = 0, tr = -1; float w = 0.0f, tl = 0.0f;
+        if (b < n_train) { l = pos[b]; w = (l > 0) ? w_train : 0.0f; }
+        else if (src >= 0) {
+            tr = ex_trow[b - kd_row0];
+            if (tr >= 0) { w = w_ex; tl = tlse_all[tr] * LOG2E; } else tr = -1;
+        }
+        lab[b] = l; wrow[b] = w; trow[b] = tr; tlse2[b] = tl;
+    }
+}
+
 // bf16 shadow of the fp32 master table: shadow[row][0:H] = bf16(emb[row][0:H]), row stride LDR (336 B), padding zero.
 // The logit GEMMs stream this copy (16-B pieces, LDS image == memory image); ader_adam_step keeps it in sync.
 __global__ __launch_bounds__(256) void k_lbf_shadow(const float* __restrict__ emb, bf16* __restrict__ shadow, size_t rows, int H) {
@@ -51,7 +77,20 @@ struct LbfArgs {
     float* pm; float* pl; float* pO;    // [ranges][Bp], [ranges][Bp], [ranges][Bp][HP]
     const float* off;           // [Bp] log2(w_b) - lse2_b
     float* demb1;               // gradient row of item 1
+    // distilled (KD) rows, ADER.py:132-137: rows [kd_row0, Bp) (kd_row0 % 128 == 0; = Bp: none) are exemplar rows whose softmax
+    // runs over the first Np items only and whose target is softmax(teacher row)
+    int kd_row0, Np;
+    int n_train, n_ex;          // valid rows: [0, n_train) and [kd_row0, kd_row0 + n_ex); compact row of b >= kd_row0: n_train + b - kd_row0
+    const float* teacher; long ldt;     // teacher logits [*, ldt] fp32, row trow[b] for batch row b
+    const int* trow;            // [Bp] teacher row of a KD row (-1: padding)
+    const float* tlse2;         // [Bp] log2-domain log-sum-exp of the teacher row over [0, Np)
+    float* pO2;                 // [ranges][Bp - kd_row0][HP] teacher readout partials: sum_j softmax(t)_j * E_j
 };
+
+static inline void lbf_no_kd(LbfArgs& a) {
+    a.kd_row0 = a.Bp; a.Np = 0; a.n_train = a.B; a.n_ex = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
+    a.pO2 = nullptr;
+}
 
 #define FB 32                      // items per streamed block
 #define PCS_ROW (LDR * 2 / 16)     // 16-byte pieces per shadow row (21)
@@ -59,31 +98,7 @@ struct LbfArgs {
 #define PPT 3                      // pieces per thread per block (256*3 >= 672)
 #define RD 3                       // register ring depth: table blocks in flight per workgroup
 
-__global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* E_l = (bf16*)smem_raw;                       // [2][FB][LDR]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int nchunk = a.Bp >> 7;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int range = xcd + 8 * (slot / nchunk), bc = slot % nchunk;
-    if (range >= a.ranges) return;
-    const int N = a.N;
-    const int nblk = (N + FB - 1) / FB;
-    const int per = (nblk + a.ranges - 1) / a.ranges;
-    const int blk_begin = range * per, blk_end = min(nblk, blk_begin + per);
-    const int nb_blocks = max(0, blk_end - blk_begin);
-    const int b0 = bc * 128 + wave * 32;
-    bf16x8 bfrag[10];
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks) bfrag[ks] = *(const bf16x8*)(a.rep_bf + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
-    f32x16 O[5];
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
-    uint4 ring[RD][PPT];
+// Streaming of 32-item table blocks: global -> register ring (RD blocks in flight) -> double-buffered LDS tile.
 #define LBF_LOAD(slot_, blk_)                                                                            \
     {                                                                                                    \
         const uint4* src_ = (const uint4*)(a.sh1 + (size_t)(blk_) * FB * LDR);                           \
@@ -102,6 +117,116 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
             if (idx_ < PCS_BLK) dst_[idx_] = ring[slot_][j];                                             \
         }                                                                                                \
     }
+
+// Teacher readout of 128 KD rows over one item range:  O2[b,:] = sum_j softmax(teacher_b)_j * E_j  (j < Np), accumulated on the
+// matrix cores exactly like the softmax-weighted readout of the forward (probabilities as the A operand, the table block read
+// k-major from LDS).  With it the distillation term needs no second softmax pass:  sum_j pt_j * s_j = rep . O2  and
+// dRep = w (O1/l - O2)  (ADER.py:135-137).  Partials go to pO2 [range][kd row][HP].
+__device__ __forceinline__ void lbf_teacher_readout(const LbfArgs& a, bf16* E_l, int range, int b0, int blk_begin, int nb_blocks,
+                                                    int Np) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    f32x16 O[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    const int tr = a.trow[b0 + r];
+    const float tl2 = a.tlse2[b0 + r];
+    const float* trp = a.teacher + (size_t)(tr < 0 ? 0 : tr) * a.ldt;
+    const bool vec = ((a.ldt & 3) == 0) && (((uintptr_t)a.teacher & 15) == 0);
+    // teacher logits of this lane's batch row for its 16 items of a block (4 runs of 4 consecutive items)
+#define LBF_TLOAD(t_, blk_)                                                                              \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
+        const int it = (blk_) * FB + 8 * g + 4 * hh;                                                     \
+        if (vec && it + 3 < Np) {                                                                        \
+            const float4 v = *(const float4*)(trp + it);                                                 \
+            t_[4 * g] = v.x; t_[4 * g + 1] = v.y; t_[4 * g + 2] = v.z; t_[4 * g + 3] = v.w;              \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) t_[4 * g + k] = (it + k < Np) ? trp[it + k] : -INFINITY; \
+        }                                                                                                \
+    }
+    uint4 ring[RD][PPT];
+    float tc[16], tn[16];
+#pragma unroll
+    for (int s_ = 0; s_ < RD; ++s_) if (s_ < nb_blocks) LBF_LOAD(s_, blk_begin + s_);
+    if (nb_blocks > 0) LBF_TLOAD(tc, blk_begin);
+    int cur = 0, i = 0;
+    while (i < nb_blocks) {
+#pragma unroll
+        for (int s_ = 0; s_ < RD; ++s_) {
+            if (i >= nb_blocks) break;                  // workgroup-uniform
+            const int blk = blk_begin + i;
+            const int i0 = blk * FB;
+            LBF_STORE(s_, cur);
+            if (i + RD < nb_blocks) LBF_LOAD(s_, blk + RD);
+            if (i + 1 < nb_blocks) { LBF_TLOAD(tn, blk + 1); }
+            __syncthreads();
+            const bf16* Eb = E_l + cur * FB * LDR;
+            f32x16 S;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // reg j of lane (r, hh) = item i0 + acc_row(j, hh) = i0 + 8 (j >> 2) + 4 hh + (j & 3): tc[] is in that order
+                const float x = (tr >= 0) ? __builtin_amdgcn_exp2f(fmaf(tc[j], LOG2E, -tl2)) : 0.0f;
+                S[j] = (i0 + acc_row(j, hh) < Np) ? x : 0.0f;
+            }
+            const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const bf16* base = Eb + (4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
+                const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
+                const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
+                bf16x8 b0v, b1v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
+                O[nb] = mfma_bf16(pa0, b0v, O[nb]);
+                O[nb] = mfma_bf16(pa1, b1v, O[nb]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tc[j] = tn[j];
+            cur ^= 1;
+            ++i;
+        }
+    }
+    float* o = a.pO2 + ((size_t)range * (a.Bp - a.kd_row0) + (b0 - a.kd_row0)) * HP;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r] = O[nb][j];
+}
+
+__global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* E_l = (bf16*)smem_raw;                       // [2][FB][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    // chunks: Bp/128 softmax chunks, then one TEACHER-READOUT chunk per 128 KD rows (same item ranges, same XCD grouping, so
+    // the table blocks they stream are shared through L2)
+    const int nsm = a.Bp >> 7, nkd = (a.Bp - a.kd_row0) >> 7, nchunk = nsm + nkd;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot / nchunk);
+    int bc = slot % nchunk;
+    if (range >= a.ranges) return;
+    const bool readout = bc >= nsm;
+    if (readout) bc = (a.kd_row0 >> 7) + (bc - nsm);
+    const int N = (bc * 128 >= a.kd_row0) ? a.Np : a.N;              // columns of this chunk's softmax
+    const int nblk_all = (a.N + FB - 1) / FB;                         // ranges partition the blocks of the whole catalog
+    const int per = (nblk_all + a.ranges - 1) / a.ranges;
+    const int blk_begin = range * per, blk_end = min((N + FB - 1) / FB, blk_begin + per);
+    const int nb_blocks = max(0, blk_end - blk_begin);
+    const int b0 = bc * 128 + wave * 32;
+    if (readout) { lbf_teacher_readout(a, E_l, range, b0, blk_begin, nb_blocks, N); return; }
+    bf16x8 bfrag[10];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) bfrag[ks] = *(const bf16x8*)(a.rep_bf + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
+    f32x16 O[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    uint4 ring[RD][PPT];
 #pragma unroll
     for (int s_ = 0; s_ < RD; ++s_) if (s_ < nb_blocks) LBF_LOAD(s_, blk_begin + s_);
     int cur = 0, i = 0;
@@ -193,10 +318,12 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
     __shared__ float sM, sL;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int R = a.ranges, H = a.H;
-    if (b >= a.B) {                                  // padding rows: no loss, no gradient
+    const bool kd = b >= a.kd_row0;
+    if (kd ? (b - a.kd_row0 >= a.n_ex) : (b >= a.n_train)) {     // padding rows: no loss, no gradient
         if (tid == 0) { lse[b] = 0.0f; rowloss[b] = 0.0f; off[b] = -INFINITY; }
         return;
     }
+    const int bc_ = kd ? a.n_train + (b - a.kd_row0) : b;        // row of the compact [n_train + n_ex, H] tensors (rep_f, drep)
     float m = -INFINITY;
     for (int i = tid; i < R; i += 640) m = fmaxf(m, a.pm[(size_t)i * a.Bp + b]);
     red[tid] = m;
@@ -240,11 +367,17 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
     float part = 0.0f, et = 0.0f;
     if (tid < H) {
         oh = ((red[tid] + red[160 + tid]) + red[320 + tid]) + red[480 + tid];
-        if (t >= 0) {                                // target logit with the same bf16-rounded operands as the MFMA path
-            if (X3) { et = emb1_f[(size_t)t * H + tid]; part = rep_f[(size_t)b * H + tid] * et; }
+        if (kd) {
+            // distilled row: the target "row" is the teacher readout O2 = sum_j softmax(t)_j E_j (range partials summed in fixed
+            // order) and  sum_j pt_j s_j = rep . O2  with the operands the MFMA path multiplied
+            const int Bk = a.Bp - a.kd_row0;
+            for (int i = 0; i < R; ++i) et += a.pO2[((size_t)i * Bk + (b - a.kd_row0)) * HP + tid];
+            part = (X3 ? rep_f[(size_t)bc_ * H + tid] : (float)a.rep_bf[(size_t)b * LDR + tid]) * et;
+        } else if (t >= 0) {                         // target logit with the same bf16-rounded operands as the MFMA path
+            if (X3) { et = emb1_f[(size_t)t * H + tid]; part = rep_f[(size_t)bc_ * H + tid] * et; }
             else { et = (float)a.sh1[(size_t)t * LDR + tid]; part = (float)a.rep_bf[(size_t)b * LDR + tid] * et; }
         }
-        drep[(size_t)b * H + tid] = w * (oh / L - et);
+        drep[(size_t)bc_ * H + tid] = w * (oh / L - et);
     }
     __syncthreads();
     red[tid] = part;
@@ -254,7 +387,7 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
         for (int k = 0; k < H; ++k) s_lab += red[k];
         const float z = lse2 / LOG2E;
         lse[b] = z;
-        rowloss[b] = (t >= 0) ? w * (z - s_lab) : 0.0f;
+        rowloss[b] = (t >= 0 || kd) ? w * (z - s_lab) : 0.0f;
         off[b] = (w > 0.0f) ? log2f(w) - lse2 : -INFINITY;
     }
 }
@@ -581,11 +714,13 @@ int ader_lbf_shadow_refresh(const float* emb, void* shadow, size_t rows, int H, 
 }
 
 int ader_lbf_ranges(int N, int Bp) {
+    // item ranges per 128-row chunk: a multiple of 8 (blocks b and b + 8 share an XCD: the chunks of a range are placed on one),
+    // as many as keep ranges * chunks within the 512 resident workgroups (2 per CU), at least one 32-item block each
     const int nblk = (N + FB - 1) / FB;
     const int nchunk = Bp / 128;
-    int target = 512 / (nchunk < 1 ? 1 : nchunk);
-    int r = 8;
-    while (r * 2 <= target && r * 2 <= nblk) r *= 2;
+    int r = (512 / (nchunk < 1 ? 1 : nchunk)) / 8 * 8;
+    if (r > (nblk + 7) / 8 * 8) r = (nblk + 7) / 8 * 8;
+    if (r < 8) r = 8;
     return r;
 }
 
@@ -608,7 +743,7 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     if (N > item_num) return -2;
     a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = ader_lbf_ranges(N, Bp);
-    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, (const float*)nullptr,
@@ -617,6 +752,46 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// Forward of a DISTILLED step (ADER.py:108-137) on the bf16 flash path: n_train one-hot rows (labels pos, weight w_train) and n_ex
+// exemplar rows distilled against softmax(teacher[ex_trow[e], :Np]) (weight w_ex = lambda / n_ex), student softmax over the first Np
+// items only.  rep is the compact [n_train + n_ex, H] tensor (exemplar rows last, main.py:229); inside, rows are laid out
+// [train rows padded to 128 | exemplar rows padded to 128] (Bp = both paddings; kd_row0 = first exemplar row): lab / wrow / trow /
+// tlse2 / lse / off / rowloss are [Bp] in THAT layout (they feed ader_tab_update_sh_kd), drep is compact.  tlse_all[r] = natural
+// log-sum-exp of teacher row r over [0, Np).  Scratch as ader_lbf_fwd plus pO2: ranges * (Bp - kd_row0) * 160 floats.
+int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
+                    int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all, float w_train,
+                    float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_bf, float* pm, float* pl, float* pO,
+                    float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+    if (n_train + n_ex <= 0) return 0;
+    if (Bp % 128 != 0 || kd_row0 % 128 != 0 || n_train > kd_row0 || kd_row0 + n_ex > Bp || H > HP || (H & 1) || H < 2 || N > item_num ||
+        Np > N || Np < 1) return -2;
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LbfArgs a;
+    a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
+    a.rep_bf = (const bf16*)rep_bf; a.B = n_train + n_ex; a.Bp = Bp; a.H = H; a.N = N;
+    const int nchunk = Bp / 128 + (Bp - kd_row0) / 128;
+    a.ranges = ader_lbf_ranges(N, nchunk * 128);
+    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    a.kd_row0 = kd_row0; a.Np = Np; a.n_train = n_train; a.n_ex = n_ex; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
+    a.pO2 = pO2;
+    hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, n_train, n_ex, kd_row0, Bp, H,
+                       pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
+    hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * nchunk), dim3(256), kFwdLds, st, a);
+    hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
+                       (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+// ranges used by ader_lbf_fwd_kd (scratch sizing): pm / pl: R*Bp, pO: R*Bp*160, pO2: R*(Bp-kd_row0)*160
+int ader_lbf_ranges_kd(int N, int Bp, int kd_row0) { return ader_lbf_ranges(N, (Bp / 128 + (Bp - kd_row0) / 128) * 128); }
 
 // rep fp32 [B,H] -> rep_bf [Bp,168] bf16 (zero padded): the operand layout of the bf16 logit kernels
 int ader_lbf_prep(const float* rep, void* rep_bf, int B, int Bp, int H, void* stream) {
@@ -648,7 +823,7 @@ int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int
     a.sh1 = (const bf16*)shadow + (size_t)LDR * (1 + item_begin); a.vrows = item_num - item_begin; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = Bp; a.Bp = Bp; a.H = H; a.N = n_loc;
     a.ranges = n_loc > 0 ? ader_lbf_ranges(n_loc, Bp) : 0;
-    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     if (a.ranges > 0) hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine_partial, dim3(Bp), dim3(640), 0, st, a, part);
     HIP_LAUNCH_CHECK();
@@ -704,7 +879,7 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
     x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
     LbfArgs a;
     a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
-    a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H);
     if (variant) hipLaunchKernelGGL((k_lx3_fwd<3, 1>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);

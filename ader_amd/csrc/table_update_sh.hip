@@ -7,7 +7,7 @@
 #include "lbf_common.h"
 #include "../../include/ader_hip.h"
 
-struct LbfArgs {
+struct ShArgs {
     int tile_off;               // first 128-item tile handled by this launch (row-sharded table update)
     const bf16* sh1;            // bf16 shadow of the table, row of item 1: rows of LDR elements (336 B), cols >= H zero
     int vrows;                  // shadow rows available from sh1 (= item_num)
@@ -16,6 +16,10 @@ struct LbfArgs {
     float* pm; float* pl; float* pO;    // [ranges][Bp], [ranges][Bp], [ranges][Bp][HP]
     const float* off;           // [Bp] log2(w_b) - lse2_b
     float* demb1;               // gradient row of item 1
+    // KD rows (ADER.py:132-137): batch rows [kd_row0, Bp) are distilled exemplar rows: dlogit = w (softmax(s[:Np]) - softmax(t)),
+    // zero for items >= Np.  kd_row0 % 128 == 0; = Bp: none
+    int kd_row0, Np;
+    const float* teacher; long ldt; const int* trow; const float* tlse2;     // as in ader_lbf_fwd_kd ([Bp] arrays)
 };
 #define PCS_ROW (LDR * 2 / 16)     // 16-byte pieces per shadow row (21)
 
@@ -36,12 +40,14 @@ struct FuseArgs128 {
 #endif
 
 
-template <bool ADAM, bool EXTRA = false>
-__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs128 f) {
+template <bool ADAM, bool EXTRA = false, bool KD = false>
+__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(ShArgs a, FuseArgs128 f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
     float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
     int* meta_l = (int*)(off_l + a.Bp);      // ADAM: per (half, list): [k0, k1, 8 x (id, row)] = 18 ints, 4 lists (SP_PRE entries prefetched)
+    float* toff_l = (float*)(meta_l + 4 * 18);              // KD: [Bp - kd_row0] log2(w_b) - tlse2_b (-inf: no teacher term)
+    int* trow_l = (int*)(toff_l + (a.Bp - a.kd_row0));      // KD: [Bp - kd_row0] teacher row (0 for padding rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int H = a.H, N = a.N;
@@ -57,6 +63,14 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs128 f)
         }
     }
     for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+    if (KD) {
+        for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
+            const int b = a.kd_row0 + i, tr = a.trow[b];
+            const float w = f.wrow[b];
+            toff_l[i] = (tr >= 0 && w > 0.0f) ? log2f(w) - a.tlse2[b] : -INFINITY;
+            trow_l[i] = tr < 0 ? 0 : tr;
+        }
+    }
     if (ADAM && tid < 4) {
         // the sparse lists of the two half-tiles (bucket bounds and the first entries) are fetched now, under the GEMM phase:
         // three dependent global round trips less between the GEMM and the streaming update
@@ -123,6 +137,14 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs128 f)
 #pragma unroll 1
         for (int bb = 0; bb < 2; ++bb) {
             const int b0 = c * 64 + bb * 32;
+            // KD rows: this lane's 16 teacher logits (item it0 + r, batch rows b0 + acc_row(j, hh)), requested ahead of the MFMAs
+            float tv[KD ? 16 : 1];
+            const bool kdc = KD && b0 >= a.kd_row0;               // (wave-uniform: chunks do not straddle kd_row0)
+            if (kdc && it0 + r < a.Np) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    tv[KD ? j : 0] = a.teacher[(size_t)trow_l[b0 - a.kd_row0 + acc_row(j, hh)] * a.ldt + it0 + r];
+            }
             f32x16 S;
 #pragma unroll
             for (int j = 0; j < 16; ++j) S[j] = 0.0f;
@@ -139,6 +161,16 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs128 f)
                 S[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 1], LOG2E, o4.y));
                 S[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 2], LOG2E, o4.z));
                 S[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 3], LOG2E, o4.w));
+            }
+            if (kdc) {          // dlogit of a distilled row: w (softmax(s[:Np]) - softmax(t)) for items < Np, 0 beyond
+                if (it0 + r < a.Np) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        S[j] -= __builtin_amdgcn_exp2f(fmaf(tv[KD ? j : 0], LOG2E, toff_l[b0 - a.kd_row0 + acc_row(j, hh)]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) S[j] = 0.0f;
+                }
             }
             const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
 #pragma unroll
@@ -296,33 +328,38 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(LbfArgs a, FuseArgs128 f)
     }
 }
 
-static size_t bwd_lds(int Bp) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 4 * 18 * sizeof(int); }
+static size_t bwd_lds(int Bp, int Bk) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 4 * 18 * sizeof(int) + (size_t)Bk * 8; }
 
 extern "C" {
 
 // Fused bf16-mode table update over 128-row tiles (see ader_tab_update for the arguments; here the sorted lists are addressed
 // through their 64-id bucket offsets sp_start / tg_start directly, and `shadow` is both the GEMM operand and rewritten).
-int ader_tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
-                       const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
-                       const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
-                       float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
-                       int tile_count, const float* extra_grad, void* stream) {
+static int tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                         const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
+                         const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
+                         float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                         int tile_count, const float* extra_grad, int kd_row0, int Np, const float* teacher, long ldt, const int* trow,
+                         const float* tlse2, void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || !shadow) return -2;
-    static bool f = false;
+    const bool kd = kd_row0 < Bp;
+    if (kd && (kd_row0 % 128 != 0 || extra_grad || !teacher || !trow || !tlse2 || Np < 1 || Np > N)) return -2;
     static int lds_set = 0;
-    const size_t lds = bwd_lds(Bp);
-    if (!f || (int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = bwd_lds(Bp, kd ? Bp - kd_row0 : 0);
+    if ((int)lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        f = true; lds_set = (int)lds;
+        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = (int)lds;
     }
-    LbfArgs a;
+    ShArgs a;
     a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = B; a.Bp = Bp; a.H = H; a.N = N; a.ranges = 0;
     a.pm = a.pl = a.pO = nullptr; a.off = off; a.demb1 = nullptr;
+    a.kd_row0 = kd ? kd_row0 : Bp; a.Np = Np; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
     FuseArgs128 fa;
     fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
     fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
@@ -336,10 +373,34 @@ int ader_tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, in
     if (te > all) te = all;
     if (te <= tb) return 0;
     a.tile_off = tb;
-    if (extra_grad) hipLaunchKernelGGL((k_lbf_bwd_de<true, true>), dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
-    else hipLaunchKernelGGL((k_lbf_bwd_de<true, false>), dim3(te - tb), dim3(256), lds, (hipStream_t)stream, a, fa);
+    hipStream_t st = (hipStream_t)stream;
+    if (kd) hipLaunchKernelGGL((k_lbf_bwd_de<true, false, true>), dim3(te - tb), dim3(256), lds, st, a, fa);
+    else if (extra_grad) hipLaunchKernelGGL((k_lbf_bwd_de<true, true, false>), dim3(te - tb), dim3(256), lds, st, a, fa);
+    else hipLaunchKernelGGL((k_lbf_bwd_de<true, false, false>), dim3(te - tb), dim3(256), lds, st, a, fa);
     HIP_LAUNCH_CHECK();
     return 0;
+}
+
+int ader_tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, int Bp, int H, int N, const float* off,
+                       const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
+                       const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow, float* emb,
+                       float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                       int tile_count, const float* extra_grad, void* stream) {
+    return tab_update_sh(rep_bf, shadow, item_num, B, Bp, H, N, off, sp_ids, sp_rows, sp_start, n_sp, sp_src, sp_scale, tg_ids, tg_rows,
+                         tg_start, n_tg, wrow, emb, adam_m, adam_v, lr_t, beta1, beta2, eps, tile_begin, tile_count, extra_grad, Bp, 0,
+                         nullptr, 0, nullptr, nullptr, stream);
+}
+
+// The same update for a DISTILLED step (ADER.py:132-137): batch rows [kd_row0, Bp) of the padded layout of ader_lbf_fwd_kd are
+// exemplar rows whose dlogit is w (softmax(s[:Np]) - softmax(teacher row)); wrow / off / trow / tlse2 as that call left them.
+int ader_tab_update_sh_kd(const void* rep_bf, void* shadow, int item_num, int Bp, int kd_row0, int H, int N, int Np, const float* off,
+                          const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp, const float* sp_src, float sp_scale,
+                          const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg, const float* wrow,
+                          const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
+                          float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream) {
+    return tab_update_sh(rep_bf, shadow, item_num, Bp, Bp, H, N, off, sp_ids, sp_rows, sp_start, n_sp, sp_src, sp_scale, tg_ids, tg_rows,
+                         tg_start, n_tg, wrow, emb, adam_m, adam_v, lr_t, beta1, beta2, eps, 0, -1, nullptr, kd_row0, Np, teacher, ldt,
+                         trow, tlse2, stream);
 }
 
 }  // extern "C"

@@ -225,6 +225,7 @@ class Engine:
         _p = os.environ.get("ADER_DP_PACK")
         self.dp_pack = (self.dp_world >= 8) if _p is None else (_p == "1")
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
+        self.kd_fast = True      # ... bf16 mode: exemplar rows on the bf16 flash path too (teacher readout + fused KD update)
         self._table_stale = False
         self._mv_sharded = False   # dp: Adam m/v of the table are current only for the rank's own rows (see _gather_if_sharded)
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
@@ -592,15 +593,7 @@ class Engine:
         call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos), ptr(ex_trow), n_ex, N, Np, float(w_train), float(w_ex), Bp,
              ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
         if teacher is not None and n_ex > 0:
-            # log-sum-exp of the teacher rows: the teacher logits of an exemplar are fixed for a whole period, so the LSE of
-            # every stored row is computed once per teacher tensor and gathered per step
-            key = (teacher.data_ptr(), tuple(teacher.shape), teacher._version)
-            if getattr(self, "_tlse_key", None) != key:
-                E_all = teacher.shape[0]
-                allrows = torch.arange(E_all, dtype=torch.int32, device=self.device)
-                self._tlse_all = torch.empty(E_all, dtype=torch.float32, device=self.device)
-                call("ader_row_lse", ptr(teacher), teacher.stride(0), Np, ptr(allrows), E_all, ptr(self._tlse_all), st)
-                self._tlse_key = key
+            self._teacher_lse(teacher, Np)
             tlse.zero_()
             tlse[n_train:n_train + n_ex] = self._tlse_all[trow[n_train:n_train + n_ex].long()]
             tptr, ldt = ptr(teacher), teacher.stride(0)
@@ -608,6 +601,18 @@ class Engine:
             tlse.zero_()
             tptr, ldt = None, 0
         return Bp, (ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), ptr(tlse), tptr, ldt)
+
+    def _teacher_lse(self, teacher, Np):
+        """Natural log-sum-exp of every stored teacher row over its Np columns (self._tlse_all [E_all]).  The teacher logits of an
+        exemplar are fixed for a whole period, so this runs once per teacher tensor and is gathered per step."""
+        key = (teacher.data_ptr(), tuple(teacher.shape), teacher._version)
+        if getattr(self, "_tlse_key", None) != key:
+            E_all = teacher.shape[0]
+            allrows = torch.arange(E_all, dtype=torch.int32, device=self.device)
+            self._tlse_all = torch.empty(E_all, dtype=torch.float32, device=self.device)
+            call("ader_row_lse", ptr(teacher), teacher.stride(0), Np, ptr(allrows), E_all, ptr(self._tlse_all), self._stream())
+            self._tlse_key = key
+        return self._tlse_all
 
     # ---------------------------------------------------------------------------------------- train step
     def loss_and_grad(self, seq, pos, max_item, *, ex_pos=None, teacher=None, ex_trow=None, lambda_=0.0, rate=0.0,
@@ -643,11 +648,19 @@ class Engine:
         # exemplar rows the exact-f32 kernels; their table gradient enters the fused update as a dense extra term
         split_kd = bool(self.lfast and teacher is not None and n_ex > 0 and n_train > 0 and _defer_table
                         and N >= self._grad_hi and self.dp_world == 1 and self.kd_split)
-        use_bf16 = self.lfast and (teacher is None or split_kd)
+        # ... or, bf16 mode (default): ALL rows on the flash path -- the exemplar rows as their own 128-row chunks whose softmax runs
+        # over the first Np items, with the teacher term as a second readout (forward) and a subtraction inside the fused update
+        kd_fast = bool(split_kd and not self.lx3 and self.kd_fast
+                       and ((n_train + 127) // 128 + (n_ex + 127) // 128) * 128 <= self.MAX_ROWS)
+        if kd_fast:
+            split_kd = False
+        use_bf16 = self.lfast and (teacher is None or split_kd or kd_fast)
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
         self._deferred = None
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
+        if kd_fast:
+            return self._loss_and_grad_kd_fast(seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex)
         if defer and self.dp_world == 1:
             # the id-bucketed lists of the fused table update need only the inputs: build them on a side stream, under the
             # logit kernels (the one-launch forward owns every CU's LDS; the logit kernels leave room for it)
@@ -721,6 +734,37 @@ class Engine:
                                   lab=lab, wrow=wrow, extra=extra)
         return self.loss
 
+    def _loss_and_grad_kd_fast(self, seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex):
+        """Distilled step (ADER.py:108-137) entirely on the bf16 flash kernels.  Rows are laid out [train rows padded to 128 |
+        exemplar rows padded to 128]; ader_lbf_fwd_kd gives the student log-sum-exp of every row (exemplar rows: over the first Np
+        items), the softmax-weighted readout O1 and, for exemplar rows, the teacher readout O2 = sum_j softmax(t)_j E_j, from which
+        loss = w (lse - rep.O2) and dRep = w (O1/l - O2); the table gradient w (softmax(s) - softmax(t))^T rep is formed inside the
+        fused update (ader_tab_update_sh_kd), which reads the teacher tile a second time.  Nothing [rows, N]-sized is materialised."""
+        st = self._stream()
+        H = self.H
+        B = n_train + n_ex
+        Bt, Bk = (n_train + 127) // 128 * 128, (n_ex + 127) // 128 * 128
+        Bp = Bt + Bk
+        tlse_all = self._teacher_lse(teacher, Np)
+        lab, trow = self.buf("kf_lab", (Bp,), torch.int32), self.buf("kf_trow", (Bp,), torch.int32)
+        wrow, tlse2 = self.buf("kf_w", (Bp,)), self.buf("kf_tlse2", (Bp,))
+        R = call("ader_lbf_ranges_kd", N, Bp, Bt)
+        rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
+        pm, pl = self.buf("lbf_pm", (R * Bp,)), self.buf("lbf_pl", (R * Bp,))
+        pO, pO2 = self.buf("lbf_pO", (R * Bp * 160,)), self.buf("lbf_pO2", (R * Bk * 160,))
+        lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
+        drep = self.buf("drep", (B, H))
+        with self._sec("logits_fwd"):
+            call("ader_lbf_fwd_kd", ptr(rep), ptr(self.shadow), self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos), ptr(ex_trow),
+                 ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow), ptr(trow),
+                 ptr(tlse2), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss),
+                 ptr(drep), st)
+        self._lists_async(seq, lab, N)            # one-hot targets in the padded row numbering (label 0 = none)
+        self._grad_hi = max(self._grad_hi, N)
+        dx = self._blocks_backward(seq, drep, True, None)
+        self._deferred = dict(seq=seq, g=dx, B=Bp, Bp=Bp, N=N, rep_bf=rep_bf, rep_lo=None, off=off, lab=lab, wrow=wrow, extra=None,
+                              kd=dict(row0=Bt, Np=Np, teacher=teacher, trow=trow, tlse2=tlse2))
+        return self.loss
 
     def _blocks_backward(self, seq, drep, defer, demb):
         """Backward of the final LayerNorm, the blocks and the prologue from drep [B,H] (gradient of the loss w.r.t. the
@@ -922,7 +966,8 @@ class Engine:
         if self.lists_side_stream:
             torch.cuda.current_stream().wait_stream(self._side)
             for t in out:
-                t.record_stream(torch.cuda.current_stream())
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream())
         return out
 
     def _fused_table_adam(self, lr):
@@ -963,6 +1008,13 @@ class Engine:
                      ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                      ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
                      self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
+            elif D.get("kd"):
+                K = D["kd"]
+                call("ader_tab_update_sh_kd", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["Bp"], K["row0"], H, D["N"], K["Np"],
+                     ptr(D["off"]), ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))),
+                     ptr(tids), ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(K["teacher"]), K["teacher"].stride(0),
+                     ptr(K["trow"]), ptr(K["tlse2"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1, self.beta2,
+                     self.eps, st)
             else:
                 call("ader_tab_update_sh", ptr(D["rep_bf"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"],
                      ptr(D["off"]), ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))),

@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--dp-mode", choices=["catalog", "replicated"], default="catalog",
                     help="N > 1: table rows owned by one rank each (catalog) or replicated with a row-sharded update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32grade", action="store_true", help="skip the float32-grade (x3 logits) companion run")
+    ap.add_argument("--pmc-json", default=None,
+                    help="rocprofv3 PMC summary of THIS command (tools/summarize_profiles.py) to quote roofline.traffic from; "
+                         "without it traffic is null (bench.py never pairs live timings with counters of another run)")
     ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -179,6 +183,51 @@ def main():
     eng.timer = None
     sections = {**sections_all, **sections}          # dominant section: timed-region average; the rest: warmup steps
 
+    # ---- standalone embedding gather (north_star: "rocprof HBM GB/s on the gather"): in the step it is fused into the one-launch
+    # forward, so it is timed here as its own kernel on the same batch (ader_embed_fwd: ids -> x0 = drop(E[ids]*sqrt(H) + P) * mask)
+    gather = None
+    if rank == 0 and not args.no_sections:
+        from ader_amd._lib import call, ptr
+        seq0 = batches[0][0][:B].contiguous()
+        x0 = torch.empty(B * T, H, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(25):
+            if it == 5:
+                a.record()
+            call("ader_embed_fwd", ptr(seq0), eng._pp["emb"], eng._pp["pos"], ptr(x0), B * T, T, H, eng.V, 0x1234, int(0.3 * 2 ** 24),
+                 1.0 / 0.7, 0, ptr(eng.status), st)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / 20 * 1e3
+        gbytes = B * T * (4 + 2 * H * 4) / 1e9                    # ids + one table row read + one row written
+        gather = {"kernel": "k_embed_fwd (standalone)", "us": round(us, 2), "bytes": B * T * (4 + 2 * H * 4),
+                  "GBps": round(gbytes / (us * 1e-6), 1), "frac_hbm": round(gbytes / (us * 1e-6) / HBM_PEAK_GBS, 4),
+                  "note": "25,600 random 600-B rows of a 600 MB table + 15.4 MB written: latency / launch bound at this size"}
+
+    # ---- float32-grade companion (the reference's arithmetic is fp32, ADER.py:91-93): the same step with logits_dtype="x3"
+    f32g = None
+    if world == 1 and args.logits == "bf16" and not args.no_f32grade and not E:
+        del eng
+        torch.cuda.empty_cache()
+        eng3 = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype="x3")
+        for i in range(5 + args.warmup):
+            seq, pos = batches[i % nbatch]
+            eng3.train_step(seq, pos, N, lr, **kw)
+        eng3.timer = SectionTimer(only={"logits_bwd_adam", "logits_fwd"}, every=4)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            seq, pos = batches[i % nbatch]
+            eng3.train_step(seq, pos, N, lr, **kw)
+        sync()
+        dt3 = time.perf_counter() - t0
+        sec3 = eng3.timer.collect()
+        eng3.timer = None
+        f32g = {"ms_per_step": dt3 / args.steps * 1e3, "value": B * args.steps / dt3, "final_loss": float(eng3.loss.item()),
+                "sections_ms": {k: round(v, 4) for k, v in sorted(sec3.items())}}
+        eng = eng3
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         P = eng.P
@@ -202,18 +251,14 @@ def main():
             "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
             "param_allgather": ("hbm", 0.0, HBM_PEAK_GBS),
         }
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
-        # --pmc WRITE_SIZE passes of this same command, gfx950 x2 read correction applied; profiles/*_pmc_hbm.json)
-        pmc_kernel = {"logits_bwd_adam": "k_lbf_bwd_de<true>", "logits_fwd": "k_lbf_fwd", "adam": "k_adam",
-                      "logits_bwd_demb": "k_lbf_bwd_de<false>"}
-        pmc = {}
-        try:
-            import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
-            if files and N == 1_000_000 and B == 512:
-                pmc = json.load(open(files[-1]))["kernels"]
-        except Exception:
-            pmc = {}
+        # HBM traffic of the dominant kernel: only from a PMC summary of THIS command passed with --pmc-json (rocprofv3 separate
+        # --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, gfx950 x2 read correction applied: tools/profile_round.sh); otherwise null
+        pmc_kernel = {"logits_bwd_adam": "k_lbf_bwd_de<true" if args.logits == "bf16" else "k_tab_upd<true, true",
+                      "logits_fwd": "k_lbf_fwd" if args.logits == "bf16" else "k_lx3_fwd", "adam": "k_adam"}
+        pmc, pmc_src = {}, None
+        if args.pmc_json:
+            pmc = json.load(open(args.pmc_json))["kernels"]
+            pmc_src = os.path.relpath(os.path.abspath(args.pmc_json), ROOT)
         roof = None
         if sections:
             if "logits_bwd_adam" in sections:     # the small-parameter Adam launch is not the 7*P*4-byte kernel any more
@@ -227,9 +272,14 @@ def main():
                 ach, unit = amount / sec / 1e9, "GB/s"
             roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                     "traffic": (next((v.get("hbm_bytes") for k_, v in pmc.items()
-                                      if pmc_kernel.get(dom) and k_.startswith(pmc_kernel[dom].rstrip(">"))), None)
+                                      if pmc_kernel.get(dom) and k_.startswith(pmc_kernel[dom])), None)
                                 if unit == "GB/s" else None),
+                    "traffic_source": pmc_src,
                     "ms": sections[dom],
+                    # whole step against SURVEY 8(d)'s compulsory traffic (6.64 GB at cfg-S, unfused accounting) and the HBM peak
+                    "step_bytes": 6.64e9 * (N / 1e6) if (B == 512 and not E) else None,
+                    "step_frac": (6.64e9 * (N / 1e6) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (B == 512 and not E and world == 1) else None,
+                    "gather": gather,
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 leg only
@@ -251,8 +301,18 @@ def main():
                                      if eng.dp_mode == "catalog" else
                                      ("row-sharded table update + all-gather" if (eng.dp_sharded and eng.shadow is not None)
                                       else "dense gradient all-reduce"))),
-                       "precision": ("logit GEMMs bf16 operands / fp32 accumulate+softmax; blocks, optimizer, master weights fp32"
-                                     if args.logits == "bf16" else "fp32 throughout"), "parallelism": "dp%d" % world, "final_loss": loss},
+                       "precision": {"bf16": "logit GEMMs: bf16 operands, fp32 accumulate + softmax; block GEMMs and attention: bf16x3 "
+                                             "(three bf16 MFMAs per product on hi/lo splits, ~2^-16 relative, fp32 accumulate); "
+                                             "LayerNorm, softmax, optimizer, master weights: fp32",
+                                     "x3": "every GEMM bf16x3 (three bf16 MFMAs per product on hi/lo splits, ~2^-16 relative, fp32 "
+                                           "accumulate): float32-grade; LayerNorm, softmax, optimizer, master weights: fp32",
+                                     "f32": "fp32 throughout (f32 MFMA)"}[args.logits],
+                       "parallelism": "dp%d" % world, "final_loss": loss,
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1)},
+            # float32-grade companion of the same step (logits_dtype = x3; reference arithmetic is fp32, ADER.py:91-93)
+            "value_f32grade": f32g["value"] if f32g else None,
+            "ms_per_step_f32grade": f32g["ms_per_step"] if f32g else None,
+            "f32grade": f32g,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

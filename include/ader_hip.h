@@ -201,6 +201,17 @@ int ader_lbf_ranges(int N, int Bp);
 int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int Bp, int H, int N, const int* lab,
                  const float* wrow, void* rep_bf, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss,
                  float* loss, float* drep, void* stream);
+/* Forward of a DISTILLED step (ADER.py:108-137: loss = CE_train + lambda * mean_e(-sum_j softmax(teacher_e)_j log_softmax(
+ * logits_e[:Np])_j)) on the bf16 flash path.  rep: compact [n_train + n_ex, H], exemplar rows last (main.py:229).  Inside, rows are
+ * laid out [train rows padded to 128 | exemplar rows padded to 128] (Bp rows, kd_row0 = first exemplar row): lab / wrow / trow / tlse2
+ * (written here) and lse / off / rowloss are [Bp] in that layout; drep is compact.  ex_trow[e]: row of `teacher` [*, ldt] for
+ * exemplar e; tlse_all[r]: natural log-sum-exp of teacher row r over [0, Np).  w_train = 1/B_train, w_ex = lambda/B_ex.
+ * Scratch: rep_bf Bp*168 bf16; R = ader_lbf_ranges_kd(N, Bp, kd_row0); pm, pl: R*Bp; pO: R*Bp*160; pO2: R*(Bp-kd_row0)*160 floats. */
+int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
+                    int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all,
+                    float w_train, float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_bf, float* pm, float* pl,
+                    float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream);
+int ader_lbf_ranges_kd(int N, int Bp, int kd_row0);
 /* Pieces of ader_lbf_fwd for catalog-sharded data parallelism (each rank holds 1/W of the table rows and streams only
  * those; ADER.py:91-93 with the item axis split across ranks): ader_lbf_prep builds the bf16 operand rows [Bp,168] of the
  * (all-gathered) representations; ader_lbf_fwd_shard returns per batch row the softmax partials {max (log2 domain), sum,
@@ -255,6 +266,14 @@ int ader_tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, in
                        float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start, int n_tg,
                        const float* wrow, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2,
                        float eps, int tile_begin, int tile_count, const float* extra_grad, void* stream);
+/* ... and for a DISTILLED step (ADER.py:132-137): batch rows [kd_row0, Bp) of the padded layout of ader_lbf_fwd_kd are exemplar
+ * rows whose dlogit is w (softmax(s[:Np]) - softmax(teacher row)); wrow / off / trow / tlse2 as that call left them. */
+int ader_tab_update_sh_kd(const void* rep_bf, void* shadow, int item_num, int Bp, int kd_row0, int H, int N, int Np,
+                          const float* off, const int* sp_ids, const int* sp_rows, const int* sp_start, int n_sp,
+                          const float* sp_src, float sp_scale, const int* tg_ids, const int* tg_rows, const int* tg_start,
+                          int n_tg, const float* wrow, const float* teacher, long ldt, const int* trow, const float* tlse2,
+                          float* emb, float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps,
+                          void* stream);
 /* tile_meta: per 64-row tile the list record {k0, k1, first 8 (id, row) entries} x 2 lists, ader_tab_meta_ints(N) ints, built
  * by ader_tab_tile_meta from the bucket offsets sp_start / tg_start (one coalesced read per tile inside the update). */
 int ader_tab_meta_ints(int N);

@@ -542,7 +542,7 @@ def test_split_kd_step_matches_all_f32_kd_step():
     out = []
     for split in (True, False):
         eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
-        eng.kd_split = split
+        eng.kd_split, eng.kd_fast = split, False
         loss = eng.train_step(seq, pos, N, 5e-4, rate=0.3, teacher=teacher, ex_trow=trow, lambda_=0.7)
         torch.cuda.synchronize()
         out.append((float(loss.item()), eng.adam_m.cpu().numpy().copy(), eng.theta.cpu().numpy().copy()))
@@ -552,6 +552,64 @@ def test_split_kd_step_matches_all_f32_kd_step():
     assert nerr(ma[:span], mb[:span]) < 3e-2              # table gradient (m = 0.1 g after one step)
     assert nerr(ma[span:], mb[span:], floor=1e-6) < 3e-2  # every other parameter
     assert np.abs(ta - tb).max() < 1.1e-3                 # one Adam step moves a parameter by at most lr
+
+
+@pytest.mark.parametrize("cfg,n_ex,Np", [(BF16_CFGS[1], 37, 4000), (BF16_CFGS[0], 70, 650), (BF16_CFGS[1], 200, 4321)])
+def test_kd_fast_step_matches_bf16_aware_oracle(cfg, n_ex, Np):
+    """Distilled step with every row on the bf16 flash path (Engine.kd_fast: exemplar rows as their own chunks with the softmax
+    over the first Np items, teacher readout in the forward, teacher term subtracted inside the fused table update).  One step
+    from zero Adam state leaves m = 0.1 g, so the whole gradient is read back from the optimiser state and compared with the
+    oracle evaluated with the same bf16 operand rounding of the logits product (reference: ADER.py:108-137): loss 3e-4, every
+    gradient tensor 6e-3 normalised (as test_bf16_logits_path_matches_bf16_aware_oracle)."""
+    item_num, T, H, L, heads, B, N = cfg
+    rs = np.random.RandomState(5)
+    seq = _seqs(rs, B + n_ex, T, N)
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    pos[0] = N
+    teacher = torch.from_numpy((rs.standard_normal((n_ex + 9, Np)) * 2).astype(np.float32)).cuda()
+    trow = rs.permutation(n_ex + 9)[:n_ex].astype(np.int32)
+    lam = 0.7
+    eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
+    assert eng.kd_fast
+    p64 = _params(eng, torch.float64)
+    eng.global_step = 3
+    loss = eng.train_step(seq, pos, N, 5e-4, rate=0.3, teacher=teacher, ex_trow=trow, lambda_=lam)
+    torch.cuda.synchronize()
+    eng.check_status()
+    assert eng._ws.get("lbf_pO2") is not None                     # the fast path ran (teacher readout scratch exists)
+    mk = relu_masks_of(eng)
+    ol, og = R.loss_and_grads(p64, seq, pos, N, L, heads, training=True, rate=0.3, seed=8, step=3, logits_bf16=True, relu_masks=mk,
+                              ex_logits=teacher.cpu()[trow.astype(np.int64)].double(), lambda_=lam)
+    assert abs(float(loss.item()) - float(ol)) < 3e-4 * max(1.0, abs(float(ol)))
+    for k in eng.layout:
+        g = eng.view(eng.adam_m, k).cpu().numpy() / 0.1            # m = (1 - beta1) g after the first update of a zero state
+        e = nerr(g, og[k].numpy(), floor=1e-4)
+        assert e < 6e-3, (k, e)
+
+
+def test_kd_fast_equals_split_kd():
+    """The all-flash distilled step against the split one (exemplar rows on the exact-f32 KD kernels): same Adam state up to the
+    bf16 rounding of the exemplar rows' logit operands."""
+    item_num, T, H, L, heads, B, N = BF16_CFGS[1]
+    n_ex, Np = 37, 4000
+    rs = np.random.RandomState(12)
+    seq = _seqs(rs, B + n_ex, T, N)
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    teacher = torch.from_numpy(rs.standard_normal((50, Np)).astype(np.float32)).cuda()
+    trow = rs.randint(0, 50, size=n_ex).astype(np.int32)
+    out = []
+    for fast in (True, False):
+        eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
+        eng.kd_fast = fast
+        loss = eng.train_step(seq, pos, N, 5e-4, rate=0.3, teacher=teacher, ex_trow=trow, lambda_=0.7)
+        torch.cuda.synchronize()
+        out.append((float(loss.item()), eng.adam_m.cpu().numpy().copy(), eng.theta.cpu().numpy().copy()))
+    (la, ma, ta), (lb, mb, tb) = out
+    assert abs(la - lb) < 5e-3 * abs(lb)
+    span = (item_num + 1) * H
+    assert nerr(ma[:span], mb[:span]) < 3e-2
+    assert nerr(ma[span:], mb[span:], floor=1e-6) < 3e-2
+    assert np.abs(ta - tb).max() < 1.1e-3
 
 
 @pytest.mark.parametrize("ld", ["bf16", "x3"])
