@@ -15,6 +15,7 @@ _DROP = [U, U, F, U]
 _SIGS = {
     "ader_embed_fwd": [P, P, P, P, I, I, I, I] + _DROP + [P, P],
     "ader_embed_bwd": [P, P, P, P, I, I, I, I] + _DROP + [P],
+    "ader_scatter_rows": [P, P, I, I, I, F, P, P],
     "ader_ln_fwd": [P, L, P, L, P, P, P, P, P, P, I, I, P],
     "ader_ln_bwd_slabs": [I],
     "ader_ln_bwd": [P, L, P, L, P, P, P, P, L, P, L, P, P, P, I, I, P],

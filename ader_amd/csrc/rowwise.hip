@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void k_embed_bwd_rows(const int* __restrict__ 
     }
 }
 
+// demb[ids[p]] += rows[p] * scale for p < n (ids 0 / out of range skipped): the scatter half of k_embed_bwd on its own, for rows
+// whose mask / dropout factors are already applied -- the data-parallel dense path adds the input-embedding gradient rows of
+// ALL ranks after the table gradient's all-reduce (float atomics, as k_embed_bwd).
+__global__ __launch_bounds__(256) void k_scatter_rows(const int* __restrict__ ids, const float* __restrict__ rows,
+                                                      float* __restrict__ demb, int n, int H, int V, float scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    const int id = ids[row];
+    if (id <= 0 || id >= V) return;
+    const float* g = rows + (size_t)row * H;
+    float* de = demb + (size_t)id * H;
+    for (int c = lane; c < H; c += 64) atomicAdd(de + c, g[c] * scale);
+}
+
 // dpos[t][c] = sum_b g[b*T + t][c].  Each workgroup owns 32 consecutive (t,c) outputs; 8 b-slices accumulate
 // sequentially and are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ g, float* __restrict__ dpos, int B, int T, int H) {
@@ -361,6 +376,13 @@ int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, i
     hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
                        sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base));
     hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, float scale, float* demb, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, rows, demb, n, H, V, scale);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -208,6 +208,10 @@ class Engine:
         self._grad_hi = 0
         self._ws = {}
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
+        # data-parallel dense path: called right after the logits backward has written the table gradient's dense term (99.8 % of
+        # the gradient bytes) so that its all-reduce runs UNDER the blocks backward; returns the pending collectives
+        self.grad_early_hook = None
+        self._early, self._dp_rows = None, None
         self.timer = None        # optional SectionTimer
         self.prune_last = True   # final block: query/FFN path only for position T-1 (exact; see forward())
         # single-GPU bf16-logits steps: apply Adam to the item table inside the table-gradient GEMM (the table gradient
@@ -728,7 +732,12 @@ class Engine:
                 call("ader_logits_bwd_drep", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(slab), ptr(drep), st)
             with self._sec("logits_bwd_demb"):
                 call("ader_logits_bwd_demb", ptr(rep), emb, B, Bp, H, N, *ri, ptr(lse), ptr(demb), st)
+        self._early = None
+        if not defer and self.grad_early_hook is not None:
+            self._early = self.grad_early_hook(self, N)       # async all-reduce of demb: overlaps the blocks backward below
         dx = self._blocks_backward(seq, drep, defer, demb)
+        if self._early is not None:
+            self._dp_rows = (seq, dx)                         # per-position input-gradient rows: exchanged and scattered in the hook
         if defer:
             self._deferred = dict(seq=seq, g=dx, B=(n_train if split_kd else B), Bp=Bp, N=N, rep_bf=rep_bf, rep_lo=rep_lo, off=off,
                                   lab=lab, wrow=wrow, extra=extra)
@@ -802,7 +811,7 @@ class Engine:
             else:
                 M, rmap, dxo = rows, (1, 0), dx
             if self.seq_fused:
-                emb_bwd = defer and l == 0
+                emb_bwd = (defer or self._early is not None) and l == 0
                 self._bwd_block_fused(l, S, seq, dxo, dxn, M, B, emb_bwd, A["d_emb"])
                 fused_emb = fused_emb or emb_bwd
                 dx, dxn = dxn, dx
@@ -857,6 +866,9 @@ class Engine:
                 self._late_call("ader_embed_bwd_rows", None, ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args())
             else:
                 call("ader_embed_bwd_rows", ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+        elif self._early is not None:
+            # the table gradient is being all-reduced: leave the masked rows in dx (scattered for all ranks after the reduction)
+            call("ader_embed_bwd_rows", None if fused_emb else ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         else:
             call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         tb.__exit__(None, None, None)

@@ -55,28 +55,38 @@ def synth_batch(B, T, N, seed, device, regime="dense"):
     return torch.from_numpy(seq).to(device), torch.from_numpy(pos).to(device)
 
 
-def cpu_baseline(N, B, T, H, L, heads, rate, lr):
-    """Reference-equivalent CPU step (oracle/ader_ref_cpu.py: materialised [B,N] logits, one-hot CE, autograd, dense
-    TF-style Adam) timed on this host's cores.  Bounded sample: ONE full step of the same workload after a tiny warm-up
-    step (thread pool / allocator); if the host has little memory the row count is reduced and stated."""
+def cpu_baseline(N, B, T, H, L, heads, rate, lr, E=0, Np=0):
+    """Reference-equivalent CPU step (oracle/ader_ref_cpu.py: materialised [B,N] logits, one-hot CE [+ distillation against E
+    teacher rows], autograd, dense TF-style Adam) timed on this host's cores.  Bounded sample: full steps of the same workload
+    after a tiny warm-up step (thread pool / allocator) -- ONE step at the 1M-item catalog (~1 minute), up to 20 steps / ~20 s at
+    the small catalogs; if the host has little memory the row count is reduced and stated."""
     import psutil
     from oracle import ader_ref_cpu as R
     cores = os.cpu_count() or 1
+    if N < 200_000:
+        cores = min(cores, 32)      # small catalogs: more threads only add synchronisation (256 threads: 49 s per step, measured)
     torch.set_num_threads(cores)
     avail = psutil.virtual_memory().available / 2 ** 30
-    Bs = B if avail > 48 else max(32, B // 4)
+    Bs = B if (avail > 48 or N < 200_000) else max(32, B // 4)
     params = R.init_params(N, T, H, L, seed=0)
     opt = R.TFAdam(params)
     rs = np.random.RandomState(0)
-    seq = rs.randint(1, N + 1, size=(Bs, T)).astype(np.int64)
+    seq = rs.randint(1, N + 1, size=(Bs + E, T)).astype(np.int64)
     pos = rs.randint(1, N + 1, size=Bs).astype(np.int64)
-    R.train_step(params, opt, seq[:4], pos[:4], N, L, heads, lr, training=True, rate=rate, seed=0, step=0)   # warm-up (4 rows)
-    t0 = time.perf_counter()
-    R.train_step(params, opt, seq, pos, N, L, heads, lr, training=True, rate=rate, seed=0, step=1)
-    dt = time.perf_counter() - t0
-    out = {"value": Bs / dt, "unit": "sessions/s", "cores": cores, "kind": "port",
-           "sample": "1 step of B=%d rows x T=%d at the full N=%d catalog (%.1f s), torch-CPU float32 restatement, %d threads"
-                     % (Bs, T, N, dt, cores)}
+    kd = dict(ex_logits=torch.randn(E, Np, generator=torch.Generator().manual_seed(7)), lambda_=0.8) if E else {}
+    kd4 = dict(ex_logits=kd["ex_logits"][:2], lambda_=0.8) if E else {}
+    R.train_step(params, opt, seq[list(range(4)) + list(range(Bs, Bs + (2 if E else 0)))], pos[:4], N, L, heads, lr, training=True,
+                 rate=rate, seed=0, step=0, **kd4)                                                   # warm-up (a few rows)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        R.train_step(params, opt, seq, pos, N, L, heads, lr, training=True, rate=rate, seed=0, step=1 + n, **kd)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 20.0 or n >= 20:
+            break
+    out = {"value": Bs * n / dt, "unit": "sessions/s", "cores": cores, "kind": "port",
+           "sample": "%d step(s) of B=%d train%s rows x T=%d at the full N=%d catalog (%.1f s), torch-CPU float32 restatement, %d threads"
+                     % (n, Bs, " + %d distilled" % E if E else "", T, N, dt, cores)}
     # single-thread figure on a smaller sample of the same workload (SURVEY 8d): 16 rows at the full catalog
     try:
         torch.set_num_threads(1)
@@ -104,8 +114,14 @@ def main():
                     help="synthetic id/length law (SURVEY 8d); the headline number is the dense regime")
     ap.add_argument("--exemplars", type=int, default=0,
                     help="ADER-mode variant: append this many exemplar rows distilled against N(0,1) teacher logits over 0.9 N items")
-    ap.add_argument("--dp-mode", choices=["catalog", "replicated"], default="catalog",
-                    help="N > 1: table rows owned by one rank each (catalog) or replicated with a row-sharded update")
+    ap.add_argument("--dp-mode", choices=["replicated", "catalog"], default="replicated",
+                    help="N > 1: 'replicated' (headline; the north-star scheme: every rank holds the table, the table update is "
+                         "row-sharded reduce-scatter / all-gather style and the updated rows are all-gathered over RCCL) or 'catalog' "
+                         "(named variant: each rank OWNS 1/N of the table rows, only touched rows travel)")
+    ap.add_argument("--workload", choices=["cfgS", "cfgD", "cfgY"], default="cfgS",
+                    help="cfgS: BASELINE configs[4] (the metric's configuration).  Step-shape variants of the real-data configs "
+                         "(SURVEY 8a): cfgD = DIGINETICA ADER last period (N 43,105, 256 train + 143 distilled rows), cfgY = YOOCHOOSE "
+                         "ADER last period (N 25,750, 512 + 102 rows); synthetic ids of those shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32grade", action="store_true", help="skip the float32-grade (x3 logits) companion run")
     ap.add_argument("--pmc-json", default=None,
@@ -125,6 +141,10 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.workload == "cfgD":
+        args.items, args.batch, args.exemplars = 43105, 256, 143
+    elif args.workload == "cfgY":
+        args.items, args.batch, args.exemplars = 25750, 512, 102
     N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, 0.3, 5e-4
     eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits,
                  dp_rank=rank, dp_world=world)
@@ -284,7 +304,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 leg only
             try:
-                cpu = cpu_baseline(N, B, T, H, L, heads, rate, lr)
+                cpu = cpu_baseline(N, B, T, H, L, heads, rate, lr, E, int(0.9 * N) if E else 0)
             except Exception as e:  # report, never fake
                 cpu = {"value": None, "unit": "sessions/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         out = {
@@ -292,8 +312,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "x3": "bf16x3", "f32": "f32"}[args.logits], "data": "synthetic",
-            "config": {"workload": "synthetic 1M-item catalog, seq_len=50, batch=512/GPU, %s regime%s (BASELINE.json configs[4])"
-                                   % (args.regime, ", +%d distilled exemplar rows" % E if E else ""),
+            "config": {"workload": ("synthetic 1M-item catalog, seq_len=50, batch=512/GPU, %s regime%s (BASELINE.json configs[4])"
+                                    % (args.regime, ", +%d distilled exemplar rows" % E if E else "")) if args.workload == "cfgS" else
+                                   ("step shape of %s: N=%d items, %d train + %d distilled rows, synthetic ids (%s regime)"
+                                    % ({"cfgD": "DIGINETICA ADER (BASELINE.json configs[1])", "cfgY": "YOOCHOOSE ADER (configs[2])"}
+                                       [args.workload], N, B, E, args.regime)),
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam",
                        "exchange": ("none" if world == 1 else

@@ -36,6 +36,10 @@ int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, i
  * (ader_seq_bwd_qkv with emb_bwd) and only dpos is computed. */
 int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, unsigned drop_key,
                         unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+/* demb[ids[p]] += rows[p] * scale, p < n (id 0 skipped; float atomics): the scatter of the gather's gradient (modules.py:127
+ * differentiated) for rows already masked / dropout-scaled by ader_embed_bwd_rows -- used by the data-parallel dense exchange to add
+ * the input-embedding rows of every rank after the table gradient's all-reduce. */
+int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, float scale, float* demb, void* stream);
 
 /* ---- LayerNorm: modules.py:23-50 (`normalize`) ---------------------------------------------------------- */
 /* xnz/ynz (optional) = sign(|sum_c x|), sign(|sum_c y|): the key / query masks of modules.py:188,208. */

@@ -144,3 +144,134 @@ def test_two_ranks_distilled_step_matches_single_process():
     ref = eng.theta.cpu().numpy()
     d = np.abs(got - ref)
     assert np.mean(d < 5e-6) > 0.995 and d.max() < 2.5e-3
+
+
+# ---------------------------------------------------------------------------------------------- RCCL branches on one GPU
+def _rccl_worker(rank, world, port, out):
+    """backend="nccl" (= RCCL) with ONE rank on the one GPU: the code paths that only exist for RCCL -- init_process_group with a
+    device_id (dist.init), even and uneven all_to_all_single on device tensors (Engine._a2a / _a2a_rows), all_gather_into_tensor /
+    all_reduce on the launch stream inside the row-sharded and the catalog-sharded steps -- execute here for real.  With one rank
+    every exchange is the identity, so the results must equal the plain single-process step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    from ader_amd import dist as adist
+    seq, pos = _data()
+    res = {}
+    ref = _engine("bf16")
+    for step in range(2):
+        ref.train_step(seq, pos, N, 5e-4, rate=0.3)
+    torch.cuda.synchronize()
+    want = ref.theta.clone()
+    for mode in ("sharded", "catalog", "catalog_packed"):
+        eng = _engine("bf16")
+        eng.dp_world, eng.dp_rank = 1, 0
+        eng.late_side_stream = False      # (the one-rank engine would otherwise queue the small launches for the single-GPU update)
+        t = torch.arange(24, dtype=torch.float32, device="cuda").view(1, 4, 6)
+        assert torch.equal(eng._a2a(t), t)                                   # even all_to_all_single over RCCL
+        rows = torch.randn(7, 5, device="cuda")
+        assert torch.equal(eng._a2a_rows(rows, [[7]]), rows)                 # uneven all_to_all_single (split sizes)
+        for step in range(2):
+            if mode == "sharded":
+                eng.loss_and_grad(seq, pos, N, rate=0.3, _defer_table=True, n_train_global=B)
+                eng._fused_table_adam_sharded(5e-4)                          # all_gather_into_tensor x6, all_reduce x2, row all-gather
+            else:
+                eng.dp_pack = mode == "catalog_packed"
+                eng._train_step_catalog(seq, pos, N, 5e-4, rate=0.3, n_train_global=B)
+        eng.sync_table()
+        torch.cuda.synchronize()
+        d = (eng.theta - want).abs()
+        res[mode] = (float((d < 5e-6).float().mean()), float(d.max()))
+    g = torch.ones(1000, device="cuda")
+    adist.allreduce_flat(g, 600, 800, bucket_elems=256)                      # bucketed dense all-reduce over RCCL
+    torch.cuda.synchronize()
+    assert torch.all(g == 1)
+    torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_executes_the_nccl_branches():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res.pt")
+        mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+        res = torch.load(out)
+    for mode, (frac, mx) in res.items():
+        assert frac > 0.995 and mx < 2.5e-3, (mode, frac, mx)
+
+
+# ---------------------------------------------------------------------------------------------- ragged shards, mixed update modes
+B_ODD = 95
+
+
+def _odd_worker(rank, world, port, out):
+    """Odd global batch (95 rows over 2 ranks: 48 + 47 -> both padded to 48 with a weight-0 row) through the row-sharded update,
+    then a checkpoint round trip (state_dict gathers the sharded Adam state), then a DISTILLED step on the dense all-reduce path
+    whose Adam needs the complete m / v on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ader_amd import dist as adist
+    seq, pos = _data()
+    seq, pos = seq[:B_ODD], pos[:B_ODD]
+    _, _, ex_seq, teacher, trow = _kd_data()
+    eng = _engine("bf16", rank, world)
+    eng.dp_sharded = True
+    dp = adist.DataParallel(eng, rank, world)
+    lo, _ = adist.shard_bounds(B_ODD, world, rank)
+    seq_l, pos_l = adist.shard_rows(seq, world, rank), adist.shard_rows(pos, world, rank)
+    assert len(seq_l) == 48 and len(pos_l) == 48
+    for step in range(2):
+        dp.set_rows(lo, N)
+        eng.train_step(seq_l, pos_l, N, 5e-4, rate=0.3, n_train_global=B_ODD)
+    assert eng._mv_sharded
+    sd = eng.state_dict()                                  # collective: gathers the table's m / v shards
+    assert not eng._mv_sharded
+    eng2 = _engine("bf16", rank, world)
+    eng2.dp_sharded = True
+    dp2 = adist.DataParallel(eng2, rank, world)
+    eng2.load_state_dict(sd)
+    tch = torch.from_numpy(teacher).cuda()
+    ex_l = adist.shard_rows(ex_seq, world, rank)
+    tr_l = adist.shard_rows(trow, world, rank, fill=-1)
+    dp2.set_rows(lo, N)
+    eng2.train_step(np.concatenate([seq_l, ex_l]), pos_l, N, 5e-4, rate=0.0, teacher=tch, ex_trow=tr_l, lambda_=0.6,
+                    n_train_global=B_ODD, n_ex_global=N_EX)
+    torch.cuda.synchronize()
+    torch.save({"theta": eng2.theta.cpu()[:(ITEMS + 1) * H], "m": eng2.adam_m.cpu()[:(ITEMS + 1) * H]},
+               out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_odd_batch_sharded_then_checkpoint_then_dense_distilled_step():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "st.pt")
+        mp.spawn(_odd_worker, args=(2, port, out), nprocs=2, join=True)
+        got = [torch.load(out + ".%d" % r) for r in range(2)]
+    # the replicas agree with each other (identical complete Adam state on both ranks) ...
+    assert torch.allclose(got[0]["m"], got[1]["m"], atol=1e-7) and torch.allclose(got[0]["theta"], got[1]["theta"], atol=1e-6)
+    # ... and with one process doing the same three steps on the whole batch
+    seq, pos = _data()
+    seq, pos = seq[:B_ODD], pos[:B_ODD]
+    _, _, ex_seq, teacher, trow = _kd_data()
+    eng = _engine("bf16")
+    eng.fuse_adam = False
+    eng.kd_split = eng.kd_fast = False
+    for step in range(2):
+        eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+    eng.train_step(np.concatenate([seq, ex_seq]), pos, N, 5e-4, rate=0.0, teacher=torch.from_numpy(teacher).cuda(), ex_trow=trow,
+                   lambda_=0.6)
+    torch.cuda.synchronize()
+    ref = eng.theta.cpu().numpy()[:(ITEMS + 1) * H]
+    d = np.abs(got[1]["theta"].numpy() - ref)
+    assert np.mean(d < 5e-6) > 0.99 and d.max() < 3e-3
