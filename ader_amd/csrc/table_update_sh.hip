@@ -4,6 +4,7 @@
 // 10^6 rows, round-2 measurements in DESIGN.md): table_update.hip reads 8 % fewer bytes (no shadow read) but spends more
 // instructions per row, and this kernel is bound by its per-workgroup latency chain, not by bytes.  table_update.hip serves the
 // x3 mode and the gradient-only entry point.
+#include <stdlib.h>
 #include "lbf_common.h"
 #include "../../include/ader_hip.h"
 
@@ -328,6 +329,253 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(ShArgs a, FuseArgs128 f) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 64-row tiles on v_mfma_f32_16x16x32_bf16: each of the 4 waves owns 16 table rows, so the dE accumulators are 40 registers per
+// lane instead of 80 and the kernel fits THREE workgroups per CU (<= 168 registers, 45 KB of LDS) instead of two.  The update is
+// bound by its per-workgroup latency chain (tile load -> GEMM over all batch rows -> theta/m/v rounds), so resident waves per CU
+// are what buys time: one workgroup per CU takes 1.37 ms per 10^6 rows, two take 0.87 ms (measured with an LDS pad).
+//   S block  = 16 batch rows x 16 items: A = rep rows (lane: row c16, k = 8g..8g+7), B = this wave's E fragments (5 k-steps of 32)
+//   P^T.rep  = 16 items x 16 channels, K = 32 batch rows: the A fragment of lane (c16, g) is its own p values of TWO S blocks
+//              (rows 4g..4g+3 of block A, then of block B -- no lane movement); the B fragment reads exactly those rows k-major
+//              with two ds_read_b64_tr_b16 per MFMA.
+// No cross-wave reduction: a wave accumulates the whole batch for its 16 rows.  The optimiser phase is the half-tile walk of the
+// 128-row form (one half).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool EXTRA, bool KD>
+__global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (first the table tile, last the dE staging tile)
+    float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
+    int* meta_l = (int*)(off_l + a.Bp);                 // per list: [k0, k1, 8 x (id, row)] = 18 ints, 2 lists
+    float* toff_l = (float*)(meta_l + 2 * 18);          // KD: [Bp - kd_row0]
+    int* trow_l = (int*)(toff_l + (a.Bp - a.kd_row0));  // KD: [Bp - kd_row0]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int H = a.H, N = a.N;
+    const int tile0 = (blockIdx.x + a.tile_off) * 64;
+    const int it0 = tile0 + wave * 16;
+    {   // table tile: 64 shadow rows, contiguous -> LDS (coalesced 16-B pieces) -> operand fragments in registers
+        const uint4* src = (const uint4*)(a.sh1 + (size_t)tile0 * LDR);
+        uint4* dst = (uint4*)R_l;
+        for (int idx = tid; idx < 64 * PCS_ROW; idx += 256) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (tile0 + idx / PCS_ROW < a.vrows) v = src[idx];
+            dst[idx] = v;
+        }
+    }
+    for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+    if (KD) {
+        for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
+            const int b = a.kd_row0 + i, tr = a.trow[b];
+            const float w = f.wrow[b];
+            toff_l[i] = (tr >= 0 && w > 0.0f) ? log2f(w) - a.tlse2[b] : -INFINITY;
+            trow_l[i] = tr < 0 ? 0 : tr;
+        }
+    }
+    if (tid < 2) {
+        // the tile's two sparse lists (bucket bounds and first entries), fetched under the GEMM phase
+        const int bkt = tile0 >> 6;
+        const int* st = tid ? f.tg_start : f.sp_start;
+        const int* ids = tid ? f.tg_ids : f.sp_ids;
+        const int* rows = tid ? f.tg_rows : f.sp_rows;
+        int* mt = meta_l + tid * 18;
+        int k0 = 0, k1 = 0;
+        if (tile0 < N) { k0 = st[bkt]; k1 = st[bkt + 1]; }
+        mt[0] = k0; mt[1] = k1;
+        for (int i = 0; i < 8 && k0 + i < k1; ++i) { mt[2 + 2 * i] = ids[k0 + i]; mt[3 + 2 * i] = rows[k0 + i]; }
+    }
+    __syncthreads();
+    float spv[SPV];
+#pragma unroll
+    for (int i = 0; i < SPV; ++i)
+        spv[i] = (tid < H && meta_l[0] + i < meta_l[1]) ? f.sp_src[(size_t)meta_l[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
+    bf16x8 efrag[5];                                    // lane (item c16, k-group g) holds E[item][32 ks + 8 g + 0..7]
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) efrag[ks] = *(const bf16x8*)(R_l + (wave * 16 + c16) * LDR + 32 * ks + 8 * g);
+    __syncthreads();
+    f32x4v dE[10];
+#pragma unroll
+    for (int cb = 0; cb < 10; ++cb) dE[cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const int nch = a.Bp >> 6;
+    const int n16 = 64 * LDR * 2 / 16;                  // 16-byte pieces per 64-row chunk (1344)
+    uint4 pf[6];
+    LBF_RPREFETCH(0); LBF_RSTAGE(0);
+    __syncthreads();
+    int cur = 0;
+    const int q4 = c16 >> 2, p4 = c16 & 3;
+    for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        if (more) LBF_RPREFETCH(c + 1);
+        const bf16* Rb = R_l + cur * 64 * LDR;
+        const int b0 = c * 64;
+        // KD rows: this lane's 16 teacher logits (item it0 + c16, batch rows b0 + 16 rb + 4 g + reg), requested ahead of the MFMAs
+        float tv[KD ? 16 : 1];
+        const bool kdc = KD && b0 >= a.kd_row0;         // (workgroup-uniform: chunks do not straddle kd_row0)
+        if (kdc && it0 + c16 < a.Np) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                tv[KD ? j : 0] = a.teacher[(size_t)trow_l[b0 - a.kd_row0 + 16 * (j >> 2) + 4 * g + (j & 3)] * a.ldt + it0 + c16];
+        }
+        f32x4v S[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) S[rb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const bf16x8 af = *(const bf16x8*)(Rb + (rb * 16 + c16) * LDR + 32 * ks + 8 * g);
+                S[rb] = mfma16_bf16(af, efrag[ks], S[rb]);
+            }
+        }
+        // rows of S are batch rows: p = w_b * softmax = exp2(S*log2e + off_b)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const float4 o4 = *(const float4*)(off_l + b0 + 16 * rb + 4 * g);
+            S[rb][0] = __builtin_amdgcn_exp2f(fmaf(S[rb][0], LOG2E, o4.x));
+            S[rb][1] = __builtin_amdgcn_exp2f(fmaf(S[rb][1], LOG2E, o4.y));
+            S[rb][2] = __builtin_amdgcn_exp2f(fmaf(S[rb][2], LOG2E, o4.z));
+            S[rb][3] = __builtin_amdgcn_exp2f(fmaf(S[rb][3], LOG2E, o4.w));
+        }
+        if (kdc) {              // dlogit of a distilled row: w (softmax(s[:Np]) - softmax(t)) for items < Np, 0 beyond
+            if (it0 + c16 < a.Np) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    S[j >> 2][j & 3] -= __builtin_amdgcn_exp2f(fmaf(tv[KD ? j : 0], LOG2E,
+                                                                    toff_l[b0 - a.kd_row0 + 16 * (j >> 2) + 4 * g + (j & 3)]));
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) S[rb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        bf16x8 pA, pB;          // k order of a fragment: rows 4g..4g+3 of the first S block, then of the second
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pA[j] = (bf16)S[0][j]; pA[4 + j] = (bf16)S[1][j];
+            pB[j] = (bf16)S[2][j]; pB[4 + j] = (bf16)S[3][j];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 10; ++cb) {
+            const bf16* base = Rb + (4 * g + q4) * LDR + 16 * cb + 4 * p4;
+            const bf16x4 t0 = tr_read(base), t1 = tr_read(base + 16 * LDR);
+            const bf16x4 t2 = tr_read(base + 32 * LDR), t3 = tr_read(base + 48 * LDR);
+            bf16x8 bA, bB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bA[j] = t0[j]; bA[4 + j] = t1[j]; bB[j] = t2[j]; bB[4 + j] = t3[j]; }
+            dE[cb] = mfma16_bf16(pA, bA, dE[cb]);
+            dE[cb] = mfma16_bf16(pB, bB, dE[cb]);
+        }
+        if (more) LBF_RSTAGE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- optimiser phase: the tile's rows are ONE contiguous block of 64*H floats in theta / m / v (and in F_l)
+    float* F_l = (float*)smem_raw;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const int rows_valid = min(64, N - tile0);
+    const int n_el = rows_valid > 0 ? rows_valid * H : 0;
+    float* __restrict__ gp = f.emb1 + (size_t)tile0 * H;
+    float* __restrict__ gm = f.m1 + (size_t)tile0 * H;
+    float* __restrict__ gv = f.v1 + (size_t)tile0 * H;
+    const int head = (((uintptr_t)gp) & 15) ? 2 : 0;
+    int e = head + 4 * tid;
+    int row = e / H, col = e - row * H;
+    const int step_r = 1024 / H, step_c = 1024 - step_r * H;
+    f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
+    const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)tile0 * H : nullptr;
+    int E[AV], RC[AV], NV[AV];
+    ROUND_LOAD();               // first round of theta/m/v: requested BEFORE the dE staging and the sparse terms
+    lds_only_barrier();
+#pragma unroll
+    for (int cb = 0; cb < 10; ++cb) {
+        const int h = 16 * cb + c16;
+        if (h < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) F_l[(wave * 16 + 4 * g + j) * H + h] = dE[cb][j];
+        }
+    }
+    lds_only_barrier();
+    {
+        // sparse terms of the tile: item ids [tile0+1, tile0+65).  Thread c owns column c of every row.
+        const int id_lo = tile0 + 1, id_hi = min(tile0 + 64, N) + 1;
+        if (tid < H && id_lo < id_hi) {
+            const int* ms = meta_l;
+            const int* mg = meta_l + 18;
+            const int k0s = ms[0], k1s = ms[1];
+#pragma unroll
+            for (int i = 0; i < SPV; ++i) {                  // rows already in registers (same (id, row) order)
+                if (k0s + i < k1s) {
+                    const int id = ms[2 + 2 * i];
+                    if (id < id_hi) F_l[(id - id_lo) * H + tid] += spv[i];
+                }
+            }
+            for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
+                const int ic = i < 8 ? i : 7;
+                const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];
+                const int id = (i < 8) ? id_c : f.sp_ids[k];
+                if (id >= id_hi) break;
+                const int srow = (i < 8) ? row_c : f.sp_rows[k];
+                F_l[(id - id_lo) * H + tid] += f.sp_src[(size_t)srow * H + tid] * f.sp_scale;
+            }
+            for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
+                const int ic = i < 8 ? i : 7;
+                const int id_c = mg[2 + 2 * ic], b_c = mg[3 + 2 * ic];
+                const int id = (i < 8) ? id_c : f.tg_ids[k];
+                if (id >= id_hi) break;
+                const int b = (i < 8) ? b_c : f.tg_rows[k];
+                F_l[(id - id_lo) * H + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
+            }
+        }
+    }
+    lds_only_barrier();
+    bf16* __restrict__ psh = f.sh1w + (size_t)tile0 * LDR;
+#define ADAM1(p_, m_, v_, g_)                                                                              \
+    { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
+    if (head && tid == 0 && n_el > 0) {                   // elements 0,1 (row 0, columns 0,1)
+        f32x2_t p = *(const f32x2_t*)gp, m = *(const f32x2_t*)gm, v = *(const f32x2_t*)gv;
+        float2 g2 = *(const float2*)F_l;
+        if (EXTRA) { g2.x += gx[0]; g2.y += gx[1]; }
+        ADAM1(p[0], m[0], v[0], g2.x); ADAM1(p[1], m[1], v[1], g2.y);
+        *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
+        bf16x2 sb; sb[0] = (bf16)p[0]; sb[1] = (bf16)p[1];
+        *(bf16x2*)psh = sb;
+    }
+#pragma unroll 1
+    for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160; round 0 is already in flight
+        if (k0) { ROUND_LOAD(); }
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+            if (NV[u] == 0) continue;
+            float2 ga = *(const float2*)(F_l + E[u]);
+            float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
+            if (EXTRA) { ga.x += G[u][0]; ga.y += G[u][1]; gb.x += G[u][2]; gb.y += G[u][3]; }
+            f32x4_t p = P[u], m = M[u], v = V[u];
+            ADAM1(p[0], m[0], v[0], ga.x); ADAM1(p[1], m[1], v[1], ga.y);
+            ADAM1(p[2], m[2], v[2], gb.x); ADAM1(p[3], m[3], v[3], gb.y);
+            const int r0 = RC[u] >> 16, c0 = RC[u] & 0xffff;
+            bf16x2 s0; s0[0] = (bf16)p[0]; s0[1] = (bf16)p[1];
+            *(bf16x2*)(psh + r0 * LDR + c0) = s0;
+            if (NV[u] == 2) {
+                __builtin_nontemporal_store(p, (f32x4_t*)(gp + E[u]));
+                __builtin_nontemporal_store(m, (f32x4_t*)(gm + E[u]));
+                __builtin_nontemporal_store(v, (f32x4_t*)(gv + E[u]));
+                const int c1 = c0 + 2;
+                bf16x2 s1; s1[0] = (bf16)p[2]; s1[1] = (bf16)p[3];
+                *(bf16x2*)(psh + ((c1 >= H) ? (r0 + 1) * LDR + (c1 - H) : r0 * LDR + c1)) = s1;
+            } else {
+                *(f32x2_t*)(gp + E[u]) = (f32x2_t){p[0], p[1]};
+                *(f32x2_t*)(gm + E[u]) = (f32x2_t){m[0], m[1]};
+                *(f32x2_t*)(gv + E[u]) = (f32x2_t){v[0], v[1]};
+            }
+        }
+    }
+#undef ADAM1
+}
+
 static size_t bwd_lds(int Bp, int Bk) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 4 * 18 * sizeof(int) + (size_t)Bk * 8; }
 
 extern "C" {
@@ -345,13 +593,22 @@ static int tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, 
     const bool kd = kd_row0 < Bp;
     if (kd && (kd_row0 % 128 != 0 || extra_grad || !teacher || !trow || !tlse2 || Np < 1 || Np > N)) return -2;
     static int lds_set = 0;
-    const size_t lds = bwd_lds(Bp, kd ? Bp - kd_row0 : 0);
+    static int pad = -1, form = -1;
+    if (pad < 0) { const char* v = getenv("ADER_SH_LDS_PAD"); pad = v ? atoi(v) : 0; }      // experiment: force fewer workgroups per CU
+    if (form < 0) { const char* v = getenv("ADER_TAB_FORM"); form = (v && v[0] == '1') ? 128 : 64; }   // 64-row 16x16x32 form / 128-row form
+    const size_t lds = bwd_lds(Bp, kd ? Bp - kd_row0 : 0) + (size_t)pad;
     if ((int)lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_tab16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_tab16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_tab16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         lds_set = (int)lds;
     }
@@ -374,6 +631,17 @@ static int tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, 
     if (te <= tb) return 0;
     a.tile_off = tb;
     hipStream_t st = (hipStream_t)stream;
+    if (form == 64) {           // 64-row tiles: tile range in units of 64 rows
+        const int all64 = (N + 63) / 64;
+        int t0 = 2 * tb, t1 = 2 * te;
+        if (t1 > all64) t1 = all64;
+        a.tile_off = t0;
+        if (kd) hipLaunchKernelGGL((k_tab16<false, true>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
+        else if (extra_grad) hipLaunchKernelGGL((k_tab16<true, false>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
+        else hipLaunchKernelGGL((k_tab16<false, false>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (kd) hipLaunchKernelGGL((k_lbf_bwd_de<true, false, true>), dim3(te - tb), dim3(256), lds, st, a, fa);
     else if (extra_grad) hipLaunchKernelGGL((k_lbf_bwd_de<true, true, false>), dim3(te - tb), dim3(256), lds, st, a, fa);
     else hipLaunchKernelGGL((k_lbf_bwd_de<true, false, false>), dim3(te - tb), dim3(256), lds, st, a, fa);
