@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADER_HIP_LIB") or os.path.join(_HERE, "libader_hip.so")      # (override: A/B runs of two builds)
 
 P, I, U, F, L, Z = c_void_p, c_int, c_uint, c_float, c_long, c_size_t
-_DROP = [U, U, F, U]
+_DROP = [P]          # const AderDrop* (NULL: no dropout)
 
 _SIGS = {
     "ader_embed_fwd": [P, P, P, P, I, I, I, I] + _DROP + [P, P],
@@ -79,7 +79,7 @@ SEQ_MAXL = 4
 
 
 class AderDrop(ctypes.Structure):
-    _fields_ = [("key", c_uint), ("thr", c_uint), ("scale", c_float), ("base", c_uint)]
+    _fields_ = [("key", c_uint), ("thr", c_uint), ("scale", c_float), ("base", c_uint), ("split", c_uint), ("base2", c_uint)]
 
 
 class AderSeqBlock(ctypes.Structure):

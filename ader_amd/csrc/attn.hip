@@ -390,8 +390,7 @@ static const size_t kAttnBwdLds = (size_t)(2 * TR * LDQ + 2 * TR * LDS_) * sizeo
 extern "C" {
 
 int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask, const float* qmask,
-                  float* out, float* P, int B, int T, int H, int heads, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                  unsigned drop_base, void* stream) {
+                  float* out, float* P, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     if (T > TR || heads < 1 || H % heads != 0 || H / heads > 160) return -2;
     static bool attr_set = false;
@@ -404,15 +403,14 @@ int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q
     a.Q = Q; a.K = K; a.V = V; a.res = q_in; a.kmask = kmask; a.qmask = qmask; a.out = out; a.P = P;
     a.dQ = a.dK = a.dV = nullptr;
     a.B = B; a.T = T; a.H = H; a.heads = heads; a.sqrt_dh = sqrtf((float)(H / heads));
-    a.drop.key = drop_key; a.drop.thr = drop_thr; a.drop.scale = drop_scale; a.drop.base = drop_base;
+    a.drop = drop_from(drop);
     hipLaunchKernelGGL(k_attn_fwd, dim3(B * heads), dim3(256), kAttnFwdLds, (hipStream_t)stream, a);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 
 int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* P, const float* kmask,
-                  const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads, unsigned drop_key,
-                  unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+                  const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     if (T > TR || heads < 1 || H % heads != 0 || H / heads > 160) return -2;
     static bool attr_set = false;
@@ -425,7 +423,7 @@ int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
     a.Q = Q; a.K = K; a.V = V; a.res = dO; a.kmask = kmask; a.qmask = qmask; a.out = nullptr; a.P = (float*)P;
     a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.B = B; a.T = T; a.H = H; a.heads = heads; a.sqrt_dh = sqrtf((float)(H / heads));
-    a.drop.key = drop_key; a.drop.thr = drop_thr; a.drop.scale = drop_scale; a.drop.base = drop_base;
+    a.drop = drop_from(drop);
     hipLaunchKernelGGL(k_attn_bwd, dim3(B * heads), dim3(256), kAttnBwdLds, (hipStream_t)stream, a);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -433,19 +431,18 @@ int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
 
 static const size_t kAttnLastLds = (size_t)(2 * TR * LAST_LD + 2 * 160 + 2 * TR) * sizeof(float);
 
-static int attn_last_args(AttnLastArgs& a, int B, int T, int H, int heads, unsigned k, unsigned thr, float sc, unsigned base) {
+static int attn_last_args(AttnLastArgs& a, int B, int T, int H, int heads, const AderDrop* drop) {
     if (T > TR || heads < 1 || H % heads != 0 || H / heads > 160) return -2;
     a.B = B; a.T = T; a.H = H; a.heads = heads; a.sqrt_dh = sqrtf((float)(H / heads));
-    a.drop.key = k; a.drop.thr = thr; a.drop.scale = sc; a.drop.base = base;
+    a.drop = drop_from(drop);
     return 0;
 }
 
 int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, const float* q_in_last, const float* kmask,
-                       const float* qmask_last, float* out_last, float* P_last, int B, int T, int H, int heads, unsigned drop_key,
-                       unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+                       const float* qmask_last, float* out_last, float* P_last, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     AttnLastArgs a;
-    int rc = attn_last_args(a, B, T, H, heads, drop_key, drop_thr, drop_scale, drop_base);
+    int rc = attn_last_args(a, B, T, H, heads, drop);
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
@@ -462,10 +459,10 @@ int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, cons
 
 int ader_attn_last_bwd(const float* dO_last, const float* Q_last, const float* K, const float* V, const float* P_last,
                        const float* kmask, const float* qmask_last, float* dQ_last, float* dK, float* dV, int B, int T, int H,
-                       int heads, unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+                       int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     AttnLastArgs a;
-    int rc = attn_last_args(a, B, T, H, heads, drop_key, drop_thr, drop_scale, drop_base);
+    int rc = attn_last_args(a, B, T, H, heads, drop);
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {

@@ -364,12 +364,12 @@ __global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
 static const size_t kFwdLds = (size_t)2 * TR * LDR * sizeof(bf16) + TR * sizeof(float);
 static const size_t kBwdLds = (size_t)(2 * TR * LDR + 4 * TR * LDP) * sizeof(bf16) + TR * sizeof(float);
 
-static int x3_args(AttnX3Args& a, int B, int T, int H, int heads, unsigned k, unsigned thr, float sc, unsigned base) {
+static int x3_args(AttnX3Args& a, int B, int T, int H, int heads, const AderDrop* drop) {
     if (T > TR || heads < 1 || H % heads != 0) return -2;
     const int dh = H / heads;
     if (dh > 160 || (dh & 1)) return -2;
     a.B = B; a.T = T; a.H = H; a.heads = heads; a.sqrt_dh = sqrtf((float)dh);
-    a.drop.key = k; a.drop.thr = thr; a.drop.scale = sc; a.drop.base = base;
+    a.drop = drop_from(drop);
     return 0;
 }
 
@@ -377,11 +377,10 @@ extern "C" {
 
 // PT: [B,heads,T,T] scratch, stored transposed ([key][query]) -- only ader_attn_x3_bwd reads it
 int ader_attn_x3_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask, const float* qmask,
-                     float* out, float* PT, int B, int T, int H, int heads, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                     unsigned drop_base, void* stream) {
+                     float* out, float* PT, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     AttnX3Args a;
-    int rc = x3_args(a, B, T, H, heads, drop_key, drop_thr, drop_scale, drop_base);
+    int rc = x3_args(a, B, T, H, heads, drop);
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
@@ -397,11 +396,10 @@ int ader_attn_x3_fwd(const float* Q, const float* K, const float* V, const float
 }
 
 int ader_attn_x3_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* PT, const float* kmask,
-                     const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads, unsigned drop_key,
-                     unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+                     const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     AttnX3Args a;
-    int rc = x3_args(a, B, T, H, heads, drop_key, drop_thr, drop_scale, drop_base);
+    int rc = x3_args(a, B, T, H, heads, drop);
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {

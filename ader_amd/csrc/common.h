@@ -20,7 +20,9 @@ struct DropArgs {
     uint32_t key;     // per (seed, step, site)
     uint32_t thr;     // round(rate * 2^24); 0 => dropout disabled
     float scale;      // float32(1)/(float32(1)-float32(rate))
-    uint32_t base;    // element index of local row 0 (global_row0 * elems_per_row), for data-parallel shards
+    uint32_t base;    // counter offset of the local elements below `split`: global_row0 * elems_per_row (data-parallel shards)
+    uint32_t split;   // first local element index of the SECOND row segment (exemplar rows follow the train rows, main.py:229;
+    uint32_t base2;   // a shard holds a slice of each, so the two segments have different global offsets); 0xFFFFFFFF: one segment
 };
 
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
@@ -28,7 +30,14 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ bool drop_keep(const DropArgs& d, uint32_t idx) {
-    return (lowbias32((idx + d.base) ^ d.key) >> 8) >= d.thr;
+    return (lowbias32((idx + (idx >= d.split ? d.base2 : d.base)) ^ d.key) >> 8) >= d.thr;
+}
+// host side of every launcher: the C-ABI descriptor (include/ader_hip.h: AderDrop; NULL = no dropout) -> kernel argument
+template <class D> static inline DropArgs drop_from(const D* d) {
+    DropArgs o;
+    if (d) { o.key = d->key; o.thr = d->thr; o.scale = d->scale; o.base = d->base; o.split = d->split; o.base2 = d->base2; }
+    else { o.key = 0; o.thr = 0; o.scale = 1.0f; o.base = 0; o.split = 0xFFFFFFFFu; o.base2 = 0; }
+    return o;
 }
 // TF2 inverted dropout: (x * scale) * keep
 __device__ __forceinline__ float drop_apply(const DropArgs& d, uint32_t idx, float x) {

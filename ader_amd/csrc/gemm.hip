@@ -160,14 +160,13 @@ static int launch_rows(const GemmArgs& g, hipStream_t st) {
 extern "C" {
 
 int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, const float* aux, const int* seq, int M, int H,
-                   int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                   unsigned drop_base, void* stream) {
+                   int epilogue, int trans_b, int row_mul, int row_add, const AderDrop* drop, void* stream) {
     if (M <= 0) return 0;
     if (H > HP || H < 1) return -2;
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.C = C; g.aux = aux; g.seq = seq; g.M = M; g.H = H;
     g.row_mul = row_mul; g.row_add = row_add;
-    g.drop.key = drop_key; g.drop.thr = drop_thr; g.drop.scale = drop_scale; g.drop.base = drop_base;
+    g.drop = drop_from(drop);
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue * 2 + (trans_b ? 1 : 0)) {
         case EPI_BIAS * 2 + 0: return launch_rows<EPI_BIAS, false>(g, st);

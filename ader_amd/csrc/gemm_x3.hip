@@ -339,15 +339,14 @@ int ader_wprep(const float* theta, const long* offs, int nw, int H, void* out, v
 
 // wplanes: the 4 prepared planes of this weight (from ader_wprep); trans_b selects W (A . W^T) instead of W^T (A . W).
 int ader_gemm_x3(const float* A, const void* wplanes, const float* bias, float* C, const float* aux, const int* seq, int M, int H,
-                 int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                 unsigned drop_base, void* stream) {
+                 int epilogue, int trans_b, int row_mul, int row_add, const AderDrop* drop, void* stream) {
     if (M <= 0) return 0;
     if (H > HP || H < 2 || (H & 1)) return -2;
     GemmX3Args g;
     const bf16* wp = (const bf16*)wplanes + (trans_b ? 2 * WSZ : 0);
     g.A = A; g.Bhi = wp; g.Blo = wp + WSZ; g.bias = bias; g.C = C; g.aux = aux; g.seq = seq; g.M = M; g.H = H;
     g.row_mul = row_mul; g.row_add = row_add;
-    g.drop.key = drop_key; g.drop.thr = drop_thr; g.drop.scale = drop_scale; g.drop.base = drop_base;
+    g.drop = drop_from(drop);
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case EPI_BIAS: return launch_x3<EPI_BIAS>(g, st);

@@ -348,9 +348,6 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, f
 }
 
 // ============================================================================================= C ABI
-static inline DropArgs mk_drop(unsigned key, unsigned thr, float scale, unsigned base) {
-    DropArgs d; d.key = key; d.thr = thr; d.scale = scale; d.base = base; return d;
-}
 static inline int cap_grid(size_t n, int per_block, int cap) {
     size_t g = (n + per_block - 1) / per_block;
     if (g > (size_t)cap) g = cap;
@@ -361,20 +358,20 @@ static inline int cap_grid(size_t n, int per_block, int cap) {
 extern "C" {
 
 int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x, int rows, int T, int H, int V,
-                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, int* status, void* stream) {
+                   const AderDrop* drop, int* status, void* stream) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_embed_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, H, V,
-                       sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base), status);
+                       sqrtf((float)H), drop_from(drop), status);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 
 int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
-                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+                   const AderDrop* drop, void* stream) {
     const int rows = B * T;
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
-                       sqrtf((float)H), mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+                       sqrtf((float)H), drop_from(drop));
     hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -387,13 +384,12 @@ int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, fl
     return 0;
 }
 
-int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, unsigned drop_key, unsigned drop_thr,
-                        float drop_scale, unsigned drop_base, void* stream) {
+int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, const AderDrop* drop, void* stream) {
     const int rows = B * T;
     if (rows <= 0) return 0;
     if (seq)     // seq == NULL: dx already holds the masked / dropout-scaled rows (ader_seq_bwd_qkv with emb_bwd)
         hipLaunchKernelGGL(k_embed_bwd_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, rows, H, V,
-                           mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+                           drop_from(drop));
     hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -428,10 +424,10 @@ int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const fl
 }
 
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
-                       unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream) {
+                       const AderDrop* drop, void* stream) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_mask_dropgrad, dim3(cap_grid((size_t)rows * H, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx2, seq, g,
-                       dh2, rows, H, row_mul, row_add, mk_drop(drop_key, drop_thr, drop_scale, drop_base));
+                       dh2, rows, H, row_mul, row_add, drop_from(drop));
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 // (vmcnt(0)): with ~100 activation stores per lane between barriers that costs a memory round trip per phase.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <class D> __device__ __forceinline__ DropArgs drop_of(const D& d) {
-    DropArgs o; o.key = d.key; o.thr = d.thr; o.scale = d.scale; o.base = d.base;
+    DropArgs o; o.key = d.key; o.thr = d.thr; o.scale = d.scale; o.base = d.base; o.split = d.split; o.base2 = d.base2;
     return o;
 }
 __device__ __forceinline__ void put_split(bf16* Th, bf16* Tl, int off, float v) {

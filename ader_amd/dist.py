@@ -139,8 +139,13 @@ class DataParallel:
                 dist.broadcast(t, src=0, group=group)
             engine.refresh_shadow()          # bf16 copies derived from theta
 
-    def set_rows(self, global_row0, max_item):
+    def set_rows(self, global_row0, max_item, ex_row0=None):
+        """global_row0: index of this rank's first train row in the global batch; ex_row0: global index of its first exemplar row
+        (= n_train_global + offset of the rank's exemplar slice; the global batch is [train rows | exemplar rows], main.py:229).
+        The dropout counters of every site are keyed by these global rows, so W ranks draw exactly the masks of one process."""
         self.engine.row0 = int(global_row0)
+        self.engine.row0_ex = int(ex_row0) if ex_row0 is not None else 0
+        self.engine._ex_row0_set = ex_row0 is not None
         self.max_item = int(max_item)
 
     def _early(self, eng, max_item):

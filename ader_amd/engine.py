@@ -51,21 +51,31 @@ def dropout_key(seed, step, site):
 
 
 class _Drop:
-    """(key, thr, scale, base) of one dropout site for one step."""
+    """Descriptor of one dropout site for one step (include/ader_hip.h: AderDrop): key, threshold, scale and the counter
+    offsets of the two local row segments -- rows [0, split_rows) continue at global row `row0`, the rows after them at global
+    row `row0_2` (a data-parallel rank holds a slice of the train rows followed by a slice of the exemplar rows)."""
 
-    __slots__ = ("key", "thr", "scale", "base")
+    __slots__ = ("c", "_ref")
 
-    def __init__(self, seed, step, site, rate, training, base):
+    def __init__(self, seed, step, site, rate, training, per_row, row0=0, split_rows=None, row0_2=0):
+        c = _lib.AderDrop()
         if training and rate > 0.0:
-            self.key = dropout_key(seed, step, site)
-            self.thr = int(round(float(rate) * 16777216.0))
-            self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
+            c.key = dropout_key(seed, step, site)
+            c.thr = int(round(float(rate) * 16777216.0))
+            c.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
         else:
-            self.key, self.thr, self.scale = 0, 0, 1.0
-        self.base = base & 0xFFFFFFFF
+            c.key, c.thr, c.scale = 0, 0, 1.0
+        c.base = (row0 * per_row) & 0xFFFFFFFF
+        if split_rows is None:
+            c.split, c.base2 = 0xFFFFFFFF, 0
+        else:
+            c.split = (split_rows * per_row) & 0xFFFFFFFF
+            c.base2 = ((row0_2 - split_rows) * per_row) & 0xFFFFFFFF     # local index + base2 = global index of a segment-2 element
+        self.c = c
+        self._ref = ctypes.byref(c)
 
     def args(self):
-        return (self.key, self.thr, self.scale, self.base)
+        return (self._ref,)
 
 
 class SectionTimer:
@@ -205,6 +215,7 @@ class Engine:
         self.b1p, self.b2p = np.float32(self.beta1), np.float32(self.beta2)   # TF keeps beta powers in float32 variables
         self.global_step = 0
         self.row0 = 0            # global index of local row 0 (data-parallel shard offset of the dropout counters)
+        self.split_rows, self.row0_ex = None, 0     # ... and of the first local exemplar row (set per step under data parallelism)
         self._grad_hi = 0
         self._ws = {}
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
@@ -395,7 +406,13 @@ class Engine:
         return out
 
     # ---------------------------------------------------------------------------------------- forward
-    _ND = (0, 0, 1.0, 0)
+    def _drop(self, step, site, rate, training, per_row):
+        """Dropout descriptor of a site for this step: counters keyed by the GLOBAL row, so W ranks draw the masks of
+        one process.  Engine.row0 = global index of local row 0; with exemplar rows in the batch (Engine.split_rows local train
+        rows first) the rows after them continue at global row Engine.row0_ex."""
+        return _Drop(self.seed, step, site, rate, training, per_row, self.row0, self.split_rows, self.row0_ex)
+
+    _ND = (None,)
 
     def _gemm(self, A, wname, bname, C, aux, seq, M, epi, trans=0, drop=None, rmap=(1, 0)):
         d = drop.args() if drop is not None else self._ND
@@ -452,7 +469,7 @@ class Engine:
         A = {"B": B, "seq": seq, "rate": rate, "training": training, "step": step}
         per_row = T * H
         pp = self._pp
-        d0 = _Drop(self.seed, step, SITE_EMB, rate, training, self.row0 * per_row)
+        d0 = self._drop(step, SITE_EMB, rate, training, per_row)
         x = self.buf(tag + "x0", (rows, H))
         call("ader_embed_fwd", ptr(seq), pp["emb"], pp["pos"], ptr(x), rows, T, H, self.V, *d0.args(), ptr(self.status), st)
         A["d_emb"] = d0
@@ -461,9 +478,9 @@ class Engine:
             p = "b%d." % l
             n = lambda s: "%s%d%s" % (tag, l, s)   # noqa: E731
             pruned = self.prune_last and l == L - 1
-            da = _Drop(self.seed, step, site_attn(l), rate, training, self.row0 * self.heads * T * T)
-            d1 = _Drop(self.seed, step, site_ffn1(l), rate, training, self.row0 * per_row)
-            d2 = _Drop(self.seed, step, site_ffn2(l), rate, training, self.row0 * per_row)
+            da = self._drop(step, site_attn(l), rate, training, self.heads * T * T)
+            d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
+            d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
             q_in = self.buf(n("qin"), (rows, H))
             mean1, std1 = self.buf(n("m1"), (rows,)), self.buf(n("s1"), (rows,))
             kmask, qmask = self.buf(n("km"), (rows,)), self.buf(n("qm"), (rows,))
@@ -537,7 +554,7 @@ class Engine:
         per_row = T * H
         pp = self._pp
         d = _lib.AderSeqFwd()
-        d0 = _Drop(self.seed, step, SITE_EMB, rate, training, self.row0 * per_row)
+        d0 = self._drop(step, SITE_EMB, rate, training, per_row)
         A["d_emb"] = d0
         x = self.buf(tag + "x0", (rows, H))
         rep = self.buf(tag + "rep", (B, H))
@@ -547,14 +564,14 @@ class Engine:
         d.B, d.T, d.H, d.V, d.L = B, T, H, self.V, L
         d.sqrtH = float(np.sqrt(np.float32(H)))
         d.sqrt_dh = float(np.sqrt(np.float32(H // self.heads)))
-        d.d_emb = _lib.AderDrop(*d0.args())
+        d.d_emb = d0.c
         for l in range(L):
             p = "b%d." % l
             n = lambda s: "%s%d%s" % (tag, l, s)   # noqa: E731
             pruned = self.prune_last and l == L - 1
-            da = _Drop(self.seed, step, site_attn(l), rate, training, self.row0 * self.heads * T * T)
-            d1 = _Drop(self.seed, step, site_ffn1(l), rate, training, self.row0 * per_row)
-            d2 = _Drop(self.seed, step, site_ffn2(l), rate, training, self.row0 * per_row)
+            da = self._drop(step, site_attn(l), rate, training, self.heads * T * T)
+            d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
+            d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
             M, sfx = (B, "L") if pruned else (rows, "")
             kmask = self.buf(n("km"), (rows,))
             K, Vv = self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
@@ -573,7 +590,7 @@ class Engine:
             k.q_in, k.mean1, k.std1, k.kmask, k.qmask = ptr(q_in), ptr(mean1), ptr(std1), ptr(kmask), ptr(qmask)
             k.Q, k.K, k.V, k.P, k.x1, k.y = ptr(Q), ptr(K), ptr(Vv), ptr(Pm), ptr(x1), ptr(y)
             k.mean2, k.std2, k.h1d, k.x2 = ptr(mean2), ptr(std2), ptr(h1d), ptr(x2)
-            k.d_attn, k.d_ffn1, k.d_ffn2 = _lib.AderDrop(*da.args()), _lib.AderDrop(*d1.args()), _lib.AderDrop(*d2.args())
+            k.d_attn, k.d_ffn1, k.d_ffn2 = da.c, d1.c, d2.c
             k.pruned = 1 if pruned else 0
             A[l] = dict(pruned=pruned, x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv, P=Pm,
                         x1=x1, y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
@@ -661,6 +678,8 @@ class Engine:
         use_bf16 = self.lfast and (teacher is None or split_kd or kd_fast)
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
         self._deferred = None
+        # data-parallel shard with exemplar rows: its train rows and its exemplar rows sit at different global positions
+        self.split_rows = n_train if (n_ex > 0 and getattr(self, "_ex_row0_set", False)) else None
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         if kd_fast:
@@ -894,7 +913,7 @@ class Engine:
         f.seq, f.dx2, f.h1d, f.x1, f.mean2, f.std2 = ptr(seq), ptr(dxo), ptr(S["h1d"]), ptr(S["x1"]), ptr(S["mean2"]), ptr(S["std2"])
         f.ln2_g, f.w2, f.w1 = pp[p + "ln2_g"], wp("w2"), wp("w1")
         f.dh2, f.da, f.dx1, f.slab = ptr(dh2), ptr(da_), ptr(dx1), ptr(slab2)
-        f.d_ffn1, f.d_ffn2 = _lib.AderDrop(*S["d1"].args()), _lib.AderDrop(*S["d2"].args())
+        f.d_ffn1, f.d_ffn2 = S["d1"].c, S["d2"].c
         f.B, f.T, f.H, f.pruned = B, T, H, pruned
         call("ader_seq_bwd_ffn", ctypes.byref(f), st)
         self._late_call("ader_reduce_slabs", ptr(slab2), 2 * H, B, H, 1, H, gp[p + "ln2_g"], gp[p + "ln2_b"])
@@ -913,7 +932,7 @@ class Engine:
         q.mean1, q.std1, q.ln1_g = ptr(S["mean1"]), ptr(S["std1"]), pp[p + "ln1_g"]
         q.wq, q.wk, q.wv = wp("wq"), wp("wk"), wp("wv")
         q.dx, q.slab = ptr(dxn), ptr(slab1)
-        q.d_emb = _lib.AderDrop(*d_emb.args())
+        q.d_emb = d_emb.c
         q.B, q.T, q.H, q.pruned, q.emb_bwd = B, T, H, pruned, 1 if emb_bwd else 0
         call("ader_seq_bwd_qkv", ctypes.byref(q), st)
         self._late_call("ader_reduce_slabs", ptr(slab1), 2 * H, B, H, 1, H, gp[p + "ln1_g"], gp[p + "ln1_b"])

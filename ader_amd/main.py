@@ -177,6 +177,8 @@ def run(args, log=print):
                         idx = np.asarray(idx, dtype=np.int32)
                         if world > 1:                                            # ... and exemplar rows (main.py:229 order kept)
                             kw.update(n_ex_global=len(ex_seq))
+                            elo, _ = adist.shard_bounds(len(ex_seq), world, rank)
+                            dp.set_rows(lo, max_item, ex_row0=len(pos) + elo)      # dropout counters keyed by the global row
                             ex_seq, ex_pos = adist.shard_rows(ex_seq, world, rank), adist.shard_rows(ex_pos, world, rank)
                             idx = adist.shard_rows(idx, world, rank, fill=-1)
                         if len(ex_seq):

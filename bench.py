@@ -212,11 +212,14 @@ def main():
         x0 = torch.empty(B * T, H, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        import ctypes
+        from ader_amd._lib import AderDrop
+        dd = AderDrop(0x1234, int(0.3 * 2 ** 24), 1.0 / 0.7, 0, 0xFFFFFFFF, 0)
         for it in range(25):
             if it == 5:
                 a.record()
-            call("ader_embed_fwd", ptr(seq0), eng._pp["emb"], eng._pp["pos"], ptr(x0), B * T, T, H, eng.V, 0x1234, int(0.3 * 2 ** 24),
-                 1.0 / 0.7, 0, ptr(eng.status), st)
+            call("ader_embed_fwd", ptr(seq0), eng._pp["emb"], eng._pp["pos"], ptr(x0), B * T, T, H, eng.V, ctypes.byref(dd),
+                 ptr(eng.status), st)
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / 20 * 1e3

@@ -19,23 +19,26 @@
 extern "C" {
 #endif
 
-/* Dropout everywhere: keep(idx) = (lowbias32((idx + drop_base) ^ drop_key) >> 8) >= drop_thr, value * drop_scale when
- * kept; drop_thr == 0 disables it.  (tf.layers.dropout sites ADER.py:55, modules.py:214,257,262; TF's RNG stream is
- * not reproducible, the counter spec is the build's own and is restated in oracle/ader_ref_cpu.py.) */
+/* Dropout everywhere (tf.layers.dropout sites ADER.py:55, modules.py:214,257,262; TF's RNG stream is not reproducible, the
+ * counter spec is the build's own and is restated in oracle/ader_ref_cpu.py):
+ *   keep(idx) = (lowbias32((idx + offset(idx)) ^ key) >> 8) >= thr,  value * scale when kept;  thr == 0 (or a NULL
+ *   descriptor) disables it.  idx is the element's LOCAL index at the site (row * elements_per_row + ...), offset(idx) makes it
+ *   global: `base` for idx < split, `base2` from `split` on -- a data-parallel rank holds a slice of the train rows followed by
+ *   a slice of the exemplar rows (main.py:229), two row segments with different global positions; split = 0xFFFFFFFF: one. */
+typedef struct { unsigned key, thr; float scale; unsigned base, split, base2; } AderDrop;
 
 /* ---- embedding prologue: modules.py:118-130 + ADER.py:41-60 ------------------------------------------- */
 int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x, int rows, int T, int H, int V,
-                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, int* status, void* stream);
+                   const AderDrop* drop, int* status, void* stream);
 /* backward: dx [B*T,H] is overwritten with the masked/dropout-scaled gradient; sqrt(H)*that is scatter-added into
  * demb (must already hold the logits-side gradient); dpos [T,H] is overwritten. */
 int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
-                   unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                   const AderDrop* drop, void* stream);
 
 /* as ader_embed_bwd but without the scatter into demb: dx is left holding the per-position gradient rows (consumed by
  * ader_lbf_bwd_adam through an id-sorted list); dpos is overwritten.  seq == NULL: dx already holds those rows
  * (ader_seq_bwd_qkv with emb_bwd) and only dpos is computed. */
-int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, unsigned drop_key,
-                        unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, const AderDrop* drop, void* stream);
 /* demb[ids[p]] += rows[p] * scale, p < n (id 0 skipped; float atomics): the scatter of the gather's gradient (modules.py:127
  * differentiated) for rows already masked / dropout-scaled by ader_embed_bwd_rows -- used by the data-parallel dense exchange to add
  * the input-embedding rows of every rank after the table gradient's all-reduce. */
@@ -58,8 +61,7 @@ enum { ADER_EPI_BIAS = 0, ADER_EPI_BIAS_RELU_DROP = 1, ADER_EPI_BIAS_DROP_RES_MA
 /* row_mul/row_add: local row m is row m*row_mul+row_add of the full [B*T,H] tensor (dropout counter and seq mask of a row
  * subset, e.g. only position T-1 of every sequence: row_mul = T, row_add = T-1); 1, 0 for full tensors. */
 int ader_gemm_rows(const float* A, const float* W, const float* bias, float* C, const float* aux, const int* seq, int M,
-                   int H, int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr,
-                   float drop_scale, unsigned drop_base, void* stream);
+                   int H, int epilogue, int trans_b, int row_mul, int row_add, const AderDrop* drop, void* stream);
 int ader_gemm_atb_slabs(int M);
 /* dW[H,H] = A^T . G, db[H] = column sums of G (db may be NULL).  slab: ader_gemm_atb_slabs(M)*160*160 floats. */
 int ader_gemm_atb(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
@@ -69,8 +71,7 @@ int ader_gemm_atb(const float* A, const float* G, float* slab, float* dW, float*
 size_t ader_wprep_elems(int nw);
 int ader_wprep(const float* theta, const long* offs, int nw, int H, void* out, void* stream);
 int ader_gemm_x3(const float* A, const void* wplanes, const float* bias, float* C, const float* aux, const int* seq, int M,
-                 int H, int epilogue, int trans_b, int row_mul, int row_add, unsigned drop_key, unsigned drop_thr,
-                 float drop_scale, unsigned drop_base, void* stream);
+                 int H, int epilogue, int trans_b, int row_mul, int row_add, const AderDrop* drop, void* stream);
 int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream);
 /* The same products batched: n <= 16 independent (A[i], G[i], M[i]) -> (dW[i], db[i] or NULL) in one product launch + one
  * reduce launch (all weight gradients of a backward pass, tf.gradients of modules.py:172-174,254-261).  A/G/dW/db/M are HOST
@@ -85,7 +86,7 @@ int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* 
  * buffers and layouts; a block with pruned != 0 keeps only position T-1 of its query / FFN path in compact [B,H] /
  * [B] / [B,T] buffers, K, V and kmask stay [B*T,..]).  w[i]: the 4 prepared planes (ader_wprep) of wq, wk, wv, w1, w2. */
 #define ADER_SEQ_MAXL 4
-typedef struct { unsigned key, thr; float scale; unsigned base; } AderDrop;   /* counter-based dropout site (see common.h) */
+
 typedef struct {
     const void* w[5];
     const float* bias[5];
@@ -135,35 +136,33 @@ int ader_seq_bwd_ffn(const AderSeqBwdFfn* desc, void* stream);
 int ader_seq_bwd_qkv(const AderSeqBwdQkv* desc, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
-                       unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                       const AderDrop* drop, void* stream);
 /* dst[(r*row_mul+row_add), :] += src[r, :] */
 int ader_add_rows(const float* src, float* dst, int rows, int H, int row_mul, int row_add, void* stream);
 
 /* ---- attention core: modules.py:177-223 --------------------------------------------------------------- */
 int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask,
-                  const float* qmask, float* out, float* P, int B, int T, int H, int heads, unsigned drop_key,
-                  unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                  const float* qmask, float* out, float* P, int B, int T, int H, int heads, const AderDrop* drop, void* stream);
 int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* P, const float* kmask,
                   const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads,
-                  unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                  const AderDrop* drop, void* stream);
 
 /* bf16x3 variants (hi/lo operand split on v_mfma_f32_32x32x16_bf16, float32-grade accuracy); dh = H/heads even.
  * PT is stored transposed ([B,heads,key,query]) and is private to this fwd/bwd pair. */
 int ader_attn_x3_fwd(const float* Q, const float* K, const float* V, const float* q_in, const float* kmask,
-                     const float* qmask, float* out, float* PT, int B, int T, int H, int heads, unsigned drop_key,
-                     unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                     const float* qmask, float* out, float* PT, int B, int T, int H, int heads, const AderDrop* drop, void* stream);
 int ader_attn_x3_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* PT, const float* kmask,
                      const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads,
-                     unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                     const AderDrop* drop, void* stream);
 
 /* Last block: only position T-1 feeds the representation (ADER.py:85), so its attention needs one query row per sequence
  * (exact).  Q_last, q_in_last, out_last, dQ_last: [B,H]; K, V, dK, dV: [B,T,H]; P_last: [B,heads,T]; qmask_last: [B]. */
 int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, const float* q_in_last, const float* kmask,
                        const float* qmask_last, float* out_last, float* P_last, int B, int T, int H, int heads,
-                       unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base, void* stream);
+                       const AderDrop* drop, void* stream);
 int ader_attn_last_bwd(const float* dO_last, const float* Q_last, const float* K, const float* V, const float* P_last,
                        const float* kmask, const float* qmask_last, float* dQ_last, float* dK, float* dV, int B, int T,
-                       int H, int heads, unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned drop_base,
+                       int H, int heads, const AderDrop* drop,
                        void* stream);
 
 /* ---- full-catalog logits + loss: ADER.py:88-93, 108-137 ------------------------------------------------ */

@@ -113,8 +113,8 @@ def _kd_worker(rank, world, port, out):
     elo, ehi = adist.shard_bounds(N_EX, world, rank)
     tch = torch.from_numpy(teacher).cuda()
     for step in range(2):
-        dp.set_rows(lo, N)
-        eng.train_step(np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]), pos[lo:hi], N, 5e-4, rate=0.0, teacher=tch,
+        dp.set_rows(lo, N, ex_row0=B + elo)
+        eng.train_step(np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]), pos[lo:hi], N, 5e-4, rate=0.3, teacher=tch,
                        ex_trow=trow[elo:ehi], lambda_=0.6, n_train_global=B, n_ex_global=N_EX)
     torch.cuda.synchronize()
     if rank == 1:
@@ -125,8 +125,9 @@ def _kd_worker(rank, world, port, out):
 
 def test_two_ranks_distilled_step_matches_single_process():
     """ADER-mode step under data parallelism (main.py:223-256 with the rows of BOTH sub-batches sharded, losses scaled by the
-    global sub-batch sizes, dense gradient all-reduce): two ranks == one process on the whole batch.  Dropout off so the
-    exemplar rows' masks (keyed by the local row numbering) do not enter."""
+    global sub-batch sizes, dense gradient all-reduce): two ranks == one process on the whole batch.  Dropout ON: the counters of
+    both row segments of a shard (its train rows, its exemplar rows) are keyed by their global rows (AderDrop.split / base2), so
+    the two ranks draw exactly the masks of the single process."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -139,7 +140,7 @@ def test_two_ranks_distilled_step_matches_single_process():
     eng = _engine("f32")
     tch = torch.from_numpy(teacher).cuda()
     for step in range(2):
-        eng.train_step(np.concatenate([seq, ex_seq]), pos, N, 5e-4, rate=0.0, teacher=tch, ex_trow=trow, lambda_=0.6)
+        eng.train_step(np.concatenate([seq, ex_seq]), pos, N, 5e-4, rate=0.3, teacher=tch, ex_trow=trow, lambda_=0.6)
     torch.cuda.synchronize()
     ref = eng.theta.cpu().numpy()
     d = np.abs(got - ref)
