@@ -64,6 +64,9 @@ _SIGS = {
     "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_tab_update_sh": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_tab_meta_ints": [I],
+    "ader_sparse_lists_scratch_n": [I, I, I],
+    "ader_sparse_lists_starts": [I],
+    "ader_sparse_lists": [P, I, P, I, I, P, P, P, P, P, P, P, P],
     "ader_tab_tile_meta": [P, P, P, P, P, P, I, P, P],
     "ader_fused_bucket_gran": [],
     "ader_fused_bucket_id0": [],
@@ -110,7 +113,7 @@ class AderSeqBwdQkv(ctypes.Structure):
                 [("d_emb", AderDrop)] + [(k, c_int) for k in ("B", "T", "H", "pruned", "emb_bwd", "pad_")])
 
 
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_lbf_ranges_kd", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints"}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_lbf_ranges_kd", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints", "ader_sparse_lists_scratch_n", "ader_sparse_lists_starts"}
 
 
 class AderHipError(RuntimeError):

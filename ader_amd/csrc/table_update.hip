@@ -290,13 +290,13 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
             }
             for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
                 const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
-                if (id >= id_hi) break;
+                if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
                 const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
                 F_l[(id - id_lo) * H + tid] += f.sp_src[(size_t)row * H + tid] * f.sp_scale;
             }
             for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
                 const int id = (i < 8) ? mg[2 + 2 * i] : f.tg_ids[k];
-                if (id >= id_hi) break;
+                if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
                 const int b = (i < 8) ? mg[3 + 2 * i] : f.tg_rows[k];
                 float rv = (float)a.rep_hi[(size_t)b * LDR + tid];
                 if (X3) rv += (float)a.rep_lo[(size_t)b * LDR + tid];

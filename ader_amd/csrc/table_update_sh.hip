@@ -266,13 +266,13 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(ShArgs a, FuseArgs128 f) 
                 }
                 for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
                     const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
-                    if (id >= id_hi) break;
+                    if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
                     const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
                     F_l[(id - id_lo) * fs + tid] += f.sp_src[(size_t)row * H + tid] * f.sp_scale;
                 }
                 for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
                     const int id = (i < 8) ? mg[2 + 2 * i] : f.tg_ids[k];
-                    if (id >= id_hi) break;
+                    if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
                     const int b = (i < 8) ? mg[3 + 2 * i] : f.tg_rows[k];
                     F_l[(id - id_lo) * fs + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
                 }
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
                 const int ic = i < 8 ? i : 7;
                 const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];
                 const int id = (i < 8) ? id_c : f.sp_ids[k];
-                if (id >= id_hi) break;
+                if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
                 const int srow = (i < 8) ? row_c : f.sp_rows[k];
                 F_l[(id - id_lo) * H + tid] += f.sp_src[(size_t)srow * H + tid] * f.sp_scale;
             }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
                 const int ic = i < 8 ? i : 7;
                 const int id_c = mg[2 + 2 * ic], b_c = mg[3 + 2 * ic];
                 const int id = (i < 8) ? id_c : f.tg_ids[k];
-                if (id >= id_hi) break;
+                if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
                 const int b = (i < 8) ? b_c : f.tg_rows[k];
                 F_l[(id - id_lo) * H + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
             }

@@ -959,23 +959,27 @@ class Engine:
         self._advance_adam()
 
     def _sparse_lists(self, seq, lab, N):
-        """Id-sorted lists of the sparse table-gradient terms (input positions, one-hot targets) for ader_lbf_bwd_adam:
-        (ids, rows, bucket starts) x 2 -- a stable sort, so duplicates of an id are added in row order (deterministic)."""
+        """Bucketed lists of the sparse table-gradient terms (input positions, one-hot targets) for the fused table update:
+        (ids, positions, bucket starts) x 2 -- buckets of 64 ids in id order, inside a bucket in position order, so the
+        contributions to a table row are added in position order (deterministic) -- and, in x3 mode, the per-tile records of the
+        64-row kernel.  Built by ader_sparse_lists (csrc/index_prep.hip) into persistent buffers."""
         seq, lab = seq.reshape(-1), lab.reshape(-1)
-        ids, order = torch.sort(seq, stable=True)
-        tids, torder = torch.sort(lab, stable=True)
-        ids, order = ids.to(torch.int32), order.to(torch.int32)
-        tids, torder = tids.to(torch.int32), torder.to(torch.int32)
-        gran, id0 = call("ader_fused_bucket_gran"), call("ader_fused_bucket_id0")
-        key = (gran, id0, N)
-        if getattr(self, "_bkt_key", None) != key:          # bucket boundaries depend on N only
-            self._bkt_key = key
-            self._bkt_bounds = torch.arange(id0, N + gran + 1, gran, dtype=torch.int32, device=self.device)
-        sp_start = torch.searchsorted(ids, self._bkt_bounds).to(torch.int32)
-        tg_start = torch.searchsorted(tids, self._bkt_bounds).to(torch.int32)
+        if seq.dtype != torch.int32:
+            seq = seq.to(torch.int32)
+        if lab.dtype != torch.int32:
+            lab = lab.to(torch.int32)
+        n_sp, n_tg = seq.numel(), lab.numel()
+        nb1 = call("ader_sparse_lists_starts", N)
+        i32 = torch.int32
+        ids, order = self.buf("sl_ids", (n_sp,), i32), self.buf("sl_rows", (n_sp,), i32)
+        tids, torder = self.buf("sl_tids", (n_tg,), i32), self.buf("sl_trows", (n_tg,), i32)
+        sp_start, tg_start = self.buf("sl_sps", (nb1,), i32), self.buf("sl_tgs", (nb1,), i32)
+        scratch = self.buf("sl_scratch", (call("ader_sparse_lists_scratch_n", n_sp, n_tg, N),), i32)
+        call("ader_sparse_lists", ptr(seq.contiguous()), n_sp, ptr(lab.contiguous()), n_tg, N, ptr(scratch), ptr(ids), ptr(order),
+             ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), self._stream())
         meta = None
         if self.lx3:        # per-tile list records of the 64-row update kernel (table_update.hip)
-            meta = torch.empty(call("ader_tab_meta_ints", N), dtype=torch.int32, device=self.device)
+            meta = self.buf("sl_meta", (call("ader_tab_meta_ints", N),), torch.int32)
             call("ader_tab_tile_meta", ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), N, ptr(meta),
                  self._stream())
         return ids, order, sp_start, tids, torder, tg_start, meta

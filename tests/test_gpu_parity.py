@@ -710,6 +710,43 @@ def test_rank_is_exact_wrt_device_logits_and_matches_oracle(cfg):
     assert nerr(lg, olg.detach().numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("n_sp,n_tg,N", [(25600, 512, 1_000_000), (19950, 399, 43105), (7, 1, 5), (51200, 1024, 777), (1, 1, 64),
+                                         (3000, 0, 65), (204800, 4096, 1_000_000)])
+def test_sparse_lists_are_bucketed_in_position_order(n_sp, n_tg, N):
+    """ader_sparse_lists (index work, bit-exact): entries grouped by 64-id bucket in id order and, inside a bucket, in position
+    order -- i.e. a stable sort by bucket -- with the bucket offsets, against numpy.  Pads (id 0), heavy duplicates, ids in the
+    last bucket, and the gathered list sizes of an 8-rank data-parallel step."""
+    from ader_amd._lib import call, ptr
+    rs = np.random.RandomState(n_sp + N)
+    seq = rs.randint(0, N + 1, size=n_sp).astype(np.int32)
+    seq[rs.rand(n_sp) < 0.3] = 0
+    if n_sp > 10:
+        seq[:5] = N
+        seq[5:9] = 1
+        seq[9:200:3] = min(N, 37)                     # a hot item
+    lab = rs.randint(1, N + 1, size=n_tg).astype(np.int32)
+    dev = torch.device("cuda")
+    d_seq, d_lab = torch.from_numpy(seq).to(dev), torch.from_numpy(lab).to(dev)
+    nb1 = call("ader_sparse_lists_starts", N)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ids, rows, st = torch.empty(n_sp, **i32), torch.empty(n_sp, **i32), torch.empty(nb1, **i32)
+    tids, trows, tst = torch.empty(max(n_tg, 1), **i32), torch.empty(max(n_tg, 1), **i32), torch.empty(nb1, **i32)
+    scratch = torch.empty(call("ader_sparse_lists_scratch_n", n_sp, n_tg, N), **i32)
+    for rep in range(2):                              # twice: the result does not depend on the atomics' arrival order
+        call("ader_sparse_lists", ptr(d_seq), n_sp, ptr(d_lab), n_tg, N, ptr(scratch), ptr(ids), ptr(rows), ptr(st), ptr(tids),
+             ptr(trows), ptr(tst), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        bounds = np.arange(1, N + 64 + 1, 64)
+        assert len(bounds) == nb1
+        for src, got_ids, got_rows, got_st, n in ((seq, ids, rows, st, n_sp), (lab, tids, trows, tst, n_tg)):
+            real = np.flatnonzero(src > 0)               # padding entries (id 0) are left out of the lists
+            o = real[np.argsort((src[real] - 1) // 64, kind="stable")]
+            nr = len(real)
+            assert np.array_equal(got_rows.cpu().numpy()[:nr], o.astype(np.int32))
+            assert np.array_equal(got_ids.cpu().numpy()[:nr], src[o])
+            assert np.array_equal(got_st.cpu().numpy(), np.searchsorted(np.sort(src[src > 0]), bounds).astype(np.int32))
+
+
 def test_herding_bit_exact_against_oracle(golden_dir):
     from make_golden import herding_inputs
     from ader_amd.exemplar import herding_max_steps
