@@ -1440,6 +1440,30 @@ class Engine:
             out[s:e] = rk[:B]
         return out.cpu().numpy()
 
+    def row_losses(self, seq, pos, max_item):
+        """Per-row cross entropy -log softmax(logits)[label] in eval mode (the quantity the reference's `loss` exemplar selector
+        means to rank by, util.py:463-495; its graph fetches the batch MEAN, see ExemplarGenerator.loss_selection) -> float32 [n]
+        device tensor.  Exact-f32 logit kernels, chunks of MAX_ROWS rows."""
+        self._refresh_stream()
+        self.sync_table()
+        seq, pos = self._dev_i32(seq), self._dev_i32(pos)
+        n, N = seq.shape[0], int(max_item)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        st = self._stream()
+        parts = call("ader_logits_parts", N)
+        scr = torch.empty(1, dtype=torch.float32, device=self.device)
+        for s in range(0, n, self.MAX_ROWS):
+            e = min(n, s + self.MAX_ROWS)
+            B = e - s
+            rep = self.forward(seq[s:e], training=False)
+            Bp, ri = self._rowinfo(B, pos[s:e].contiguous(), B, None, None, N, 0, 1.0, 0.0, None, tag="rl_")
+            part = self.buf("lg_part", (parts * Bp * 3,))
+            lse, rowloss = self.buf("rl_lse", (Bp,)), self.buf("rl_rowloss", (Bp,))
+            call("ader_logits_loss_fwd", ptr(rep), self._pp["emb"], B, Bp, self.H, N, *ri, ptr(part), ptr(lse), ptr(rowloss),
+                 ptr(scr), st)
+            out[s:e] = rowloss[:B]
+        return out
+
     def herding_select(self, seq_rows, offs, quota, max_item):
         """Segmented herding over label groups (util.py:436-461).  seq_rows [n,T] candidates in group order, offs [G+1],
         quota [G] = min(m, n_g).  Returns (sel [n] local indices per group span, sel_cnt [G]) as numpy."""

@@ -137,6 +137,37 @@ class ExemplarGenerator:
             p += c
         return int(len(keep))
 
+    def loss_selection(self, sess, model):
+        """Exemplars with the SMALLEST loss per label (util.py:463-495), ranking by the per-row cross entropy.
+
+        The reference fetches `model.loss` -- the batch MEAN, a scalar (ADER.py:93) -- so its `loss.argsort()[:m]` sees a 0-d array,
+        yields [0] and always keeps just the FIRST candidate of every label.  This implementation does
+        what the method documents ("selects exemplars by ranking loss"): one batched eval-mode pass gives every candidate's own
+        -log softmax(logits)[label]; per label the min(m, n) rows of smallest loss are kept, ties by candidate order (stable
+        argsort, as numpy's on equal keys).  Labels with quota 0 are skipped (`if m < 0.5: continue`, util.py:481)."""
+        labels, offs, quota, rows = self._segments()
+        loss = model.engine.row_losses(rows[:, :self.maxlen], rows[:, self.maxlen], self.max_item).cpu().numpy()
+        keep, counts = [], []
+        for g, label in enumerate(labels):
+            n = int(offs[g + 1] - offs[g])
+            m = int(self.item_count[label - 1])
+            c = 0
+            if m >= 1:
+                ids = np.argsort(loss[offs[g]:offs[g + 1]], kind="stable")[:min(m, n)]
+                keep.append(ids + offs[g])
+                c = len(ids)
+            counts.append(c)
+        keep = np.concatenate(keep) if keep else np.zeros(0, np.int64)
+        sel_rows = rows[keep]
+        logits = model.engine.teacher_logits(sel_rows[:, :self.maxlen], self.max_item)
+        self.store = ExemplarStore(sel_rows, logits, self.max_item)
+        p = 0
+        for label, c in zip(labels, counts):
+            if c:
+                self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
+            p += c
+        return int(len(keep))
+
     def randomly_selection(self, sess, model):
         """Random exemplars per label (util.py:497-522): np.random.choice without replacement, in group order."""
         labels, offs, quota, rows = self._segments()

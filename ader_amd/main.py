@@ -229,10 +229,12 @@ def run(args, log=print):
                                              args.maxlen, args.dropout_rate, max_item, shard)
                 if args.selection == 'herding':
                     saved_num = exemplar.herding_selection(sess, model)
+                elif args.selection == 'loss':
+                    saved_num = exemplar.loss_selection(sess, model)
                 elif args.selection == 'random':
                     saved_num = exemplar.randomly_selection(sess, model)
                 else:
-                    raise ValueError("Invalid exemplar selection method (supported: herding, random)")
+                    raise ValueError("Invalid exemplar selection method")
                 info = 'Total saved exemplar: %d' % saved_num
                 log(info)
                 logs.write(info + '\n')
