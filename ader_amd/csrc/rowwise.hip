@@ -79,6 +79,41 @@ __global__ __launch_bounds__(256) void k_embed_bwd_rows(const int* __restrict__ 
     }
 }
 
+// EWC baseline (reference EWC.py:115-164).  Fisher accumulation: F += scale * g * g  (EWC.py:160-163: squared per-sample
+// gradients, divided by the sample count at the end).
+__global__ __launch_bounds__(256) void k_sq_accum(const float* __restrict__ g, float* __restrict__ F, size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = g[i];
+        F[i] += scale * x * x;
+    }
+}
+// Penalty lambda/2 * sum F (theta - theta_prev)^2 (EWC.py:121-124): grad += lambda * F * (theta - theta_prev); per-block
+// partial sums of the penalty go to part[blockIdx.x] (summed in a fixed order by k_sum_add: deterministic).
+__global__ __launch_bounds__(256) void k_ewc_penalty(const float* __restrict__ theta, const float* __restrict__ prev,
+                                                     const float* __restrict__ F, float* __restrict__ grad, size_t n, float lam,
+                                                     float* __restrict__ part) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = theta[i] - prev[i], f = F[i];
+        grad[i] += lam * f * d;
+        acc += f * d * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_sum_add(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] += scale * red[0];
+}
+
 // demb[ids[p]] += rows[p] * scale for p < n (ids 0 / out of range skipped): the scatter half of k_embed_bwd on its own, for rows
 // whose mask / dropout factors are already applied -- the data-parallel dense path adds the input-embedding gradient rows of
 // ALL ranks after the table gradient's all-reduce (float atomics, as k_embed_bwd).
@@ -373,6 +408,27 @@ int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, i
     hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
                        sqrtf((float)H), drop_from(drop));
     hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ader_sq_accum(const float* g, float* F, size_t n, float scale, void* stream) {
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_sq_accum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, F, n, scale);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss[0] += lambda/2 * sum F (theta - prev)^2;  grad += lambda * F * (theta - prev).  part: 1024 floats of scratch.
+int ader_ewc_penalty(const float* theta, const float* prev, const float* F, float* grad, size_t n, float lambda_, float* part,
+                     float* loss, void* stream) {
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_ewc_penalty, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, theta, prev, F, grad, n, lambda_, part);
+    hipLaunchKernelGGL(k_sum_add, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)blocks, 0.5f * lambda_, loss);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -223,6 +223,7 @@ class Engine:
         # the gradient bytes) so that its all-reduce runs UNDER the blocks backward; returns the pending collectives
         self.grad_early_hook = None
         self._early, self._dp_rows = None, None
+        self.ewc = None          # EWC baseline (EWC.py): dict(F=, prev=, lam=) -> quadratic penalty added between backward and Adam
         self.timer = None        # optional SectionTimer
         self.prune_last = True   # final block: query/FFN path only for position T-1 (exact; see forward())
         # single-GPU bf16-logits steps: apply Adam to the item table inside the table-gradient GEMM (the table gradient
@@ -1356,6 +1357,8 @@ class Engine:
         self.sync_table()
         sharded = self.dp_world > 1 and self.dp_sharded and self.shadow is not None      # (x3 / f32 logits: dense exchange)
         fuse = self.fuse_adam and (self.grad_hook is None or sharded)
+        if self.ewc is not None and self.ewc["lam"] != 0.0:
+            fuse, sharded = False, False         # the penalty's gradient lives in the dense gradient buffer
         loss = self.loss_and_grad(seq, pos, max_item, _defer_table=fuse, **kw)
         if self._deferred is not None:
             if sharded:
@@ -1366,6 +1369,10 @@ class Engine:
         if self.grad_hook is not None:
             with self._sec("grad_exchange"):
                 self.grad_hook(self)
+        if self.ewc is not None and self.ewc["lam"] != 0.0:
+            # loss += lambda/2 sum F (theta - theta_prev)^2 and its gradient (EWC.py:121-124); every rank holds the same F / prev
+            call("ader_ewc_penalty", ptr(self.theta), ptr(self.ewc["prev"]), ptr(self.ewc["F"]), ptr(self.grad), self.P,
+                 float(self.ewc["lam"]), ptr(self.buf("ewc_part", (1024,))), ptr(self.loss), self._stream())
         self.adam(lr)
         return loss
 
@@ -1439,6 +1446,39 @@ class Engine:
                  ptr(tl), ptr(rk), self._stream())
             out[s:e] = rk[:B]
         return out.cpu().numpy()
+
+    # ---------------------------------------------------------------------------------------- EWC baseline (EWC.py:115-164)
+    def ewc_snapshot(self):
+        """variables_prev = sess.run(model.variables) (main.py:260,321): the parameters the penalty pulls towards."""
+        self._refresh_stream()
+        if self.ewc is None:
+            self.ewc = {"F": torch.zeros(self.P, dtype=torch.float32, device=self.device), "lam": 0.0}
+        self.ewc["prev"] = self.theta.detach().clone()
+
+    def compute_fisher(self, seq, pos, max_item):
+        """Diagonal Fisher information of EWC.py:126-164: the mean over the n given sub-sequences of the SQUARED per-sample
+        gradient of the eval-mode cross entropy (batch of one, dropout off) w.r.t. every parameter -> self.ewc["F"] (flat, the
+        parameter layout).  One forward / backward per sample like the reference (n <= --ewc_sample_num = 1000)."""
+        self._refresh_stream()
+        self.sync_table()
+        if self.ewc is None:
+            self.ewc_snapshot()
+        seq, pos = self._dev_i32(seq), self._dev_i32(pos)
+        n = seq.shape[0]
+        F = self.ewc["F"]
+        F.zero_()
+        hook, early = self.grad_hook, self.grad_early_hook
+        self.grad_hook = self.grad_early_hook = None
+        step = self.global_step
+        try:
+            for i in range(n):
+                # (loss_and_grad overwrites only the table rows <= max_item; rows above were never touched and are zero)
+                self.loss_and_grad(seq[i:i + 1], pos[i:i + 1], max_item, rate=0.0)
+                call("ader_sq_accum", ptr(self.grad), ptr(F), self.P, 1.0 / n, self._stream())
+        finally:
+            self.grad_hook, self.grad_early_hook = hook, early
+            self.global_step = step
+        return F
 
     def row_losses(self, seq, pos, max_item):
         """Per-row cross entropy -log softmax(logits)[label] in eval mode (the quantity the reference's `loss` exemplar selector

@@ -25,7 +25,7 @@ import torch
 
 from .data import DataLoader, Evaluator, Sampler, load_exemplars
 from .exemplar import ExemplarGenerator
-from .model import Ader, Saver, Session
+from .model import Ader, Ewc, Saver, Session
 
 
 def str2bool(v):
@@ -46,6 +46,7 @@ _REFERENCE_FLAGS = (
     ("num_epochs", 100, int), ("batch_size", 256, int), ("test_batch", 64, int), ("device_num", 0, int), ("lr", 0.0005, float),
     ("num_blocks", 2, int), ("num_heads", 1, int), ("stop", 5, int), ("random_seed", 0, int), ("hidden_units", 150, int),
     ("maxlen", 50, int), ("dropout_rate", 0.3, float), ("l2_emb", 0.0, float),
+    ("ewc", False, bool), ("ewc_sample_num", 1000, int),
 )
 # Flags of this build only: (flag, default, type, help / choices)
 _BUILD_FLAGS = (
@@ -97,9 +98,9 @@ def run(args, log=print):
     if args.dataset not in ITEM_NUM:
         raise ValueError('Invalid dataset name')
     item_num = ITEM_NUM[args.dataset]
-    args.dropout_rate = 0 if args.finetune else args.dropout_rate      # main.py:141
+    args.dropout_rate = 0 if (args.ewc or args.finetune) else args.dropout_rate      # main.py:141
     dev_index = (local % max(torch.cuda.device_count(), 1)) if world > 1 else args.device_num
-    model = Ader(item_num, args, device="cuda:%d" % dev_index, dp_rank=rank, dp_world=world)
+    model = (Ewc if args.ewc else Ader)(item_num, args, device="cuda:%d" % dev_index, dp_rank=rank, dp_world=world)   # main.py:144
     dp = adist.DataParallel(model.engine, rank, world)
     baseline = args.finetune or args.dropout or args.joint
     dataloader = DataLoader(args.dataset, root=args.data_root)
@@ -145,7 +146,7 @@ def run(args, log=print):
             exemplar_sampler.add_exemplar(exemplar_data_logits)
             if args.device_feed:
                 exemplar_sampler.to_device(model.engine.device)
-            if args.fix_lambda:
+            if args.ewc or args.fix_lambda:                              # main.py:196
                 lambda_ = args.lambda_
             else:                                                        # main.py:200
                 lambda_ = args.lambda_ * math.sqrt((item_num_prev / max_item) * (exemplar_size / train_sampler.data_size()))
@@ -172,7 +173,7 @@ def run(args, log=print):
                         dp.set_rows(lo, max_item)
                     else:
                         seq_t, pos_t = seq, pos
-                    if use_ex:
+                    if use_ex and not args.ewc:                                   # main.py:225
                         ex_seq, ex_pos, idx = exemplar_sampler.next_exemplar_batch()
                         idx = np.asarray(idx, dtype=np.int32)
                         if world > 1:                                            # ... and exemplar rows (main.py:229 order kept)
@@ -194,6 +195,12 @@ def run(args, log=print):
                     else:
                         model.train_step(seq_t, pos_t, max_item, args.lr, args.dropout_rate, **kw)
                 model.engine.check_status()
+                if use_ex and args.ewc:                                           # main.py:258-262
+                    # The reference re-takes the snapshot and the Fisher information after every epoch, but its loss tensor was built
+                    # from the arrays of the moment update_loss() was called (EWC.py:115-124), so these per-epoch values never reach
+                    # the running period and are overwritten at its end: only their consumption of the `random` stream is kept.
+                    random_exemplar = random.sample(exemplar_subseq, min(len(exemplar_subseq), args.ewc_sample_num))
+                    model.compute_fisher(sess, random_exemplar, 50, max_item, dry_run=True)
                 valid_evaluator = Evaluator(valid_subseq, True, args.maxlen, args.eval_batch, max_item, 'valid', model, sess, shard)
                 info = valid_evaluator.evaluate(epoch)
                 logs.write(info + '\n')
@@ -246,6 +253,11 @@ def run(args, log=print):
                     store.save(os.path.join(d, 'exemplars.pt'))
                 del exemplar
             item_num_prev = max_item
+            if args.ewc:                                                 # main.py:319-323: Fisher information for the next period
+                exemplar_subseq = [e[0] for e in load_exemplars(fast_exemplar)]
+                model.snapshot_variables()
+                random_exemplar = random.sample(exemplar_subseq, min(len(exemplar_subseq), args.ewc_sample_num))
+                model.compute_fisher(sess, random_exemplar, 50, max_item)
         logs.flush()
     res = (np.array(MRR_20).mean(), np.array(Recall_20).mean(), np.array(MRR_10).mean(), np.array(Recall_10).mean())
     info = 'Average: (MRR@20: %.4f, RECALL@20: %.4f, MRR@10: %.4f, RECALL@10: %.4f)' % res

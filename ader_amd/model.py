@@ -68,6 +68,61 @@ class Ader:
                                          self.dropout_rate: self.args.dropout_rate})
 
 
+class Ewc(Ader):
+    """EWC baseline (reference EWC.py:14-164) on the same engine: the SASRec graph with the cross-entropy loss plus
+    lambda/2 * sum_v F_v (theta_v - theta_prev_v)^2.  `variables_prev` and `F_accum` live on the device in the flat parameter
+    layout (the reference holds them as numpy arrays baked into the graph when update_loss is called, EWC.py:115-124)."""
+
+    def update_loss(self, lambda_):
+        """EWC.py:115-124: from now on train with the penalty, using the Fisher information and the snapshot taken LAST (the
+        reference bakes the arrays of the moment of this call into the graph: later compute_fisher calls do not change the loss
+        of the running period)."""
+        e = self.engine
+        if e.ewc is None or "prev" not in e.ewc:
+            e.ewc_snapshot()
+        e.ewc["F_live"] = e.ewc["F"].clone()
+        e.ewc["prev_live"] = e.ewc["prev"].clone()
+        e.ewc["lam"] = float(lambda_)
+        self._loss_mode, self._lambda = "vanilla", 0.0
+
+    def set_vanilla_loss(self):
+        if self.engine.ewc is not None:
+            self.engine.ewc["lam"] = 0.0
+        super().set_vanilla_loss()
+
+    def train_step(self, seq, pos, max_item, lr, dropout_rate, **kw):
+        e = self.engine
+        if e.ewc is not None and e.ewc["lam"] != 0.0:
+            live = {"F": e.ewc["F_live"], "prev": e.ewc["prev_live"], "lam": e.ewc["lam"]}
+            saved, e.ewc = e.ewc, live
+            try:
+                return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, **{k: v for k, v in kw.items() if k.startswith("n_")})
+            finally:
+                e.ewc = saved
+        return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, **{k: v for k, v in kw.items() if k.startswith("n_")})
+
+    def snapshot_variables(self):
+        """model.variables_prev = sess.run(model.variables) (main.py:260, 321)."""
+        self.engine.ewc_snapshot()
+
+    def compute_fisher(self, sess, data, batch_size, max_item, dry_run=False):
+        """EWC.py:126-164 over the sub-sequences `data` (lists [items..., label]); `batch_size` only shapes the reference's
+        sampler batches (every sample is differentiated on its own), but the sampler's shuffle consumes the `random` stream and
+        fixes the sample order, so it is kept.  dry_run: consume the random stream only (see main.py)."""
+        from .data import Sampler
+        smp = Sampler(data, self.args.maxlen, batch_size, is_subseq=True)
+        if dry_run:
+            return
+        seqs, poss = [], []
+        for _ in range(smp.batch_num()):
+            s, p = smp.next_batch()
+            seqs.append(np.asarray(s.cpu() if hasattr(s, "cpu") else s))
+            poss.append(np.asarray(p.cpu() if hasattr(p, "cpu") else p))
+        if not seqs:
+            return
+        self.engine.compute_fisher(np.concatenate(seqs), np.concatenate(poss), max_item)
+
+
 class Session:
     """Minimal `tf.Session` stand-in: context manager + run(fetches, feed_dict)."""
 

@@ -298,6 +298,13 @@ int ader_sparse_lists(const int* seq, int n_sp, const int* lab, int n_tg, int N,
 int ader_fused_bucket_gran(void);
 int ader_fused_bucket_id0(void);
 
+/* ---- EWC baseline (reference EWC.py:115-164) -------------------------------------------------------------------- */
+/* Fisher accumulation F += scale * g * g over a flat buffer (EWC.py:160-163), and the penalty of EWC.py:121-124:
+ * loss[0] += lambda/2 * sum F (theta - prev)^2, grad += lambda * F * (theta - prev).  part: 1024 floats of scratch. */
+int ader_sq_accum(const float* g, float* F, size_t n, float scale, void* stream);
+int ader_ewc_penalty(const float* theta, const float* prev, const float* F, float* grad, size_t n, float lambda_, float* part,
+                     float* loss, void* stream);
+
 /* ---- optimiser: tf.train.AdamOptimizer (ADER.py:96), dense over one flat buffer ------------------------ */
 /* shadow (optional, may be NULL): bf16 shadow of the first table_elems parameters (the item table, rows of H), see above */
 int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2, float eps,

@@ -166,3 +166,69 @@ def test_torch_ops_match_the_engine():
     # dtype / shape violations raise instead of clamping
     with pytest.raises(RuntimeError):
         torch.ops.ader.rank_of_target(rep, eng.param("emb").contiguous(), dpos.long(), N)
+
+
+def test_ewc_fisher_and_penalty_match_oracle():
+    """EWC baseline (reference EWC.py:115-164).  (a) compute_fisher: mean of squared per-sample gradients of the eval-mode cross
+    entropy, against the oracle's autograd, every parameter tensor within 2e-3 normalised (twice the gradient tolerance: squares).
+    (b) one training step with the penalty lambda/2 sum F (theta - prev)^2: loss and the whole gradient (read back from Adam's
+    first-moment state, m = 0.1 g after one step) against oracle gradient + lambda F (theta - prev)."""
+    from ader_amd.engine import Engine
+    item_num, N, T, H, L = 300, 260, 50, 150, 2
+    eng = Engine(item_num, maxlen=T, hidden_units=H, num_blocks=L, num_heads=1, seed=2, logits_dtype="f32", gemm="f32")
+    g = torch.Generator().manual_seed(4)
+    for k in eng.layout:
+        if k.endswith("_b"):
+            eng.param(k).copy_(torch.randn(eng.layout[k][1], generator=g) * 0.1)
+    rs = np.random.RandomState(3)
+    n = 12
+    seq, pos = _seqs(rs, n, T, N), rs.randint(1, N + 1, size=n).astype(np.int32)
+    p64 = {k: v.double() for k, v in eng.export_params().items()}
+    F = eng.compute_fisher(seq, pos, N)
+    torch.cuda.synchronize()
+    want = {k: torch.zeros_like(v) for k, v in p64.items()}
+    for i in range(n):
+        _, og = R.loss_and_grads(p64, seq[i:i + 1], pos[i:i + 1], N, L, 1, training=False)
+        for k in want:
+            want[k] += og[k] ** 2 / n
+    for k in eng.layout:
+        got = eng.view(F, k).cpu().double()
+        err = float((got - want[k]).abs().max() / max(float(want[k].abs().max()), 1e-12))
+        assert err < 2e-3, (k, err)
+    # (b) penalty step
+    lam = 3.0
+    Fr = torch.zeros(eng.P, device="cuda")            # (the flat buffer has alignment gaps between the tensors: F stays 0 there,
+    prev = eng.theta.clone()                           #  as it does when it comes from compute_fisher)
+    for k in eng.layout:
+        eng.view(Fr, k).copy_(torch.rand(eng.layout[k][1], generator=g) * 5.0)
+        eng.view(prev, k).add_((torch.randn(eng.layout[k][1], generator=g) * 0.01).cuda())
+    eng.ewc = {"F": Fr, "prev": prev, "lam": lam}
+    B = 40
+    seq2, pos2 = _seqs(rs, B, T, N), rs.randint(1, N + 1, size=B).astype(np.int32)
+    loss = eng.train_step(seq2, pos2, N, 5e-4, rate=0.0)
+    torch.cuda.synchronize()
+    ol, og = R.loss_and_grads(p64, seq2, pos2, N, L, 1, training=True, rate=0.0, seed=2, step=0)
+    pen = 0.0
+    for k in eng.layout:
+        d = p64[k] - eng.view(prev, k).cpu().double()
+        f = eng.view(Fr, k).cpu().double()
+        pen += float((f * d * d).sum())
+        wantg = og[k] + lam * f * d
+        gotg = eng.view(eng.adam_m, k).cpu().double() / 0.1
+        err = float((gotg - wantg).abs().max() / max(float(wantg.abs().max()), 1e-12))
+        assert err < 5e-4, (k, err)
+    assert abs(float(loss.item()) - (float(ol) + 0.5 * lam * pen)) < 1e-4 * max(1.0, abs(float(ol) + 0.5 * lam * pen))
+
+
+def test_ewc_driver_two_periods():
+    """python -m ader_amd.main --ewc=True (reference main.py --ewc): period 1 vanilla, exemplars selected, Fisher information computed;
+    period 2 trains with the penalty.  Plumbing: flags, flow, sane metrics."""
+    from ader_amd import main as M
+    with tempfile.TemporaryDirectory() as d:
+        args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--ewc", "True", "--lambda_", "100", "--max_periods", "2",
+                                            "--num_epochs", "1", "--ewc_sample_num", "64", "--results_root", d])
+        lines = []
+        out = M.run(args, log=lambda s="": lines.append(str(s)))
+    assert args.dropout_rate == 0 and "Done." in lines[-1]
+    per = out["periods"]
+    assert len(per) == 2 and all(0.02 < p["recall20"] < 0.6 for p in per)
