@@ -78,6 +78,7 @@ _SIGS = {
     "ader_adam_step": [P, P, P, P, Z, F, F, F, F, P, Z, I, P],
     "ader_fill": [P, Z, F, P],
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
+    "ader_reduce_slabs_batch": [P, P, P, P, P, P, P, P, I, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
 SEQ_MAXL = 4

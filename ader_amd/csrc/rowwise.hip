@@ -323,6 +323,39 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__
     }
 }
 
+// Several such reductions in ONE launch (blockIdx.y = job): the LayerNorm gamma / beta partials of all blocks of a backward pass.
+#define RS_MAXJOBS 8
+struct ReduceJobs {
+    const float* src[RS_MAXJOBS]; float* dst[RS_MAXJOBS]; float* dst_extra[RS_MAXJOBS];
+    long slab_stride[RS_MAXJOBS]; int S[RS_MAXJOBS], ld[RS_MAXJOBS], n_rows[RS_MAXJOBS], n_cols[RS_MAXJOBS];
+};
+__global__ __launch_bounds__(1024) void k_reduce_slabs_batch(ReduceJobs j) {
+    __shared__ float red[RS_G][64];
+    const int y = blockIdx.y;
+    const int n_rows = j.n_rows[y], n_cols = j.n_cols[y], S = j.S[y];
+    float* dst_extra = j.dst_extra[y];
+    const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float acc = 0.0f;
+    int r = 0, c = 0;
+    if (i < total) {
+        r = i / n_cols; c = i - r * n_cols;
+        const float* p = j.src[y] + (size_t)r * j.ld[y] + c;
+#pragma unroll 8
+        for (int s = sg; s < S; s += RS_G) acc += p[(size_t)s * j.slab_stride[y]];
+    }
+    red[sg][o] = acc;
+    __syncthreads();
+    if (sg == 0 && i < total) {
+        float a = red[0][o];
+#pragma unroll
+        for (int k = 1; k < RS_G; ++k) a += red[k][o];
+        if (r < n_rows) j.dst[y][(size_t)r * n_cols + c] = a;
+        else dst_extra[c] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dense Adam over one flat parameter buffer, TF ApplyAdam semantics (ADER.py:96):
 //   m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= (m*lr_t)/(sqrt(v)+eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host).
@@ -502,6 +535,25 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 63) / 64), dim3(1024), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
                        n_cols, dst, dst_extra);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// n <= 8 reductions of ader_reduce_slabs in one launch (same arithmetic and summation order per job)
+int ader_reduce_slabs_batch(const float* const* src, const long* slab_stride, const int* S, const int* ld, const int* n_rows,
+                            const int* n_cols, float* const* dst, float* const* dst_extra, int n, void* stream) {
+    if (n <= 0) return 0;
+    if (n > RS_MAXJOBS) return -2;
+    ReduceJobs j = {};
+    int maxtot = 0;
+    for (int y = 0; y < n; ++y) {
+        j.src[y] = src[y]; j.dst[y] = dst[y]; j.dst_extra[y] = dst_extra[y]; j.slab_stride[y] = slab_stride[y];
+        j.S[y] = S[y]; j.ld[y] = ld[y]; j.n_rows[y] = n_rows[y]; j.n_cols[y] = n_cols[y];
+        const int total = (n_rows[y] + (dst_extra[y] ? 1 : 0)) * n_cols[y];
+        if (total > maxtot) maxtot = total;
+    }
+    if (maxtot <= 0) return 0;
+    hipLaunchKernelGGL(k_reduce_slabs_batch, dim3((maxtot + 63) / 64, n), dim3(1024), 0, (hipStream_t)stream, j);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -444,6 +444,20 @@ class Engine:
         else:
             call(name, *args, self._stream())
 
+    def _flush_late(self):
+        """Issue the queued small launches; the LayerNorm partial reductions of all blocks go out as ONE batched launch."""
+        late, self._late = self._late, []
+        red = [a for n, a in late if n == "ader_reduce_slabs"]
+        if len(red) > 1:
+            n = len(red)
+            VP, LA, IA = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+            call("ader_reduce_slabs_batch", VP(*[a[0] for a in red]), LA(*[a[1] for a in red]), IA(*[a[2] for a in red]),
+                 IA(*[a[3] for a in red]), IA(*[a[4] for a in red]), IA(*[a[5] for a in red]), VP(*[a[6] for a in red]),
+                 VP(*[a[7] for a in red]), n, self._stream())
+            late = [(nm, a) for nm, a in late if nm != "ader_reduce_slabs"]
+        for name, args in late:
+            call(name, *args, self._stream())
+
     def _atb_flush(self):
         q, self._atb_q = self._atb_q, []
         if not q:
@@ -1018,9 +1032,7 @@ class Engine:
         span = self.layout["pos"][0]
 
         def small_update():     # everything that feeds / is the update of the non-table parameters
-            for name, args in self._late:
-                call(name, *args, self._stream())
-            self._late = []
+            self._flush_late()
             self._atb_flush()
             with self._sec("adam"):
                 call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
@@ -1291,9 +1303,7 @@ class Engine:
                 self._side = torch.cuda.Stream(device=self.device, priority=-1)
             self._side.wait_stream(main)
             with Engine._OnStream(self, self._side):
-                for name, args in self._late:
-                    call(name, *args, self._stream())
-                self._late = []
+                self._flush_late()
                 self._atb_flush()
         lr_t = self._lr_t(lr)
         span = self.layout["pos"][0]

@@ -312,6 +312,9 @@ int ader_adam_step(float* p, float* m, float* v, const float* g, size_t n, float
 int ader_fill(float* p, size_t n, float value, void* stream);
 int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_rows, int n_cols, float* dst,
                       float* dst_extra, void* stream);
+/* up to 8 such reductions in one launch (arrays of n job descriptions; same arithmetic and summation order per job) */
+int ader_reduce_slabs_batch(const float* const* src, const long* slab_stride, const int* S, const int* ld, const int* n_rows,
+                            const int* n_cols, float* const* dst, float* const* dst_extra, int n, void* stream);
 
 /* ---- herding exemplar selection: util.py:401-434 ------------------------------------------------------- */
 int ader_herding_select(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
