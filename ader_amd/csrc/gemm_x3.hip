@@ -276,14 +276,14 @@ __global__ __launch_bounds__(320) void k_gemm_atb_x3_batch(AtbBatch b, float* __
 }
 
 // dW[y] = sum of product y's slabs (fixed order), row H of the augmented slab -> db[y].  grid (blocks of 64 outputs, n).
-__global__ __launch_bounds__(1024) void k_atb_reduce_batch(AtbBatch b, const float* __restrict__ slab, int H) {
-    __shared__ float red[16][64];
+__global__ __launch_bounds__(256) void k_atb_reduce_batch(AtbBatch b, const float* __restrict__ slab, int H) {
+    __shared__ float red[16][16];     // 16 slab groups x 16 outputs: small workgroups that fit next to the table update
     const int y = blockIdx.y;
     const int S = b.wg0[y + 1] - b.wg0[y];
     const float* src = slab + (size_t)b.wg0[y] * HP * HP;
     const int total = (H + 1) * H;
-    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o;
+    const int o = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
     float acc = 0.0f;
     int r = 0, c = 0;
     if (i < total) {
@@ -418,7 +418,7 @@ int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* 
     atb_batch_plan(M, n, b.wg0);
     hipLaunchKernelGGL(k_gemm_atb_x3_batch, dim3(b.wg0[n]), dim3(320), kAtbX3Lds, (hipStream_t)stream, b, slab, H);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_atb_reduce_batch, dim3(((H + 1) * H + 63) / 64, n), dim3(1024), 0, (hipStream_t)stream, b, slab, H);
+    hipLaunchKernelGGL(k_atb_reduce_batch, dim3(((H + 1) * H + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, b, slab, H);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -31,25 +31,25 @@ __global__ __launch_bounds__(256) void k_ip_count(const int* __restrict__ ids0, 
     else if (i < n0 + n1) { const int k = key_of(ids1[i - n0], gran, nkeys); if (k) atomicAdd(cnt + nkeys + k, 1); }
 }
 
-// grid = 2 (one workgroup per list), 1024 threads.  cnt [2][nkeys] -> first [2][nkeys + 1] (exclusive prefix, total at the end);
+// grid = 2 (one workgroup per list), 256 threads (small enough to start on a CU that the logit forward occupies).  cnt [2][nkeys] -> first [2][nkeys + 1] (exclusive prefix, total at the end);
 // start_l[j] = first[j + 1], j = 0 .. nkeys - 1 (= the nb + 1 bucket offsets); cnt is cleared for the scatter tickets.
-__global__ __launch_bounds__(1024) void k_ip_scan(int* __restrict__ cnt, int nkeys, int* __restrict__ first, int* __restrict__ start0,
+__global__ __launch_bounds__(256) void k_ip_scan(int* __restrict__ cnt, int nkeys, int* __restrict__ first, int* __restrict__ start0,
                                                   int* __restrict__ start1) {
-    __shared__ int part[1024];
+    __shared__ int part[256];
     const int lst = blockIdx.x, t = threadIdx.x;
     int* c = cnt + lst * nkeys;
     int* f = first + lst * (nkeys + 1);
     int* st = lst ? start1 : start0;
-    const int per = (nkeys + 1023) / 1024;
+    const int per = (nkeys + 255) / 256;
     const int lo = min(nkeys, t * per), hi = min(nkeys, lo + per);
     int s = 0;
     for (int k = lo; k < hi; ++k) s += c[k];
     part[t] = s;
     __syncthreads();
-    if (t < 64) {
-        int acc[16], tot = 0;
+    if (t < 64) {                                   // one wave scans the 256 partial sums (4 per lane)
+        int acc[4], tot = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { acc[k] = tot; tot += part[t * 16 + k]; }
+        for (int k = 0; k < 4; ++k) { acc[k] = tot; tot += part[t * 4 + k]; }
         int incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void k_ip_scan(int* __restrict__ cnt, int nke
         }
         const int base = incl - tot;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) part[t * 16 + k] = base + acc[k];
+        for (int k = 0; k < 4; ++k) part[t * 4 + k] = base + acc[k];
     }
     __syncthreads();
     int run = part[t];
@@ -133,7 +133,7 @@ int ader_sparse_lists(const int* seq, int n_sp, const int* lab, int n_tg, int N,
     if (e != hipSuccess) return (int)e;
     const int g = (n + 255) / 256;
     if (g > 0) hipLaunchKernelGGL(k_ip_count, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, cnt);
-    hipLaunchKernelGGL(k_ip_scan, dim3(2), dim3(1024), 0, st, cnt, nkeys, first, sp_start, tg_start);
+    hipLaunchKernelGGL(k_ip_scan, dim3(2), dim3(256), 0, st, cnt, nkeys, first, sp_start, tg_start);
     if (g > 0) {
         hipLaunchKernelGGL(k_ip_scatter, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, cnt, (const int*)first, tmp);
         hipLaunchKernelGGL(k_ip_rank, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, (const int*)first, (const int*)tmp,

@@ -297,13 +297,14 @@ __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ src,
 // groups sum interleaved slab subsets (s = k mod 16, ascending, 8 loads in flight) and are combined in a fixed order:
 // deterministic, and the serial chain per thread is S/16 loads instead of S (the reads are latency-bound).
 #define RS_G 16
-__global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__ src, long slab_stride, int S, int ld,
+#define RS_O 16     // outputs per workgroup: 256-thread workgroups of <= 64 registers slot into any CU next to the table update
+__global__ __launch_bounds__(RS_G * RS_O) void k_reduce_slabs(const float* __restrict__ src, long slab_stride, int S, int ld,
                                                        int n_rows, int n_cols, float* __restrict__ dst,
                                                        float* __restrict__ dst_extra) {
-    __shared__ float red[RS_G][64];
+    __shared__ float red[RS_G][RS_O];
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
-    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o;
+    const int o = threadIdx.x % RS_O, sg = threadIdx.x / RS_O;
+    const int i = blockIdx.x * RS_O + o;
     float acc = 0.0f;
     int r = 0, c = 0;
     if (i < total) {
@@ -329,14 +330,14 @@ struct ReduceJobs {
     const float* src[RS_MAXJOBS]; float* dst[RS_MAXJOBS]; float* dst_extra[RS_MAXJOBS];
     long slab_stride[RS_MAXJOBS]; int S[RS_MAXJOBS], ld[RS_MAXJOBS], n_rows[RS_MAXJOBS], n_cols[RS_MAXJOBS];
 };
-__global__ __launch_bounds__(1024) void k_reduce_slabs_batch(ReduceJobs j) {
-    __shared__ float red[RS_G][64];
+__global__ __launch_bounds__(RS_G * RS_O) void k_reduce_slabs_batch(ReduceJobs j) {
+    __shared__ float red[RS_G][RS_O];
     const int y = blockIdx.y;
     const int n_rows = j.n_rows[y], n_cols = j.n_cols[y], S = j.S[y];
     float* dst_extra = j.dst_extra[y];
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
-    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o;
+    const int o = threadIdx.x % RS_O, sg = threadIdx.x / RS_O;
+    const int i = blockIdx.x * RS_O + o;
     float acc = 0.0f;
     int r = 0, c = 0;
     if (i < total) {
@@ -506,7 +507,7 @@ int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const fl
     hipLaunchKernelGGL(k_ln_bwd, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, dy_rs, x, x_rs, gamma, mean_i, std_i, add, add_rs,
                        dx, dx_rs, slab, rows, H);
     // slab layout [G][2][H]: row 0 = dgamma partial, row 1 = dbeta partial
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + 63) / 64), dim3(1024), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + RS_O - 1) / RS_O), dim3(RS_G * RS_O), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
                        dgamma, dbeta);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -533,7 +534,7 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
                       void* stream) {
     const int total = (n_rows + (dst_extra ? 1 : 0)) * n_cols;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + 63) / 64), dim3(1024), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((total + RS_O - 1) / RS_O), dim3(RS_G * RS_O), 0, (hipStream_t)stream, src, slab_stride, S, ld, n_rows,
                        n_cols, dst, dst_extra);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -553,7 +554,7 @@ int ader_reduce_slabs_batch(const float* const* src, const long* slab_stride, co
         if (total > maxtot) maxtot = total;
     }
     if (maxtot <= 0) return 0;
-    hipLaunchKernelGGL(k_reduce_slabs_batch, dim3((maxtot + 63) / 64, n), dim3(1024), 0, (hipStream_t)stream, j);
+    hipLaunchKernelGGL(k_reduce_slabs_batch, dim3((maxtot + RS_O - 1) / RS_O, n), dim3(RS_G * RS_O), 0, (hipStream_t)stream, j);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -315,8 +315,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "x3": "bf16x3", "f32": "f32"}[args.logits], "data": "synthetic",
-            "config": {"workload": ("synthetic 1M-item catalog, seq_len=50, batch=512/GPU, %s regime%s (BASELINE.json configs[4])"
-                                    % (args.regime, ", +%d distilled exemplar rows" % E if E else "")) if args.workload == "cfgS" else
+            "config": {"workload": ("synthetic %s-item catalog, seq_len=50, batch=%d/GPU, %s regime%s (BASELINE.json configs[4]%s)"
+                                    % ("1M" if N == 1_000_000 else "%d" % N, B, args.regime,
+                                       ", +%d distilled exemplar rows" % E if E else "",
+                                       "" if (N == 1_000_000 and B == 512) else ", REDUCED SIZE")) if args.workload == "cfgS" else
                                    ("step shape of %s: N=%d items, %d train + %d distilled rows, synthetic ids (%s regime)"
                                     % ({"cfgD": "DIGINETICA ADER (BASELINE.json configs[1])", "cfgY": "YOOCHOOSE ADER (configs[2])"}
                                        [args.workload], N, B, E, args.regime)),

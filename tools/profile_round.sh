@@ -1,13 +1,16 @@
 # Round profile bundle: bench line, rocprofv3 kernel stats, separate PMC passes (HBM bytes; SQ busy counters).
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r1g
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [extra bench.py arguments, e.g. --logits x3]
 set -e
 TAG=${1:-rX}
+shift || true
+EXTRA="$@"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-python3 bench.py --steps 40 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || true
+python3 bench.py --steps 40 --warmup 5 $EXTRA > $OUT/bench.json 2> $OUT/bench.err || true
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sections > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-sections > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-sections > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-sections > /dev/null 2>&1
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sections --no-f32grade $EXTRA"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $B --steps 20 --warmup 3 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $B --steps 6 --warmup 2 > /dev/null 2>&1
 ls $OUT/*
