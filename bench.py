@@ -276,12 +276,29 @@ def main():
         }
         # HBM traffic of the dominant kernel: only from a PMC summary of THIS command passed with --pmc-json (rocprofv3 separate
         # --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, gfx950 x2 read correction applied: tools/profile_round.sh); otherwise null
-        pmc_kernel = {"logits_bwd_adam": "k_lbf_bwd_de<true" if args.logits == "bf16" else "k_tab_upd<true, true",
+        pmc_kernel = {"logits_bwd_adam": "k_tab16<" if args.logits == "bf16" else "k_tab_upd<true, true",
                       "logits_fwd": "k_lbf_fwd" if args.logits == "bf16" else "k_lx3_fwd", "adam": "k_adam"}
-        pmc, pmc_src = {}, None
-        if args.pmc_json:
-            pmc = json.load(open(args.pmc_json))["kernels"]
-            pmc_src = os.path.relpath(os.path.abspath(args.pmc_json), ROOT)
+        pmc, pmc_src, prof_us = {}, None, None
+        pmc_path = args.pmc_json
+        if pmc_path is None and N == 1_000_000 and B == 512 and not E and world == 1 and args.regime == "dense":
+            # default: the committed end-of-round profile of THIS command (profiles/CURRENT.json names it and the commit it was
+            # taken at); quoted with its provenance, never silently
+            try:
+                cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
+                tag = cur["x3" if args.logits == "x3" else "bf16"]
+                pmc_path = os.path.join(ROOT, "profiles", tag + "_pmc_hbm.json")
+                pmc_src = {"file": "profiles/%s_pmc_hbm.json" % tag, "kernel_stats": "profiles/%s_kernel_stats.csv" % tag,
+                           "profiled_at_commit": cur.get("git_head"),
+                           "note": "rocprofv3 passes of this same command, run separately (tools/profile_round.sh)"}
+            except Exception:
+                pmc_path, pmc_src = None, None
+        elif pmc_path:
+            pmc_src = {"file": os.path.relpath(os.path.abspath(pmc_path), ROOT)}
+        if pmc_path:
+            try:
+                pmc = json.load(open(pmc_path))["kernels"]
+            except Exception:
+                pmc, pmc_src = {}, None
         roof = None
         if sections:
             if "logits_bwd_adam" in sections:     # the small-parameter Adam launch is not the 7*P*4-byte kernel any more
@@ -298,12 +315,26 @@ def main():
                                       if pmc_kernel.get(dom) and k_.startswith(pmc_kernel[dom])), None)
                                 if unit == "GB/s" else None),
                     "traffic_source": pmc_src,
+                    "frac_rocprof": None,
                     "ms": sections[dom],
                     # whole step against SURVEY 8(d)'s compulsory traffic (6.64 GB at cfg-S, unfused accounting) and the HBM peak
                     "step_bytes": 6.64e9 * (N / 1e6) if (B == 512 and not E) else None,
                     "step_frac": (6.64e9 * (N / 1e6) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (B == 512 and not E and world == 1) else None,
                     "gather": gather,
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
+        if roof and pmc_src and pmc_src.get("kernel_stats") and roof["unit"] == "GB/s":
+            try:
+                import csv
+                want = pmc_kernel.get(roof["kernel"])
+                for r_ in csv.DictReader(open(os.path.join(ROOT, pmc_src["kernel_stats"]))):
+                    nm = r_["Name"].replace("void ", "")
+                    if want and nm.startswith(want):
+                        us = float(r_["AverageNs"]) / 1e3
+                        roof["ms_rocprof"] = us / 1e3
+                        roof["frac_rocprof"] = work[roof["kernel"]][1] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                        break
+            except Exception:
+                pass
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 leg only
             try:

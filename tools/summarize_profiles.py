@@ -1,7 +1,7 @@
 """Turns the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>/) into the committed summaries:
 profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_hbm.json (HBM bytes per launch: FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
 separate passes), profiles/<tag>_pmc_sq.json (per-launch SQ counters) and profiles/bench_<tag>.json.
-usage: python tools/summarize_profiles.py r1g"""
+usage: python tools/summarize_profiles.py r1g [bf16|x3]   (the second argument makes it the default profile bench.py quotes)"""
 import collections
 import csv
 import json
@@ -52,4 +52,15 @@ sq = {k: v for k, v in counters(os.path.join(src, "pmc_sq", "p_counter_collectio
 json.dump({"note": "rocprofv3 --pmc SQ_* (own pass, tools/profile_round.sh); per-launch sums over all waves.  SQ_WAVE_CYCLES, "
                    "SQ_WAIT_*, SQ_ACTIVE_INST_* are in units of 4 clocks; SQ_VALU_MFMA_BUSY_CYCLES in clocks summed over SIMDs.",
            "kernels": sq}, open(os.path.join(dst, "%s_pmc_sq.json" % tag), "w"), indent=1)
+# profiles/CURRENT.json: which summaries bench.py may quote by default (with provenance)
+import subprocess
+cur_p = os.path.join(dst, "CURRENT.json")
+cur = json.load(open(cur_p)) if os.path.exists(cur_p) else {}
+if len(sys.argv) > 2 and sys.argv[2] in ("bf16", "x3"):
+    cur[sys.argv[2]] = tag
+    try:
+        cur["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"]).decode().strip()
+    except Exception:
+        pass
+    json.dump(cur, open(cur_p, "w"), indent=1)
 print("wrote profiles/%s_*" % tag)
