@@ -52,3 +52,13 @@ def test_yoochoose_ader_regression_pin():
     r20, m20 = 100.0 * avg["recall20"], 100.0 * avg["mrr20"]
     assert abs(r20 - 72.31) <= 0.3, ("Recall@20 moved from the committed pin 72.31", r20)
     assert abs(m20 - 36.72) <= 0.3, ("MRR@20 moved from the committed pin 36.72", m20)
+
+
+def test_diginetica_ader_float32_grade_inside_the_poster_band():
+    """The same 16-period run with the float32-grade logit kernels (logits_dtype = x3: every product as three bf16 MFMAs on hi/lo
+    splits, the reference's fp32 arithmetic of ADER.py:91-93): the band of the bf16 run must hold as well."""
+    out = _run(["--dataset", "DIGINETICA", "--logits_dtype", "x3"])
+    avg = out["average"]
+    r20, m20 = 100.0 * avg["recall20"], 100.0 * avg["mrr20"]
+    assert 49.4 <= r20 <= 50.6, ("Recall@20 outside the poster band", r20)
+    assert 16.9 <= m20 <= 17.7, ("MRR@20 outside the poster band", m20)

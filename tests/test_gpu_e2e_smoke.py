@@ -26,3 +26,60 @@ def test_two_periods_of_the_driver():
     assert len(per) == 2 and per[0]["max_item"] < per[1]["max_item"]
     # one epoch only: far from converged (the full run reaches ~0.50), but well above chance (20 / 18,569 items)
     assert all(0.05 < p["recall20"] < 0.6 and 0.0 < p["mrr20"] < p["recall20"] for p in per)
+
+
+@pytest.mark.parametrize("flags", [
+    ["--finetune", "True"],                                   # BASELINE configs[0]: finetune baseline (no exemplars, dropout 0)
+    ["--dropout", "True"],
+    ["--joint", "True"],
+    ["--disable_distillation", "True"],                       # exemplars with one-hot labels (ADER.py:126-131)
+    ["--equal_exemplar", "True", "--fix_lambda", "True"],     # the poster's ADER-equal / ADER-fix ablations
+    ["--selection", "random"],
+    ["--selection", "loss"],
+    ["--logits_dtype", "x3"],
+    ["--logits_dtype", "bf16", "--batch_size", "128"],
+])
+def test_driver_flag_variants_run_two_periods(flags):
+    """Every mode of the reference driver (main.py:79-107: baselines, ablations, selectors) through two periods of one epoch."""
+    from ader_amd import main as M
+    with tempfile.TemporaryDirectory() as d:
+        args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--max_periods", "2", "--num_epochs", "1",
+                                            "--results_root", d] + flags)
+        lines = []
+        out = M.run(args, log=lambda s="": lines.append(str(s)))
+    assert "Done." in lines[-1]
+    per = out["periods"]
+    assert len(per) == 2 and all(0.03 < p["recall20"] < 0.6 and 0.0 < p["mrr20"] < p["recall20"] for p in per)
+    baseline = any(f in flags for f in ("--finetune", "--dropout", "--joint"))
+    assert any(l.startswith("Total saved exemplar:") for l in lines) != baseline       # baselines select no exemplars (main.py:294)
+
+
+def test_two_data_parallel_ranks_of_the_driver_match_one_process():
+    """`python -m torch.distributed.run --nproc-per-node 2 -m ader_amd.main` (two ranks sharing the one GPU, gloo carrying the
+    collectives) against the single process, bf16 logits, two periods: period 1 takes the row-sharded table update (equal-size
+    padded shards, sharded Adam state gathered for the checkpoint), period 2 the distilled dense all-reduce overlapped with
+    backward (exemplar rows sharded, dropout keyed by global rows); evaluation and herding are sharded by units.  Same data
+    order and masks, so the metrics agree to float noise."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--dataset", "DIGINETICA", "--max_periods", "2", "--num_epochs", "2", "--logits_dtype", "bf16"]
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+        for name, cmd in (("one", [sys.executable, "-m", "ader_amd.main"] + common + ["--results_root", os.path.join(d, "a")]),
+                          ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29533", "-m", "ader_amd.main"] + common +
+                           ["--dist_backend", "gloo", "--results_root", os.path.join(d, "b")])):
+            p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+            text = p.stdout.decode()
+            assert p.returncode == 0, text[-3000:]
+            tests_ = re.findall(r"test \(MRR@20: ([0-9.]+), RECALL@20: ([0-9.]+)", text)
+            saved = re.findall(r"Total saved exemplar: (\d+)", text)
+            assert len(tests_) == 2 and len(saved) == 2, text[-3000:]
+            res[name] = ([tuple(map(float, t)) for t in tests_], list(map(int, saved)))
+    (ta, sa), (tb, sb) = res["one"], res["two"]
+    for (m1, r1), (m2, r2) in zip(ta, tb):
+        assert abs(r1 - r2) < 0.01 and abs(m1 - m2) < 0.01, (ta, tb)
+    assert abs(sa[0] - sb[0]) <= 0.02 * sa[0], (sa, sb)           # herding on slightly different representations
