@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void k_lbf_prep(const float* __restrict__ rep,
 // The same for the padded row layout of a distilled step: rows [0, n_train) then rows [kd_row0, kd_row0 + n_ex) of rep_bf come from
 // the compact rep [n_train + n_ex, H]; everything else is zero.  Also fills the per-row info of that layout: label (0 for KD and
 // padding rows), loss weight, teacher row (-1: none) and the teacher's log-sum-exp in the log2 domain.
-__global__ __launch_bounds__(256) void k_lbf_prep_kd(const float* __restrict__ rep, bf16* __restrict__ rep_bf, int n_train, int n_ex,
+__global__ __launch_bounds__(256) void k_lbf_prep_kd(const float* __restrict__ rep, bf16* __restrict__ rep_bf, bf16* __restrict__ rep_lo,
+                                                     int n_train, int n_ex,
                                                      int kd_row0, int Bp, int H, const int* __restrict__ pos,
                                                      const int* __restrict__ ex_trow, const float* __restrict__ tlse_all, float w_train,
                                                      float w_ex, int* __restrict__ lab, float* __restrict__ wrow, int* __restrict__ trow,
@@ -45,7 +46,12 @@ __global__ __launch_bounds__(256) void k_lbf_prep_kd(const float* __restrict__ r
     int src = -1;
     if (b < n_train) src = b;
     else if (b >= kd_row0 && b - kd_row0 < n_ex) src = n_train + (b - kd_row0);
-    rep_bf[i] = (bf16)((src >= 0 && c < H) ? rep[(size_t)src * H + c] : 0.0f);
+    {
+        const float x = (src >= 0 && c < H) ? rep[(size_t)src * H + c] : 0.0f;
+        const bf16 h = (bf16)x;
+        rep_bf[i] = h;
+        if (rep_lo) rep_lo[i] = (bf16)(x - (float)h);          // x3 mode: low-order operand rows
+    }
     if (c == 0) {
         int l = 0, tr = -1; float w = 0.0f, tl = 0.0f;
         if (b < n_train) { l = pos[b]; w = (l > 0) ? w_train : 0.0f; }
@@ -84,12 +90,13 @@ struct LbfArgs {
     const float* teacher; long ldt;     // teacher logits [*, ldt] fp32, row trow[b] for batch row b
     const int* trow;            // [Bp] teacher row of a KD row (-1: padding)
     const float* tlse2;         // [Bp] log2-domain log-sum-exp of the teacher row over [0, Np)
-    float* pO2;                 // [ranges][Bp - kd_row0][HP] teacher readout partials: sum_j softmax(t)_j * E_j
+    float* pO2;                 // [ranges2][Bp - kd_row0][HP] teacher readout partials: sum_j softmax(t)_j * E_j
+    int ranges2;                // item ranges of the readout (= ranges when it shares the forward's launch)
 };
 
 static inline void lbf_no_kd(LbfArgs& a) {
     a.kd_row0 = a.Bp; a.Np = 0; a.n_train = a.B; a.n_ex = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
-    a.pO2 = nullptr;
+    a.pO2 = nullptr; a.ranges2 = 0;
 }
 
 #define FB 32                      // items per streamed block
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
             // distilled row: the target "row" is the teacher readout O2 = sum_j softmax(t)_j E_j (range partials summed in fixed
             // order) and  sum_j pt_j s_j = rep . O2  with the operands the MFMA path multiplied
             const int Bk = a.Bp - a.kd_row0;
-            for (int i = 0; i < R; ++i) et += a.pO2[((size_t)i * Bk + (b - a.kd_row0)) * HP + tid];
+            for (int i = 0; i < a.ranges2; ++i) et += a.pO2[((size_t)i * Bk + (b - a.kd_row0)) * HP + tid];
             part = (X3 ? rep_f[(size_t)bc_ * H + tid] : (float)a.rep_bf[(size_t)b * LDR + tid]) * et;
         } else if (t >= 0) {                         // target logit with the same bf16-rounded operands as the MFMA path
             if (X3) { et = emb1_f[(size_t)t * H + tid]; part = rep_f[(size_t)bc_ * H + tid] * et; }
@@ -521,11 +528,15 @@ struct Lx3Args {
     const bf16* rep_hi; const bf16* rep_lo;     // [Bp][LDR]
     int Bp, H, N, ranges;
     float* pm; float* pl; float* pO;
+    // distilled rows (as LbfArgs): rows [kd_row0, Bp) take the softmax over the first Np items and have a teacher readout chunk
+    int kd_row0, Np;
+    const float* teacher; long ldt; const int* trow; const float* tlse2; float* pO2;
+    int ranges2;                // item ranges of the readout launch (it is a launch of its own in x3 mode: its own partition)
 };
 
 #define XPPT 5                     // 16-byte fp32 vectors per thread per 32-item block (5 * 1024 floats >= 32 * 160)
 // XRD = register ring depth, OCC = workgroups per CU the register budget is sized for (256 / 512 registers per lane)
-template <int XRD, int OCC>
+template <int XRD, int OCC, bool READOUT = false>
 __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* E_l = (bf16*)smem_raw;                       // [2 buffers][2 planes: hi, lo][FB][LDR]
@@ -533,23 +544,32 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int nchunk = a.Bp >> 7;
+    // READOUT = false: the Bp/128 softmax chunks; READOUT = true (own launch: its registers would otherwise push the softmax path
+    // into spills): one teacher-readout chunk per 128 KD rows, O2 = sum_j softmax(teacher)_j E_j as in lbf_teacher_readout
+    const int nchunk = READOUT ? (a.Bp - a.kd_row0) >> 7 : a.Bp >> 7;
+    const int nranges = READOUT ? a.ranges2 : a.ranges;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int range = xcd + 8 * (slot / nchunk), bc = slot % nchunk;
-    if (range >= a.ranges) return;
-    const int N = a.N, H = a.H;
-    const int nblk = (N + FB - 1) / FB;
-    const int per = (nblk + a.ranges - 1) / a.ranges;
-    const int blk_begin = range * per, blk_end = min(nblk, blk_begin + per);
+    const int range = xcd + 8 * (slot / nchunk);
+    int bc = slot % nchunk;
+    if (range >= nranges) return;
+    constexpr bool readout = READOUT;
+    if (readout) bc += a.kd_row0 >> 7;
+    const int H = a.H;
+    const int N = (bc * 128 >= a.kd_row0) ? a.Np : a.N;              // columns of this chunk's softmax
+    const int nblk_all = ((READOUT ? N : a.N) + FB - 1) / FB;          // (the readout partitions only the Np columns it reads)
+    const int per = (nblk_all + nranges - 1) / nranges;
+    const int blk_begin = range * per, blk_end = min((N + FB - 1) / FB, blk_begin + per);
     const int nb_blocks = max(0, blk_end - blk_begin);
     const int b0 = bc * 128 + wave * 32;
     // K padding (columns >= H) of both planes of both buffers stays zero: the block stores never touch it
     for (int i = tid; i < 2 * 2 * FB * LDR / 8; i += 256) ((uint4*)E_l)[i] = make_uint4(0u, 0u, 0u, 0u);
     bf16x8 bh_[10], bl_[10];
+    if (!readout) {
 #pragma unroll
-    for (int ks = 0; ks < 10; ++ks) {
-        bh_[ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
-        bl_[ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
+        for (int ks = 0; ks < 10; ++ks) {
+            bh_[ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
+            bl_[ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + r) * LDR + 16 * ks + 8 * hh);
+        }
     }
     f32x16 O[5];
 #pragma unroll
@@ -603,11 +623,80 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
         }                                                                                                \
         if (head && tid == 0) LX3_PUT2(dst_, 0, ringh[slot_][0], ringh[slot_][1]);                       \
     }
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    if constexpr (READOUT) {
+        // teacher readout of 128 KD rows (see lbf_teacher_readout): O2 += PT^T . E with PT = softmax(teacher) split hi/lo
+        const int tr = a.trow[b0 + r];
+        const float tl2 = a.tlse2[b0 + r];
+        const float* trp = a.teacher + (size_t)(tr < 0 ? 0 : tr) * a.ldt;
+        const bool vec = ((a.ldt & 3) == 0) && (((uintptr_t)a.teacher & 15) == 0);
+        const int Np = N;
+        float tc[16], tn[16];
+#pragma unroll
+        for (int s_ = 0; s_ < XRD; ++s_) if (s_ < nb_blocks) LX3_LOAD(s_, blk_begin + s_);
+        if (nb_blocks > 0) LBF_TLOAD(tc, blk_begin);
+        __syncthreads();
+        int cur = 0, i = 0;
+        while (i < nb_blocks) {
+#pragma unroll
+            for (int s_ = 0; s_ < XRD; ++s_) {
+                if (i >= nb_blocks) break;
+                const int blk = blk_begin + i;
+                const int i0 = blk * FB;
+                LX3_STORE(s_, cur);
+                if (i + XRD < nb_blocks) LX3_LOAD(s_, blk + XRD);
+                if (i + 1 < nb_blocks) { LBF_TLOAD(tn, blk + 1); }
+                __syncthreads();
+                const bf16* Eh = E_l + cur * 2 * FB * LDR;
+                f32x16 S;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float x = (tr >= 0) ? __builtin_amdgcn_exp2f(fmaf(tc[j], LOG2E, -tl2)) : 0.0f;
+                    S[j] = (i0 + acc_row(j, hh) < Np) ? x : 0.0f;
+                }
+                const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
+                bf16x8 pl0, pl1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { pl0[j] = (bf16)(S[j] - (float)pa0[j]); pl1[j] = (bf16)(S[8 + j] - (float)pa1[j]); }
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const bf16* base = Eh + (4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
+                    const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
+                    const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
+                    bf16x8 b0v, b1v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
+                    O[nb] = mfma_bf16(pa0, b0v, O[nb]);
+                    O[nb] = mfma_bf16(pa1, b1v, O[nb]);
+                    O[nb] = mfma_bf16(pl0, b0v, O[nb]);
+                    O[nb] = mfma_bf16(pl1, b1v, O[nb]);
+                    const bf16* bl = base + FB * LDR;
+                    const bf16x4 m0 = tr_read(bl), n0 = tr_read(bl + 8 * LDR);
+                    const bf16x4 m1 = tr_read(bl + 16 * LDR), n1 = tr_read(bl + 24 * LDR);
+                    bf16x8 c0v, c1v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { c0v[j] = m0[j]; c0v[4 + j] = n0[j]; c1v[j] = m1[j]; c1v[4 + j] = n1[j]; }
+                    O[nb] = mfma_bf16(pa0, c0v, O[nb]);
+                    O[nb] = mfma_bf16(pa1, c1v, O[nb]);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tc[j] = tn[j];
+                cur ^= 1;
+                ++i;
+            }
+        }
+        float* o2 = a.pO2 + ((size_t)range * (a.Bp - a.kd_row0) + (b0 - a.kd_row0)) * HP;
+#pragma unroll
+        for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o2[(size_t)acc_row(j, hh) * HP + 32 * nb + r] = O[nb][j];
+        return;
+    }
+    else {
 #pragma unroll
     for (int s_ = 0; s_ < XRD; ++s_) if (s_ < nb_blocks) LX3_LOAD(s_, blk_begin + s_);
     __syncthreads();                                    // zero fill done before the first block store
     int cur = 0, i = 0;
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
     while (i < nb_blocks) {
 #pragma unroll
         for (int s_ = 0; s_ < XRD; ++s_) {
@@ -695,6 +784,7 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r] = O[nb][j];
+    }
 }
 
 // ============================================================================================= C ABI
@@ -780,9 +870,9 @@ int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_tr
     a.ranges = ader_lbf_ranges(N, nchunk * 128);
     a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
     a.kd_row0 = kd_row0; a.Np = Np; a.n_train = n_train; a.n_ex = n_ex; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
-    a.pO2 = pO2;
-    hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, n_train, n_ex, kd_row0, Bp, H,
-                       pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
+    a.pO2 = pO2; a.ranges2 = a.ranges;
+    hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, (bf16*)nullptr, n_train, n_ex,
+                       kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * nchunk), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        (const float*)nullptr, (const float*)nullptr);
@@ -856,35 +946,78 @@ int ader_lx3_prep(const float* rep, void* rep_hi, void* rep_lo, int B, int Bp, i
 
 // Forward of the one-hot softmax CE over items 1..N at float32 grade (three bf16 MFMAs per product), streaming the fp32
 // table itself.  Same scratch and outputs as ader_lbf_fwd; rep_hi / rep_lo: Bp*168 bf16 each.
+static int lx3_attr() {
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lx3_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)2 * 2 * FB * LDR * sizeof(bf16)));
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_lx3_fwd<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)2 * 2 * FB * LDR * sizeof(bf16)));
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    return 0;
+}
+
 int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
                  void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
                  float* drep, void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || ((uintptr_t)emb & 7)) return -2;
     const size_t lds = (size_t)2 * 2 * FB * LDR * sizeof(bf16);
-    static bool f = false;
-    static int variant = 0;
-    if (!f) {
-        const char* v = getenv("ADER_LX3_VARIANT");        // tuning switch: 0 = two workgroups per CU, 1 = one (deeper ring)
-        variant = (v && v[0] == '1') ? 1 : 0;
-        hipError_t e = hipFuncSetAttribute((const void*)k_lx3_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lx3_fwd<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        f = true;
-    }
+    int rc = lx3_attr();
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     Lx3Args x;
     x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
     x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
+    x.kd_row0 = Bp; x.Np = 0; x.teacher = nullptr; x.ldt = 0; x.trow = nullptr; x.tlse2 = nullptr; x.pO2 = nullptr; x.ranges2 = 0;
     LbfArgs a;
     a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
     a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H);
-    if (variant) hipLaunchKernelGGL((k_lx3_fwd<3, 1>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
-    else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
+    hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// x3 distilled forward: scratch sizes.  pm / pl / pO use R = ader_lbf_ranges(N, Bp); the teacher readout is a launch of its own with
+// R2 = ader_lx3_readout_ranges(Np, Bp - kd_row0) item ranges: pO2 holds R2 * (Bp - kd_row0) * 160 floats.
+int ader_lx3_readout_ranges(int Np, int Bk) { return ader_lbf_ranges(Np, Bk); }
+
+// ader_lbf_fwd_kd at float32 grade: the distilled step's forward on the x3 kernels (arguments as ader_lbf_fwd_kd, with the fp32
+// table instead of the shadow and the two operand planes rep_hi / rep_lo).
+int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
+                    int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all, float w_train,
+                    float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo, float* pm, float* pl,
+                    float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+    if (n_train + n_ex <= 0) return 0;
+    if (Bp % 128 != 0 || kd_row0 % 128 != 0 || n_train > kd_row0 || kd_row0 + n_ex > Bp || H > HP || (H & 1) || H < 2 || N > item_num ||
+        Np > N || Np < 1 || ((uintptr_t)emb & 7)) return -2;
+    const size_t lds = (size_t)2 * 2 * FB * LDR * sizeof(bf16);
+    int rc = lx3_attr();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Lx3Args x;
+    x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
+    x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
+    x.kd_row0 = kd_row0; x.Np = Np; x.teacher = teacher; x.ldt = ldt; x.trow = trow; x.tlse2 = tlse2; x.pO2 = pO2;
+    x.ranges2 = ader_lx3_readout_ranges(Np, Bp - kd_row0);
+    LbfArgs a;
+    a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = n_train + n_ex; a.Bp = Bp; a.H = H; a.N = N;
+    a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
+    a.kd_row0 = kd_row0; a.Np = Np; a.n_train = n_train; a.n_ex = n_ex; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
+    a.pO2 = pO2; a.ranges2 = x.ranges2;
+    hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, n_train, n_ex,
+                       kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
+    hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
+    hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
+    hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
+                       emb + H, rep);
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -46,9 +46,13 @@ struct TabArgs {
     const float* off;       // [Bp] log2(w_b) - lse2_b; -inf for rows without a loss term
     int Bp, H, N, tile_off;
     float* demb1;           // !ADAM: gradient row of item 1
+    // KD rows (ADER.py:132-137): batch rows [kd_row0, Bp) are distilled exemplar rows: dlogit = w (softmax(s[:Np]) - softmax(t)),
+    // zero for items >= Np.  kd_row0 % 128 == 0; = Bp: none.  trow / tlse2: [Bp] as written by ader_lx3_fwd_kd.
+    int kd_row0, Np;
+    const float* teacher; long ldt; const int* trow; const float* tlse2;
 };
 
-template <bool X3, bool ADAM, bool EXTRA>
+template <bool X3, bool ADAM, bool EXTRA, bool KD = false>
 __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr bool RES = ADAM && !X3;             // theta tile resident in LDS from the operand cut to the optimiser phase
@@ -76,6 +80,8 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
     float* F_l = (float*)(wk + 4 * ph);                          // dE staging tile, flat [64*H]
     float* off_l = (float*)(wk + work_bytes);                    // [Bp]
     int* meta_l = (int*)(off_l + a.Bp);                          // ADAM: the tile's record [2][TM_LIST] (k_tile_meta)
+    float* toff_l = (float*)(meta_l + 2 * TM_LIST);              // KD: [Bp - kd_row0] log2(w_b) - tlse2_b (-inf: no teacher term)
+    int* trow_l = (int*)(toff_l + (a.Bp - a.kd_row0));           // KD: [Bp - kd_row0] teacher row (0 for padding rows)
 
     // ---- theta tile -> LDS (zero beyond the table's last row)
     {
@@ -90,6 +96,14 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
         f32x2_t h2 = (f32x2_t){0.f, 0.f};
         if (head && tid == 0 && n_av > 0) h2 = *(const f32x2_t*)gsrc;
         for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+        if (KD) {
+            for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
+                const int b = a.kd_row0 + i, tr = a.trow[b];
+                const float w = f.wrow[b];
+                toff_l[i] = (tr >= 0 && w > 0.0f) ? log2f(w) - a.tlse2[b] : -INFINITY;
+                trow_l[i] = tr < 0 ? 0 : tr;
+            }
+        }
         if (ADAM && tid < 2 * TM_LIST) meta_l[tid] = f.tile_meta[(size_t)tile * (2 * TM_LIST) + tid];     // this tile's list record
 #pragma unroll
         for (int u = 0; u < NVEC; ++u) {
@@ -182,6 +196,20 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
             S[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 1], LOG2E, o4.y));
             S[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 2], LOG2E, o4.z));
             S[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 3], LOG2E, o4.w));
+        }
+        if (KD && b0 >= a.kd_row0) {   // dlogit of a distilled row: w (softmax(s[:Np]) - softmax(t)) for items < Np, 0 beyond
+            const int it = tile0 + ih * 32 + r;                  // (wave-uniform branch: chunks do not straddle kd_row0)
+            if (it < a.Np) {
+                float tv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tv[j] = a.teacher[(size_t)trow_l[b0 - a.kd_row0 + acc_row(j, hh)] * a.ldt + it];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    S[j] -= __builtin_amdgcn_exp2f(fmaf(tv[j], LOG2E, toff_l[b0 - a.kd_row0 + acc_row(j, hh)]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) S[j] = 0.0f;
+            }
         }
         const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
         bf16x8 pl0, pl1;
@@ -415,18 +443,18 @@ static size_t tab_lds(int Bp, int H, bool x3, bool adam) {
     const size_t tile = (size_t)TI * H * 4 + 16;
     size_t work = (size_t)TI * LDR * 2 * (x3 ? 2 : 1);
     if (work < tile) work = tile;
-    return ((adam && !x3) ? tile : 0) + work + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int);
+    return ((adam && !x3) ? tile : 0) + work + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int) + (size_t)Bp * 8;
 }
 
-template <bool X3, bool ADAM, bool EXTRA>
+template <bool X3, bool ADAM, bool EXTRA, bool KD = false>
 static int tab_launch(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
     static int lds_set = 0;
     if ((int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tab_upd<X3, ADAM, EXTRA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tab_upd<X3, ADAM, EXTRA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         lds_set = (int)lds;
     }
-    hipLaunchKernelGGL((k_tab_upd<X3, ADAM, EXTRA>), dim3(tiles), dim3(256), lds, st, a, fa);
+    hipLaunchKernelGGL((k_tab_upd<X3, ADAM, EXTRA, KD>), dim3(tiles), dim3(256), lds, st, a, fa);
     return 0;
 }
 
@@ -456,6 +484,7 @@ int ader_tab_grad(const void* rep_hi, const void* rep_lo, const float* emb, int 
     TabArgs a;
     a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
     a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = demb + H;
+    a.kd_row0 = Bp; a.Np = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
     FuseArgs fa = {};
     const int tiles = (N + TI - 1) / TI;
     int rc = rep_lo ? tab_launch<true, false, false>(a, fa, tiles, tab_lds(Bp, H, true, false), st)
@@ -487,6 +516,7 @@ int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int it
     TabArgs a;
     a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
     a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = nullptr;
+    a.kd_row0 = Bp; a.Np = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
     FuseArgs fa;
     fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
     fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
@@ -508,6 +538,35 @@ int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int it
     int rc;
     if (x3) rc = extra_grad ? tab_launch<true, true, true>(a, fa, te - tb, lds, st) : tab_launch<true, true, false>(a, fa, te - tb, lds, st);
     else rc = extra_grad ? tab_launch<false, true, true>(a, fa, te - tb, lds, st) : tab_launch<false, true, false>(a, fa, te - tb, lds, st);
+    if (rc) return rc;
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The x3-mode update of a DISTILLED step (ADER.py:132-137): batch rows [kd_row0, Bp) of the padded layout of ader_lx3_fwd_kd are
+// exemplar rows whose dlogit is w (softmax(s[:Np]) - softmax(teacher row)); wrow / off / trow / tlse2 as that call left them.
+int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int Bp, int kd_row0, int H, int N, int Np, const float* off,
+                       const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale, const int* tg_ids,
+                       const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, const float* teacher, long ldt,
+                       const int* trow, const float* tlse2, float* emb, float* adam_m, float* adam_v, float lr_t, float beta1,
+                       float beta2, float eps, void* stream) {
+    if (Bp <= 0) return 0;
+    if (Bp % 128 != 0 || kd_row0 % 128 != 0 || kd_row0 >= Bp || H > HP || (H & 1) || H < 2 || N > item_num || !rep_lo || !teacher ||
+        !trow || !tlse2 || Np < 1 || Np > N) return -2;
+    const uintptr_t ph = (uintptr_t)emb & 15;
+    if ((ph & 7) || ((uintptr_t)adam_m & 15) != ph || ((uintptr_t)adam_v & 15) != ph) return -2;
+    TabArgs a;
+    a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
+    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = nullptr;
+    a.kd_row0 = kd_row0; a.Np = Np; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
+    FuseArgs fa;
+    fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
+    fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
+    fa.tile_meta = tile_meta;
+    fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = nullptr;
+    fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
+    fa.extra1 = nullptr;
+    int rc = tab_launch<true, true, false, true>(a, fa, (N + TI - 1) / TI, tab_lds(Bp, H, true, true), (hipStream_t)stream);
     if (rc) return rc;
     HIP_LAUNCH_CHECK();
     return 0;

@@ -684,9 +684,9 @@ class Engine:
         # exemplar rows the exact-f32 kernels; their table gradient enters the fused update as a dense extra term
         split_kd = bool(self.lfast and teacher is not None and n_ex > 0 and n_train > 0 and _defer_table
                         and N >= self._grad_hi and self.dp_world == 1 and self.kd_split)
-        # ... or, bf16 mode (default): ALL rows on the flash path -- the exemplar rows as their own 128-row chunks whose softmax runs
+        # ... or (default, bf16 and x3 modes): ALL rows on the flash path -- the exemplar rows as their own 128-row chunks whose softmax runs
         # over the first Np items, with the teacher term as a second readout (forward) and a subtraction inside the fused update
-        kd_fast = bool(split_kd and not self.lx3 and self.kd_fast
+        kd_fast = bool(split_kd and self.kd_fast
                        and ((n_train + 127) // 128 + (n_ex + 127) // 128) * 128 <= self.MAX_ROWS)
         if kd_fast:
             split_kd = False
@@ -791,21 +791,31 @@ class Engine:
         tlse_all = self._teacher_lse(teacher, Np)
         lab, trow = self.buf("kf_lab", (Bp,), torch.int32), self.buf("kf_trow", (Bp,), torch.int32)
         wrow, tlse2 = self.buf("kf_w", (Bp,)), self.buf("kf_tlse2", (Bp,))
-        R = call("ader_lbf_ranges_kd", N, Bp, Bt)
+        if self.lx3:      # the x3 teacher readout is a launch of its own, with its own item ranges
+            R, R2 = call("ader_lbf_ranges", N, Bp), call("ader_lx3_readout_ranges", Np, Bk)
+        else:
+            R = R2 = call("ader_lbf_ranges_kd", N, Bp, Bt)
         rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
+        rep_lo = self.buf("lbf_rep_lo", (Bp * 168,), torch.bfloat16) if self.lx3 else None
         pm, pl = self.buf("lbf_pm", (R * Bp,)), self.buf("lbf_pl", (R * Bp,))
-        pO, pO2 = self.buf("lbf_pO", (R * Bp * 160,)), self.buf("lbf_pO2", (R * Bk * 160,))
+        pO, pO2 = self.buf("lbf_pO", (R * Bp * 160,)), self.buf("lbf_pO2", (R2 * Bk * 160,))
         lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
         drep = self.buf("drep", (B, H))
         with self._sec("logits_fwd"):
-            call("ader_lbf_fwd_kd", ptr(rep), ptr(self.shadow), self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos), ptr(ex_trow),
-                 ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow), ptr(trow),
-                 ptr(tlse2), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss),
-                 ptr(drep), st)
+            if self.lx3:
+                call("ader_lx3_fwd_kd", ptr(rep), self._pp["emb"], self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
+                     ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
+                     ptr(trow), ptr(tlse2), ptr(rep_bf), ptr(rep_lo), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off),
+                     ptr(rowloss), ptr(self.loss), ptr(drep), st)
+            else:
+                call("ader_lbf_fwd_kd", ptr(rep), ptr(self.shadow), self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
+                     ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
+                     ptr(trow), ptr(tlse2), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off), ptr(rowloss),
+                     ptr(self.loss), ptr(drep), st)
         self._lists_async(seq, lab, N)            # one-hot targets in the padded row numbering (label 0 = none)
         self._grad_hi = max(self._grad_hi, N)
         dx = self._blocks_backward(seq, drep, True, None)
-        self._deferred = dict(seq=seq, g=dx, B=Bp, Bp=Bp, N=N, rep_bf=rep_bf, rep_lo=None, off=off, lab=lab, wrow=wrow, extra=None,
+        self._deferred = dict(seq=seq, g=dx, B=Bp, Bp=Bp, N=N, rep_bf=rep_bf, rep_lo=rep_lo, off=off, lab=lab, wrow=wrow, extra=None,
                               kd=dict(row0=Bt, Np=Np, teacher=teacher, trow=trow, tlse2=tlse2))
         return self.loss
 
@@ -1051,7 +1061,13 @@ class Engine:
             with Engine._OnStream(self, self._side):
                 small_update()
         with self._sec("logits_bwd_adam"):
-            if self.lx3:
+            if self.lx3 and D.get("kd"):
+                K = D["kd"]
+                call("ader_tab_update_kd", ptr(D["rep_bf"]), ptr(D["rep_lo"]), self.item_num, D["Bp"], K["row0"], H, D["N"], K["Np"],
+                     ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
+                     ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(K["teacher"]), K["teacher"].stride(0), ptr(K["trow"]),
+                     ptr(K["tlse2"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1, self.beta2, self.eps, st)
+            elif self.lx3:
                 call("ader_tab_update", ptr(D["rep_bf"]), ptr(D["rep_lo"]), None, self.item_num, D["B"], D["Bp"], H, D["N"],
                      ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                      ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,

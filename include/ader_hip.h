@@ -215,6 +215,15 @@ int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_tr
                     float w_train, float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_bf, float* pm, float* pl,
                     float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream);
 int ader_lbf_ranges_kd(int N, int Bp, int kd_row0);
+/* the same forward at float32 grade (x3): the fp32 table instead of the shadow, two operand planes rep_hi / rep_lo.  Scratch:
+ * pm / pl / pO with R = ader_lbf_ranges(N, Bp); pO2: ader_lx3_readout_ranges(Np, Bp - kd_row0) * (Bp - kd_row0) * 160 floats (the
+ * teacher readout is a launch of its own here) */
+int ader_lx3_readout_ranges(int Np, int Bk);
+int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
+                    int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all,
+                    float w_train, float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo,
+                    float* pm, float* pl, float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep,
+                    void* stream);
 /* Pieces of ader_lbf_fwd for catalog-sharded data parallelism (each rank holds 1/W of the table rows and streams only
  * those; ADER.py:91-93 with the item axis split across ranks): ader_lbf_prep builds the bf16 operand rows [Bp,168] of the
  * (all-gathered) representations; ader_lbf_fwd_shard returns per batch row the softmax partials {max (log2 domain), sum,
@@ -261,6 +270,12 @@ int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int it
                     const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, float* emb,
                     float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
                     int tile_count, const float* extra_grad, void* stream);
+/* ... and for a DISTILLED step at float32 grade (x3; layout and arguments as ader_lx3_fwd_kd left them; ADER.py:132-137) */
+int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int Bp, int kd_row0, int H, int N, int Np,
+                       const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                       const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow,
+                       const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
+                       float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
 /* The bf16-mode form over 128-row tiles: the GEMM operand is the tile's bf16 shadow rows (`shadow` is read AND rewritten) and the
  * sorted lists are addressed through their 64-id bucket offsets sp_start / tg_start.  Faster than ader_tab_update(rep_lo = NULL) at
  * H = 150 on MI355X although it reads 336 B more per row (measurements: DESIGN.md). */

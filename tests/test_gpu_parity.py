@@ -555,6 +555,36 @@ def test_split_kd_step_matches_all_f32_kd_step():
 
 
 @pytest.mark.parametrize("cfg,n_ex,Np", [(BF16_CFGS[1], 37, 4000), (BF16_CFGS[0], 70, 650), (BF16_CFGS[1], 200, 4321)])
+def test_kd_fast_x3_step_matches_exact_oracle(cfg, n_ex, Np):
+    """The all-flash distilled step at float32 grade (logits_dtype = x3): loss and the whole gradient (from Adam's first moment
+    after one step, m = 0.1 g) against the plain float64 oracle of ADER.py:108-137 at the bounds of the exact-f32 kernels with
+    bf16x3 block GEMMs: loss 2e-5, every gradient tensor 6e-4 normalised."""
+    item_num, T, H, L, heads, B, N = cfg
+    rs = np.random.RandomState(5)
+    seq = _seqs(rs, B + n_ex, T, N)
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    pos[0] = N
+    teacher = torch.from_numpy((rs.standard_normal((n_ex + 9, Np)) * 2).astype(np.float32)).cuda()
+    trow = rs.permutation(n_ex + 9)[:n_ex].astype(np.int32)
+    lam = 0.7
+    eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="x3")
+    p64 = _params(eng, torch.float64)
+    eng.global_step = 3
+    loss = eng.train_step(seq, pos, N, 5e-4, rate=0.3, teacher=teacher, ex_trow=trow, lambda_=lam)
+    torch.cuda.synchronize()
+    eng.check_status()
+    assert eng._ws.get("lbf_pO2") is not None                     # the fast path ran
+    mk = relu_masks_of(eng)
+    ol, og = R.loss_and_grads(p64, seq, pos, N, L, heads, training=True, rate=0.3, seed=8, step=3, relu_masks=mk,
+                              ex_logits=teacher.cpu()[trow.astype(np.int64)].double(), lambda_=lam)
+    assert abs(float(loss.item()) - float(ol)) < 2e-5 * max(1.0, abs(float(ol)))
+    for k in eng.layout:
+        g = eng.view(eng.adam_m, k).cpu().numpy() / 0.1
+        e = nerr(g, og[k].numpy(), floor=1e-4)
+        assert e < 6e-4, (k, e)
+
+
+@pytest.mark.parametrize("cfg,n_ex,Np", [(BF16_CFGS[1], 37, 4000), (BF16_CFGS[0], 70, 650), (BF16_CFGS[1], 200, 4321)])
 def test_kd_fast_step_matches_bf16_aware_oracle(cfg, n_ex, Np):
     """Distilled step with every row on the bf16 flash path (Engine.kd_fast: exemplar rows as their own chunks with the softmax
     over the first Np items, teacher readout in the forward, teacher term subtracted inside the fused table update).  One step
