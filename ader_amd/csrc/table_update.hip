@@ -496,6 +496,31 @@ int ader_tab_grad(const void* rep_hi, const void* rep_lo, const float* emb, int 
     return 0;
 }
 
+// The same for a DISTILLED step (padded row layout of ader_lbf_fwd_kd / ader_lx3_fwd_kd: rows [kd_row0, Bp) are exemplar rows with
+// dlogit = w (softmax(s[:Np]) - softmax(teacher row))): the gradient-only form that feeds the dense data-parallel exchange.
+int ader_tab_grad_kd(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int Bp, int kd_row0, int H, int N, int Np,
+                     const int* lab, const float* wrow, const float* off, const float* teacher, long ldt, const int* trow,
+                     const float* tlse2, float* demb, void* stream) {
+    if (Bp <= 0) return 0;
+    if (Bp % 128 != 0 || kd_row0 % 128 != 0 || kd_row0 >= Bp || H > HP || (H & 1) || H < 2 || N > item_num || ((uintptr_t)emb & 7) ||
+        !teacher || !trow || !tlse2 || Np < 1 || Np > N) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    TabArgs a;
+    a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
+    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = demb + H;
+    a.kd_row0 = kd_row0; a.Np = Np; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
+    FuseArgs fa = {};
+    fa.wrow = wrow;
+    const int tiles = (N + TI - 1) / TI;
+    int rc = rep_lo ? tab_launch<true, false, false, true>(a, fa, tiles, tab_lds(Bp, H, true, false), st)
+                    : tab_launch<false, false, false, true>(a, fa, tiles, tab_lds(Bp, H, false, false), st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tab_target_fix, dim3((Bp + 3) / 4), dim3(256), 0, st, (const bf16*)rep_hi, (const bf16*)rep_lo, lab, wrow,
+                       demb + H, Bp, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // Fused: table-gradient GEMM + sparse terms + TF-Adam on table rows 1..N (+ bf16 shadow rows), in one pass.
 // sp_ids/sp_rows: the B*T input positions sorted by item id (pads = id 0 first) and their row index into sp_src [B*T,H]
 // (the masked/dropout-scaled gradient rows left by ader_embed_bwd_rows); sp_scale = sqrt(H).  tg_ids/tg_rows: the labels

@@ -686,9 +686,13 @@ class Engine:
                         and N >= self._grad_hi and self.dp_world == 1 and self.kd_split)
         # ... or (default, bf16 and x3 modes): ALL rows on the flash path -- the exemplar rows as their own 128-row chunks whose softmax runs
         # over the first Np items, with the teacher term as a second readout (forward) and a subtraction inside the fused update
-        kd_fast = bool(split_kd and self.kd_fast
-                       and ((n_train + 127) // 128 + (n_ex + 127) // 128) * 128 <= self.MAX_ROWS)
-        if kd_fast:
+        kd_rows_fit = ((n_train + 127) // 128 + (n_ex + 127) // 128) * 128 <= self.MAX_ROWS
+        kd_fast = bool(split_kd and self.kd_fast and kd_rows_fit)
+        # the same forward without the fused update (data-parallel ranks, or no optimiser step): the table gradient is written
+        # out (ader_tab_grad_kd) and takes the dense exchange
+        kd_fast_unfused = bool(not kd_fast and self.lfast and teacher is not None and n_ex > 0 and n_train > 0 and self.kd_fast
+                               and kd_rows_fit and N >= self._grad_hi and (self.dp_world > 1 or not _defer_table))
+        if kd_fast or kd_fast_unfused:
             split_kd = False
         use_bf16 = self.lfast and (teacher is None or split_kd or kd_fast)
         defer = bool(_defer_table and use_bf16 and N >= self._grad_hi)
@@ -697,8 +701,8 @@ class Engine:
         self.split_rows = n_train if (n_ex > 0 and getattr(self, "_ex_row0_set", False)) else None
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
-        if kd_fast:
-            return self._loss_and_grad_kd_fast(seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex)
+        if kd_fast or kd_fast_unfused:
+            return self._loss_and_grad_kd_fast(seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex, fused=kd_fast)
         if defer and self.dp_world == 1:
             # the id-bucketed lists of the fused table update need only the inputs: build them on a side stream, under the
             # logit kernels (the one-launch forward owns every CU's LDS; the logit kernels leave room for it)
@@ -777,7 +781,7 @@ class Engine:
                                   lab=lab, wrow=wrow, extra=extra)
         return self.loss
 
-    def _loss_and_grad_kd_fast(self, seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex):
+    def _loss_and_grad_kd_fast(self, seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex, fused=True):
         """Distilled step (ADER.py:108-137) entirely on the bf16 flash kernels.  Rows are laid out [train rows padded to 128 |
         exemplar rows padded to 128]; ader_lbf_fwd_kd gives the student log-sum-exp of every row (exemplar rows: over the first Np
         items), the softmax-weighted readout O1 and, for exemplar rows, the teacher readout O2 = sum_j softmax(t)_j E_j, from which
@@ -812,8 +816,20 @@ class Engine:
                      ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
                      ptr(trow), ptr(tlse2), ptr(rep_bf), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off), ptr(rowloss),
                      ptr(self.loss), ptr(drep), st)
-        self._lists_async(seq, lab, N)            # one-hot targets in the padded row numbering (label 0 = none)
         self._grad_hi = max(self._grad_hi, N)
+        if not fused:
+            demb = self.gradient("emb")
+            with self._sec("logits_bwd_demb"):
+                call("ader_tab_grad_kd", ptr(rep_bf), ptr(rep_lo), self._pp["emb"], self.item_num, Bp, Bt, H, N, Np, ptr(lab), ptr(wrow),
+                     ptr(off), ptr(teacher), teacher.stride(0), ptr(trow), ptr(tlse2), ptr(demb), st)
+            self._early = None
+            if self.grad_early_hook is not None:
+                self._early = self.grad_early_hook(self, N)
+            dx = self._blocks_backward(seq, drep, False, demb)
+            if self._early is not None:
+                self._dp_rows = (seq, dx)
+            return self.loss
+        self._lists_async(seq, lab, N)            # one-hot targets in the padded row numbering (label 0 = none)
         dx = self._blocks_backward(seq, drep, True, None)
         self._deferred = dict(seq=seq, g=dx, B=Bp, Bp=Bp, N=N, rep_bf=rep_bf, rep_lo=rep_lo, off=off, lab=lab, wrow=wrow, extra=None,
                               kd=dict(row0=Bt, Np=Np, teacher=teacher, trow=trow, tlse2=tlse2))

@@ -255,6 +255,12 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
 int ader_tab_grad(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int B, int Bp, int H, int N,
                   const int* lab, const float* wrow, const float* off, float* demb, void* stream);
 
+/* ... for a distilled step (padded layout of ader_lbf_fwd_kd / ader_lx3_fwd_kd; rows [kd_row0, Bp) carry the teacher term of
+ * ADER.py:132-137): the gradient-only form behind the dense data-parallel exchange. */
+int ader_tab_grad_kd(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int Bp, int kd_row0, int H, int N,
+                     int Np, const int* lab, const float* wrow, const float* off, const float* teacher, long ldt, const int* trow,
+                     const float* tlse2, float* demb, void* stream);
+
 /* Fused table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both sorted by
  * item id) + tf.train.AdamOptimizer (ADER.py:96) on table rows 1..N of emb/adam_m/adam_v, one workgroup per 64-row tile.
  * The table gradient is never written to memory and the item parameters are read ONCE (GEMM operand and Adam input come

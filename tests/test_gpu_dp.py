@@ -102,12 +102,12 @@ def _kd_data():
     return seq, pos, ex_seq, teacher, trow
 
 
-def _kd_worker(rank, world, port, out):
+def _kd_worker(rank, world, port, out, logits):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ader_amd import dist as adist
     seq, pos, ex_seq, teacher, trow = _kd_data()
-    eng = _engine("f32", rank, world)
+    eng = _engine(logits, rank, world)
     dp = adist.DataParallel(eng, rank, world)
     lo, hi = adist.shard_bounds(B, world, rank)
     elo, ehi = adist.shard_bounds(N_EX, world, rank)
@@ -123,21 +123,23 @@ def _kd_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_distilled_step_matches_single_process():
+@pytest.mark.parametrize("logits", ["f32", "bf16", "x3"])
+def test_two_ranks_distilled_step_matches_single_process(logits):
     """ADER-mode step under data parallelism (main.py:223-256 with the rows of BOTH sub-batches sharded, losses scaled by the
     global sub-batch sizes, dense gradient all-reduce): two ranks == one process on the whole batch.  Dropout ON: the counters of
     both row segments of a shard (its train rows, its exemplar rows) are keyed by their global rows (AderDrop.split / base2), so
-    the two ranks draw exactly the masks of the single process."""
+    the two ranks draw exactly the masks of the single process.  bf16 / x3: the ranks take the flash forward with the table gradient
+    written out (ader_tab_grad_kd) and reduced; the single process takes the fused update."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "theta.pt")
-        mp.spawn(_kd_worker, args=(2, port, out), nprocs=2, join=True)
+        mp.spawn(_kd_worker, args=(2, port, out, logits), nprocs=2, join=True)
         got = torch.load(out).numpy()
     seq, pos, ex_seq, teacher, trow = _kd_data()
-    eng = _engine("f32")
+    eng = _engine(logits)
     tch = torch.from_numpy(teacher).cuda()
     for step in range(2):
         eng.train_step(np.concatenate([seq, ex_seq]), pos, N, 5e-4, rate=0.3, teacher=tch, ex_trow=trow, lambda_=0.6)
