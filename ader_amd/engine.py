@@ -197,7 +197,7 @@ class Engine:
         self.lists_side_stream = True      # build the sparse lists under the block kernels
         self.late_side_stream = True       # small-parameter gradients / Adam run beside the (HBM-bound) fused table update
         self._late, self._late_on, self._late_force = [], False, False
-        self._st_ptr = None
+        self._st_ptr, self._main, self._in_step = None, None, False
         self._pin = {}
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
         self._atb_q = []
@@ -363,21 +363,28 @@ class Engine:
         return self._st_ptr if self._st_ptr is not None else torch.cuda.current_stream().cuda_stream
 
     def _refresh_stream(self):
-        self._st_ptr = torch.cuda.current_stream().cuda_stream
+        if self._in_step:            # nested entry points of one train step: the stream was looked up at its start
+            return
+        self._main = torch.cuda.current_stream()
+        self._st_ptr = self._main.cuda_stream
 
     class _OnStream:
-        """with torch.cuda.stream(s), keeping Engine._stream() in step."""
+        """Launch on `stream` inside the block.  The launchers take the stream handle explicitly, so only Engine._stream() has to
+        change; torch's own current stream is switched as well only while a SectionTimer is recording (its events go to torch's
+        current stream) -- the torch.cuda.stream() context costs ~20 us of host time per use, three times per step."""
 
         def __init__(self, eng, stream):
-            self.eng, self.stream, self.ctx = eng, stream, torch.cuda.stream(stream)
+            self.eng, self.stream = eng, stream
+            self.ctx = torch.cuda.stream(stream) if eng.timer is not None else None
 
         def __enter__(self):
-            self.ctx.__enter__()
+            if self.ctx is not None:
+                self.ctx.__enter__()
             self.prev, self.eng._st_ptr = self.eng._st_ptr, self.stream.cuda_stream
 
         def __exit__(self, *exc):
             self.eng._st_ptr = self.prev
-            return self.ctx.__exit__(*exc)
+            return self.ctx.__exit__(*exc) if self.ctx is not None else False
 
     def _sec(self, name):
         return self.timer.section(name) if self.timer is not None else _NULL
@@ -1026,7 +1033,7 @@ class Engine:
         return ids, order, sp_start, tids, torder, tg_start, meta
 
     def _lists_async(self, seq, lab, N):
-        main = torch.cuda.current_stream()
+        main = self._main
         if not self.lists_side_stream:
             self._lists = self._sparse_lists(seq, lab, N)
             return
@@ -1040,10 +1047,7 @@ class Engine:
     def _lists_wait(self):
         out, self._lists = self._lists, None
         if self.lists_side_stream:
-            torch.cuda.current_stream().wait_stream(self._side)
-            for t in out:
-                if t is not None:
-                    t.record_stream(torch.cuda.current_stream())
+            self._main.wait_stream(self._side)       # (the lists live in persistent workspace buffers: no record_stream needed)
         return out
 
     def _fused_table_adam(self, lr):
@@ -1066,7 +1070,7 @@ class Engine:
                      self.beta2, self.eps, None, 0, H, self._stream())
             self._advance_adam()
 
-        main = torch.cuda.current_stream()
+        main = self._main
         overlap = bool(self._late or self._atb_q) and self.late_side_stream
         if overlap:
             # weight-gradient products, LayerNorm / positional reductions, small Adam and the bf16 weight planes are compute /
@@ -1114,6 +1118,7 @@ class Engine:
         are all-gathered.  Mathematically the same update as the dense all-reduce (sum over all rows of the global batch);
         Adam m/v of the table stay sharded.  The small parameters use a plain all-reduce."""
         import torch.distributed as dist
+        self._refresh_stream()
         D = self._deferred
         st = self._stream()
         W, r, grp = self.dp_world, self.dp_rank, self.dp_group
@@ -1227,6 +1232,7 @@ class Engine:
           5. fused gradient + Adam + shadow on the local shard for the global batch (ader_lbf_bwd_adam); nothing is sent back.
         Same update as a single process on the global batch (sum over rows; tests/test_gpu_dp.py)."""
         import torch.distributed as dist
+        self._refresh_stream()
         W, r, grp = self.dp_world, self.dp_rank, self.dp_group
         seq, pos = self._dev_i32(seq), self._dev_i32(pos)
         B, T, H, S = seq.shape[0], self.T, self.H, self.shard_items
@@ -1329,7 +1335,7 @@ class Engine:
             dx = self._blocks_backward(seq, drep, True, None)
         finally:
             self._late_force = False
-        main = torch.cuda.current_stream()
+        main = self._main
         if self._late or self._atb_q:      # ... and run on the side stream under the row exchange below (the CUs are idle there)
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=self.device, priority=-1)
@@ -1393,6 +1399,13 @@ class Engine:
         """One `sess.run(train_op)` (main.py:233-256): forward, loss, backward, [gradient exchange], Adam.
         Returns the loss as a 1-element device tensor (no host sync)."""
         self._refresh_stream()
+        self._in_step = True
+        try:
+            return self._train_step(seq, pos, max_item, lr, **kw)
+        finally:
+            self._in_step = False
+
+    def _train_step(self, seq, pos, max_item, lr, **kw):
         if (self.dp_world > 1 and self.dp_mode == "catalog" and self.shadow is not None and self.seq_fused
                 and kw.get("teacher") is None and kw.get("ex_pos") is None):
             return self._train_step_catalog(seq, pos, max_item, lr, **kw)
