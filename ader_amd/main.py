@@ -6,7 +6,8 @@ Differences from the reference that do not change results: booleans are parsed w
 `type=bool` turns "--finetune=False" into True, main.py:83-91); `stop_counter` is initialised (main.py:272-273);
 batches and teacher logits stay on the GPU (the reference feeds Python float lists every step, util.py:254);
 the best-epoch checkpoint is kept in memory and written to disk only with --save_ckpt.
-Extra flags: --logits_dtype, --max_periods, --data_root, --device, --save_ckpt.
+Extra flags: --logits_dtype, --max_periods, --data_root, --save_ckpt, --eval_batch (--test_batch is accepted and ignored:
+ranks do not depend on the evaluation batch size), --dist_backend, --device_feed.
 
 Data parallel: launched as `python -m torch.distributed.run --nproc-per-node W -m ader_amd.main ...` every
 rank builds the same batches from the same RNG streams, trains on its slice of the train rows and of the exemplar rows
@@ -60,8 +61,10 @@ _BUILD_FLAGS = (
 
 def build_parser():
     p = argparse.ArgumentParser()
+    _help = {"test_batch": "accepted for compatibility with the reference's command lines (README.md:77); evaluation launches take "
+                           "--eval_batch rows -- the ranks, hence the metrics, do not depend on the evaluation batch size"}
     for name, default, typ in _REFERENCE_FLAGS:
-        p.add_argument("--" + name, default=default, type=str2bool if typ is bool else typ)
+        p.add_argument("--" + name, default=default, type=str2bool if typ is bool else typ, help=_help.get(name))
     for name, default, typ, extra in _BUILD_FLAGS:
         kw = {"default": default, "type": str2bool if typ is bool else typ}
         if isinstance(extra, tuple):

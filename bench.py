@@ -118,10 +118,11 @@ def main():
                     help="N > 1: 'replicated' (headline; the north-star scheme: every rank holds the table, the table update is "
                          "row-sharded reduce-scatter / all-gather style and the updated rows are all-gathered over RCCL) or 'catalog' "
                          "(named variant: each rank OWNS 1/N of the table rows, only touched rows travel)")
-    ap.add_argument("--workload", choices=["cfgS", "cfgD", "cfgY"], default="cfgS",
+    ap.add_argument("--workload", choices=["cfgS", "cfgD", "cfgY", "cfgF"], default="cfgS",
                     help="cfgS: BASELINE configs[4] (the metric's configuration).  Step-shape variants of the real-data configs "
                          "(SURVEY 8a): cfgD = DIGINETICA ADER last period (N 43,105, 256 train + 143 distilled rows), cfgY = YOOCHOOSE "
-                         "ADER last period (N 25,750, 512 + 102 rows); synthetic ids of those shapes")
+                         "ADER last period (N 25,750, 512 + 102 rows), cfgF = DIGINETICA finetune baseline (BASELINE configs[0]: N 43,105, "
+                         "batch 128, no exemplars, dropout 0); synthetic ids of those shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32grade", action="store_true", help="skip the float32-grade (x3 logits) companion run")
     ap.add_argument("--pmc-json", default=None,
@@ -145,7 +146,9 @@ def main():
         args.items, args.batch, args.exemplars = 43105, 256, 143
     elif args.workload == "cfgY":
         args.items, args.batch, args.exemplars = 25750, 512, 102
-    N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, 0.3, 5e-4
+    elif args.workload == "cfgF":
+        args.items, args.batch, args.exemplars = 43105, 128, 0
+    N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, (0.0 if args.workload == "cfgF" else 0.3), 5e-4
     eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits,
                  dp_rank=rank, dp_world=world)
     dp = adist.DataParallel(eng, rank, world)
@@ -351,7 +354,8 @@ def main():
                                        ", +%d distilled exemplar rows" % E if E else "",
                                        "" if (N == 1_000_000 and B == 512) else ", REDUCED SIZE")) if args.workload == "cfgS" else
                                    ("step shape of %s: N=%d items, %d train + %d distilled rows, synthetic ids (%s regime)"
-                                    % ({"cfgD": "DIGINETICA ADER (BASELINE.json configs[1])", "cfgY": "YOOCHOOSE ADER (configs[2])"}
+                                    % ({"cfgD": "DIGINETICA ADER (BASELINE.json configs[1])", "cfgY": "YOOCHOOSE ADER (configs[2])",
+                                        "cfgF": "DIGINETICA finetune baseline (configs[0], main.py --finetune=True)"}
                                        [args.workload], N, B, E, args.regime)),
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam",
