@@ -1,10 +1,10 @@
-// Fused table update, bf16 mode, 128-row tiles: table-gradient GEMM + sparse terms + TF-Adam (ADER.py:96) + bf16 shadow rows in
-// one pass.  The GEMM operand E is the tile's bf16 SHADOW rows (336 B per row, read once), theta / m / v are streamed in rounds
-// of 16-byte vectors per half-tile.  This is the faster of the two fused forms on MI355X at H = 150 (0.88 ms vs 1.00 ms per
-// 10^6 rows, round-2 measurements in DESIGN.md): table_update.hip reads 8 % fewer bytes (no shadow read) but spends more
-// instructions per row, and this kernel is bound by its per-workgroup latency chain, not by bytes.  table_update.hip serves the
-// x3 mode and the gradient-only entry point.
-#include <stdlib.h>
+// Fused table update, bf16 mode: table-gradient GEMM + sparse terms + TF-Adam (ADER.py:96) + bf16 shadow rows in one pass.
+// The GEMM operand E is the tile's bf16 SHADOW rows (336 B per row, read once), theta / m / v are streamed in rounds of 16-byte
+// vectors.  64-row tiles on v_mfma_f32_16x16x32_bf16, three workgroups per CU (k_tab16 below).  This form reads 8 % more bytes
+// than table_update.hip's theta-resident kernel (the shadow rows) but is 10 % faster: both are bound by the per-workgroup
+// latency chain and the HBM queue, and resident waves per CU are what buys time (round-2 measurements in DESIGN.md section 6;
+// the 128-row 32x32x16 predecessor of this kernel fitted two workgroups per CU: 0.95 ms against 0.90 ms per 10^6 rows).
+// table_update.hip serves the x3 mode and the gradient-only entry point.
 #include "lbf_common.h"
 #include "../../include/ader_hip.h"
 
@@ -24,7 +24,7 @@ struct ShArgs {
 };
 #define PCS_ROW (LDR * 2 / 16)     // 16-byte pieces per shadow row (21)
 
-// sparse terms and optimiser constants of the 128-row form (bucket offsets instead of per-tile records)
+// sparse terms and optimiser constants (the lists are addressed through their 64-id bucket offsets)
 struct FuseArgs128 {
     const int* sp_ids; const int* sp_rows; int n_sp; const float* sp_src; float sp_scale;   // input-embedding rows (sorted by id)
     const int* tg_ids; const int* tg_rows; int n_tg; const float* wrow;                      // one-hot targets (sorted by id)
@@ -34,83 +34,10 @@ struct FuseArgs128 {
     const float* extra1;        // EXTRA: dense gradient rows to add (row of item 1; [.,H] fp32), e.g. distilled rows' term
 };
 
-// dE tile (128 items per workgroup, 32 per wave); loops over all batch rows in chunks of 64 staged through LDS.
-#define FLD 152                    // fp32 row stride of the dE staging tile
-#ifndef NT_STORES
-#define NT_STORES 1
-#endif
+#define SPV 3                      // input-embedding gradient rows prefetched under the GEMM phase
+#define AV 6                       // 16-byte vectors per thread and load round of the optimiser phase (x theta, m, v)
 
-
-template <bool ADAM, bool EXTRA = false, bool KD = false>
-__global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(ShArgs a, FuseArgs128 f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* R_l = (bf16*)smem_raw;                        // [2][64][LDR]  (also: the table tile, then the dE staging tile)
-    float* off_l = (float*)(smem_raw + 2 * 64 * LDR * sizeof(bf16));   // [Bp]
-    int* meta_l = (int*)(off_l + a.Bp);      // ADAM: per (half, list): [k0, k1, 8 x (id, row)] = 18 ints, 4 lists (SP_PRE entries prefetched)
-    float* toff_l = (float*)(meta_l + 4 * 18);              // KD: [Bp - kd_row0] log2(w_b) - tlse2_b (-inf: no teacher term)
-    int* trow_l = (int*)(toff_l + (a.Bp - a.kd_row0));      // KD: [Bp - kd_row0] teacher row (0 for padding rows)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int H = a.H, N = a.N;
-    const int tile0 = (blockIdx.x + a.tile_off) * 128;
-    const int it0 = tile0 + wave * 32;
-    {   // table tile: 128 shadow rows, contiguous -> LDS (coalesced 16-B pieces) -> operand fragments in registers
-        const uint4* src = (const uint4*)(a.sh1 + (size_t)tile0 * LDR);
-        uint4* dst = (uint4*)R_l;
-        for (int idx = tid; idx < 128 * PCS_ROW; idx += 256) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (tile0 + idx / PCS_ROW < a.vrows) v = src[idx];
-            dst[idx] = v;
-        }
-    }
-    for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
-    if (KD) {
-        for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
-            const int b = a.kd_row0 + i, tr = a.trow[b];
-            const float w = f.wrow[b];
-            toff_l[i] = (tr >= 0 && w > 0.0f) ? log2f(w) - a.tlse2[b] : -INFINITY;
-            trow_l[i] = tr < 0 ? 0 : tr;
-        }
-    }
-    if (ADAM && tid < 4) {
-        // the sparse lists of the two half-tiles (bucket bounds and the first entries) are fetched now, under the GEMM phase:
-        // three dependent global round trips less between the GEMM and the streaming update
-        const int half = tid >> 1, lst = tid & 1;
-        const int bkt = (tile0 + half * 64) >> 6;
-        const int* st = lst ? f.tg_start : f.sp_start;
-        const int* ids = lst ? f.tg_ids : f.sp_ids;
-        const int* rows = lst ? f.tg_rows : f.sp_rows;
-        int* mt = meta_l + tid * 18;
-        int k0 = 0, k1 = 0;
-        if (tile0 + half * 64 < N) { k0 = st[bkt]; k1 = st[bkt + 1]; }
-        mt[0] = k0; mt[1] = k1;
-        for (int i = 0; i < 8 && k0 + i < k1; ++i) { mt[2 + 2 * i] = ids[k0 + i]; mt[3 + 2 * i] = rows[k0 + i]; }
-    }
-    __syncthreads();
-    // ADAM: the first SPV input-embedding gradient rows of each half-tile (thread c holds column c), requested now and
-    // consumed after the GEMM phase
-#define SPV 3
-    float spv0[SPV], spv1[SPV];
-    if (ADAM) {
-#pragma unroll
-        for (int i = 0; i < SPV; ++i) {
-            const int* m0 = meta_l, * m1 = meta_l + 2 * 18;
-            spv0[i] = (tid < H && m0[0] + i < m0[1]) ? f.sp_src[(size_t)m0[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
-            spv1[i] = (tid < H && m1[0] + i < m1[1]) ? f.sp_src[(size_t)m1[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
-        }
-    }
-    bf16x8 efrag[10];                                   // lane (item r, half hh) holds E[item][16ks + 8hh + 0..7]
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks) efrag[ks] = *(const bf16x8*)(R_l + (wave * 32 + r) * LDR + 16 * ks + 8 * hh);
-    __syncthreads();
-    f32x16 dE[5];
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) dE[nb][j] = 0.0f;
-    const int nch = a.Bp >> 6;
-    const int n16 = 64 * LDR * 2 / 16;                  // 16-byte pieces per 64-row chunk (1344)
-    uint4 pf[6];
+// rep chunk (64 rows x 336 B, contiguous) global -> registers -> LDS buffer, one chunk ahead of the MFMAs
 #define LBF_RPREFETCH(c_)                                                                               \
     {                                                                                                   \
         const uint4* src_ = (const uint4*)(a.rep_bf + (size_t)(c_) * 64 * LDR);                          \
@@ -127,206 +54,22 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(ShArgs a, FuseArgs128 f) 
             if (idx < n16) dst_[idx] = pf[j];                                                           \
         }                                                                                               \
     }
-    LBF_RPREFETCH(0); LBF_RSTAGE(0);
-    __syncthreads();
-    int cur = 0;
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    for (int c = 0; c < nch; ++c) {
-        const bool more = c + 1 < nch;
-        if (more) LBF_RPREFETCH(c + 1);
-        const bf16* Rb = R_l + cur * 64 * LDR;
-#pragma unroll 1
-        for (int bb = 0; bb < 2; ++bb) {
-            const int b0 = c * 64 + bb * 32;
-            // KD rows: this lane's 16 teacher logits (item it0 + r, batch rows b0 + acc_row(j, hh)), requested ahead of the MFMAs
-            float tv[KD ? 16 : 1];
-            const bool kdc = KD && b0 >= a.kd_row0;               // (wave-uniform: chunks do not straddle kd_row0)
-            if (kdc && it0 + r < a.Np) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    tv[KD ? j : 0] = a.teacher[(size_t)trow_l[b0 - a.kd_row0 + acc_row(j, hh)] * a.ldt + it0 + r];
-            }
-            f32x16 S;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) S[j] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 10; ++ks) {
-                const bf16x8 af = *(const bf16x8*)(Rb + (bb * 32 + r) * LDR + 16 * ks + 8 * hh);
-                S = mfma_bf16(af, efrag[ks], S);
-            }
-            // rows of S are batch rows: p = w_b * softmax = exp2(S*log2e + off_b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 o4 = *(const float4*)(off_l + b0 + 8 * g + 4 * hh);
-                S[4 * g + 0] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 0], LOG2E, o4.x));
-                S[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 1], LOG2E, o4.y));
-                S[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 2], LOG2E, o4.z));
-                S[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(S[4 * g + 3], LOG2E, o4.w));
-            }
-            if (kdc) {          // dlogit of a distilled row: w (softmax(s[:Np]) - softmax(t)) for items < Np, 0 beyond
-                if (it0 + r < a.Np) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        S[j] -= __builtin_amdgcn_exp2f(fmaf(tv[KD ? j : 0], LOG2E, toff_l[b0 - a.kd_row0 + acc_row(j, hh)]));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) S[j] = 0.0f;
-                }
-            }
-            const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
-#pragma unroll
-            for (int nb = 0; nb < 5; ++nb) {
-                const bf16* base = Rb + (bb * 32 + 4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
-                const bf16x4 l0 = tr_read(base), h0 = tr_read(base + 8 * LDR);
-                const bf16x4 l1 = tr_read(base + 16 * LDR), h1 = tr_read(base + 24 * LDR);
-                bf16x8 b0v, b1v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { b0v[j] = l0[j]; b0v[4 + j] = h0[j]; b1v[j] = l1[j]; b1v[4 + j] = h1[j]; }
-                dE[nb] = mfma_bf16(pa0, b0v, dE[nb]);
-                dE[nb] = mfma_bf16(pa1, b1v, dE[nb]);
-            }
-        }
-        if (more) LBF_RSTAGE(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    // dE acc (rows = items, col = channel) -> LDS [64 items][fs] -> coalesced row stores, two halves of 64 items.
-    // ADAM: fs = H, so the LDS tile is the same flat [64*H] block as the half-tile's rows of theta / m / v in memory.
-    float* F_l = (float*)smem_raw;
-    const int HH = H >> 1;
-    const int fs = ADAM ? H : FLD;
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#define AV 6
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        // ADAM: the first round of theta/m/v vectors of this half-tile is requested BEFORE the dE staging and the sparse
-        // terms (independent of both); the barriers in between order LDS only, so the loads stay in flight across them
-        const int base_it = tile0 + half * 64;
-        const int rows_valid = min(64, N - base_it);
-        const int n_el = rows_valid > 0 ? rows_valid * H : 0;
-        float* __restrict__ gp = ADAM ? f.emb1 + (size_t)base_it * H : nullptr;
-        float* __restrict__ gm = ADAM ? f.m1 + (size_t)base_it * H : nullptr;
-        float* __restrict__ gv = ADAM ? f.v1 + (size_t)base_it * H : nullptr;
-        const int head = (((uintptr_t)gp) & 15) ? 2 : 0;
-        int e = head + 4 * tid;
-        int row = e / H, col = e - row * H;
-        const int step_r = 1024 / H, step_c = 1024 - step_r * H;
-        f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
-        const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)base_it * H : nullptr;
-        int E[AV], RC[AV], NV[AV];
+// one round of theta / m / v vectors of the tile's flat [64*H] block: all loads issued before any math or store; (row, col) of a
+// vector -- needed only for the bf16 shadow row -- is stepped without divisions
 #define ROUND_LOAD()                                                                                       \
-        _Pragma("unroll") for (int u = 0; u < AV; ++u) {                                                   \
-            E[u] = e; RC[u] = (row << 16) | col;                                                           \
-            NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);                                         \
-            if (NV[u] == 2) {                                                                              \
-                P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e); \
-                if (EXTRA) G[u] = __builtin_nontemporal_load((const f32x4_t*)(gx + e));                    \
-            } else if (NV[u] == 1) {                                                                       \
-                if (EXTRA) { const f32x2_t g_ = *(const f32x2_t*)(gx + e); G[u] = (f32x4_t){g_[0], g_[1], 0.f, 0.f}; } \
-                const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e); \
-                P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f}; \
-            }                                                                                              \
-            e += 1024; row += step_r; col += step_c;                                                       \
-            if (col >= H) { col -= H; ++row; }                                                             \
-        }
-        if (ADAM) { ROUND_LOAD(); }
-        if (ADAM) lds_only_barrier(); else __syncthreads();
-        if ((wave >> 1) == half) {
-#pragma unroll
-            for (int nb = 0; nb < 5; ++nb) {
-                const int h = 32 * nb + r;
-                if (h < fs) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) F_l[((wave & 1) * 32 + acc_row(j, hh)) * fs + h] = dE[nb][j];
-                }
-            }
-        }
-        if (ADAM) lds_only_barrier(); else __syncthreads();
-        if (!ADAM) {
-            for (int idx = tid; idx < 64 * HH; idx += 256) {
-                const int row = idx / HH, c2 = idx - row * HH;
-                if (base_it + row < N)
-                    *(float2*)(a.demb1 + (size_t)(base_it + row) * H + 2 * c2) = *(const float2*)(F_l + row * FLD + 2 * c2);
-            }
-        } else {
-            // sparse terms of this half-tile: item ids [base_it+1, base_it+65).  Thread c owns column c of every row.
-            const int id_lo = base_it + 1, id_hi = min(base_it + 64, N) + 1;
-            if (tid < H && id_lo < id_hi) {
-                // entries of bucket base_it >> 6 (ids [base_it+1, base_it+65): exactly this half-tile), (id, row)-ordered
-                const int* ms = meta_l + (half * 2 + 0) * 18;
-                const int* mg = meta_l + (half * 2 + 1) * 18;
-                const int k0s = ms[0], k1s = ms[1];
-#pragma unroll
-                for (int i = 0; i < SPV; ++i) {                  // rows already in registers (same (id, row) order)
-                    if (k0s + i < k1s) {
-                        const int id = ms[2 + 2 * i];
-                        if (id < id_hi) F_l[(id - id_lo) * fs + tid] += half ? spv1[i] : spv0[i];
-                    }
-                }
-                for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
-                    const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
-                    if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
-                    const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
-                    F_l[(id - id_lo) * fs + tid] += f.sp_src[(size_t)row * H + tid] * f.sp_scale;
-                }
-                for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
-                    const int id = (i < 8) ? mg[2 + 2 * i] : f.tg_ids[k];
-                    if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
-                    const int b = (i < 8) ? mg[3 + 2 * i] : f.tg_rows[k];
-                    F_l[(id - id_lo) * fs + tid] -= f.wrow[b] * (float)a.rep_bf[(size_t)b * LDR + tid];
-                }
-            }
-            lds_only_barrier();
-            // Adam on the half-tile.  Its rows are ONE contiguous block of 64*H floats in theta / m / v (and in F_l): it is
-            // walked as 16-byte vectors (the block starts 0 or 8 bytes past a 16-byte boundary: `head` floats are peeled),
-            // all loads of a round issued before any math or store; (row, col) of a vector -- needed only for the bf16
-            // shadow row -- is stepped without divisions.
-            bf16* __restrict__ psh = f.sh1w + (size_t)base_it * LDR;
-#define ADAM1(p_, m_, v_, g_)                                                                              \
-            { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
-            if (head && tid == 0 && n_el > 0) {                   // elements 0,1 (row 0, columns 0,1)
-                f32x2_t p = *(const f32x2_t*)gp, m = *(const f32x2_t*)gm, v = *(const f32x2_t*)gv;
-                float2 g2 = *(const float2*)F_l;
-                if (EXTRA) { g2.x += gx[0]; g2.y += gx[1]; }
-                ADAM1(p[0], m[0], v[0], g2.x); ADAM1(p[1], m[1], v[1], g2.y);
-                *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
-                bf16x2 sb; sb[0] = (bf16)p[0]; sb[1] = (bf16)p[1];
-                *(bf16x2*)psh = sb;
-            }
-#pragma unroll 1
-            for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160; round 0 is already in flight
-                if (k0) { ROUND_LOAD(); }
-#pragma unroll
-                for (int u = 0; u < AV; ++u) {
-                    if (NV[u] == 0) continue;
-                    float2 ga = *(const float2*)(F_l + E[u]);
-                    float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
-                    if (EXTRA) { ga.x += G[u][0]; ga.y += G[u][1]; gb.x += G[u][2]; gb.y += G[u][3]; }
-                    f32x4_t p = P[u], m = M[u], v = V[u];
-                    ADAM1(p[0], m[0], v[0], ga.x); ADAM1(p[1], m[1], v[1], ga.y);
-                    ADAM1(p[2], m[2], v[2], gb.x); ADAM1(p[3], m[3], v[3], gb.y);
-                    const int r0 = RC[u] >> 16, c0 = RC[u] & 0xffff;
-                    bf16x2 s0; s0[0] = (bf16)p[0]; s0[1] = (bf16)p[1];
-                    *(bf16x2*)(psh + r0 * LDR + c0) = s0;
-                    if (NV[u] == 2) {
-                        // theta/m/v of this block are not touched again this step: keep them out of the caches
-                        __builtin_nontemporal_store(p, (f32x4_t*)(gp + E[u]));
-                        __builtin_nontemporal_store(m, (f32x4_t*)(gm + E[u]));
-                        __builtin_nontemporal_store(v, (f32x4_t*)(gv + E[u]));
-                        const int c1 = c0 + 2;
-                        bf16x2 s1; s1[0] = (bf16)p[2]; s1[1] = (bf16)p[3];
-                        *(bf16x2*)(psh + ((c1 >= H) ? (r0 + 1) * LDR + (c1 - H) : r0 * LDR + c1)) = s1;
-                    } else {
-                        *(f32x2_t*)(gp + E[u]) = (f32x2_t){p[0], p[1]};
-                        *(f32x2_t*)(gm + E[u]) = (f32x2_t){m[0], m[1]};
-                        *(f32x2_t*)(gv + E[u]) = (f32x2_t){v[0], v[1]};
-                    }
-                }
-            }
-#undef ADAM1
-        }
-    }
+_Pragma("unroll") for (int u = 0; u < AV; ++u) {                                                   \
+    E[u] = e; RC[u] = (row << 16) | col;                                                           \
+    NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);                                         \
+    if (NV[u] == 2) {                                                                              \
+        P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e); \
+        if (EXTRA) G[u] = __builtin_nontemporal_load((const f32x4_t*)(gx + e));                    \
+    } else if (NV[u] == 1) {                                                                       \
+        if (EXTRA) { const f32x2_t g_ = *(const f32x2_t*)(gx + e); G[u] = (f32x4_t){g_[0], g_[1], 0.f, 0.f}; } \
+        const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e); \
+        P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f}; \
+    }                                                                                              \
+    e += 1024; row += step_r; col += step_c;                                                       \
+    if (col >= H) { col -= H; ++row; }                                                             \
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -338,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void k_lbf_bwd_de(ShArgs a, FuseArgs128 f) 
 //   P^T.rep  = 16 items x 16 channels, K = 32 batch rows: the A fragment of lane (c16, g) is its own p values of TWO S blocks
 //              (rows 4g..4g+3 of block A, then of block B -- no lane movement); the B fragment reads exactly those rows k-major
 //              with two ds_read_b64_tr_b16 per MFMA.
-// No cross-wave reduction: a wave accumulates the whole batch for its 16 rows.  The optimiser phase is the half-tile walk of the
-// 128-row form (one half).
+// No cross-wave reduction: a wave accumulates the whole batch for its 16 rows.  The optimiser phase walks the tile's rows of
+// theta / m / v as one flat block of 16-byte vectors.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -576,7 +319,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
 #undef ADAM1
 }
 
-static size_t bwd_lds(int Bp, int Bk) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 4 * 18 * sizeof(int) + (size_t)Bk * 8; }
+static size_t bwd_lds(int Bp, int Bk) { return (size_t)2 * 64 * LDR * sizeof(bf16) + (size_t)Bp * sizeof(float) + 2 * 18 * sizeof(int) + (size_t)Bk * 8; }
 
 extern "C" {
 
@@ -593,18 +336,9 @@ static int tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, 
     const bool kd = kd_row0 < Bp;
     if (kd && (kd_row0 % 128 != 0 || extra_grad || !teacher || !trow || !tlse2 || Np < 1 || Np > N)) return -2;
     static int lds_set = 0;
-    static int pad = -1, form = -1;
-    if (pad < 0) { const char* v = getenv("ADER_SH_LDS_PAD"); pad = v ? atoi(v) : 0; }      // experiment: force fewer workgroups per CU
-    if (form < 0) { const char* v = getenv("ADER_TAB_FORM"); form = (v && v[0] == '1') ? 128 : 64; }   // 64-row 16x16x32 form / 128-row form
-    const size_t lds = bwd_lds(Bp, kd ? Bp - kd_row0 : 0) + (size_t)pad;
+    const size_t lds = bwd_lds(Bp, kd ? Bp - kd_row0 : 0);
     if ((int)lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lbf_bwd_de<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_tab16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tab16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)k_tab16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -631,20 +365,14 @@ static int tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, 
     if (te <= tb) return 0;
     a.tile_off = tb;
     hipStream_t st = (hipStream_t)stream;
-    if (form == 64) {           // 64-row tiles: tile range in units of 64 rows
-        const int all64 = (N + 63) / 64;
-        int t0 = 2 * tb, t1 = 2 * te;
-        if (t1 > all64) t1 = all64;
-        a.tile_off = t0;
-        if (kd) hipLaunchKernelGGL((k_tab16<false, true>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
-        else if (extra_grad) hipLaunchKernelGGL((k_tab16<true, false>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
-        else hipLaunchKernelGGL((k_tab16<false, false>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
-        HIP_LAUNCH_CHECK();
-        return 0;
-    }
-    if (kd) hipLaunchKernelGGL((k_lbf_bwd_de<true, false, true>), dim3(te - tb), dim3(256), lds, st, a, fa);
-    else if (extra_grad) hipLaunchKernelGGL((k_lbf_bwd_de<true, true, false>), dim3(te - tb), dim3(256), lds, st, a, fa);
-    else hipLaunchKernelGGL((k_lbf_bwd_de<true, false, false>), dim3(te - tb), dim3(256), lds, st, a, fa);
+    // 64-row tiles: the tile range (given in 128-row units) in units of 64 rows
+    const int all64 = (N + 63) / 64;
+    int t0 = 2 * tb, t1 = 2 * te;
+    if (t1 > all64) t1 = all64;
+    a.tile_off = t0;
+    if (kd) hipLaunchKernelGGL((k_tab16<false, true>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
+    else if (extra_grad) hipLaunchKernelGGL((k_tab16<true, false>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
+    else hipLaunchKernelGGL((k_tab16<false, false>), dim3(t1 - t0), dim3(256), lds, st, a, fa);
     HIP_LAUNCH_CHECK();
     return 0;
 }
