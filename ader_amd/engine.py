@@ -241,7 +241,10 @@ class Engine:
         _p = os.environ.get("ADER_DP_PACK")
         self.dp_pack = (self.dp_world >= 8) if _p is None else (_p == "1")
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
-        self.kd_fast = True      # ... bf16 mode: exemplar rows on the bf16 flash path too (teacher readout + fused KD update)
+        self.kd_fast = True      # ... exemplar rows on the flash path too (teacher readout + fused KD update)
+        # bf16 mode, fused table update: "sh" = k_tab16 (operand from the shadow rows, three workgroups per CU: the faster form),
+        # "resident" = k_tab_upd (theta tile read once and kept in LDS, no shadow read: 8 % fewer bytes, 10 % slower)
+        self.bf16_update = "sh"
         self._table_stale = False
         self._mv_sharded = False   # dp: Adam m/v of the table are current only for the rank's own rows (see _gather_if_sharded)
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
@@ -1026,7 +1029,7 @@ class Engine:
         call("ader_sparse_lists", ptr(seq.contiguous()), n_sp, ptr(lab.contiguous()), n_tg, N, ptr(scratch), ptr(ids), ptr(order),
              ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), self._stream())
         meta = None
-        if self.lx3:        # per-tile list records of the 64-row update kernel (table_update.hip)
+        if self.lx3 or self.bf16_update == "resident":        # per-tile list records of the 64-row update kernel (table_update.hip)
             meta = self.buf("sl_meta", (call("ader_tab_meta_ints", N),), torch.int32)
             call("ader_tab_tile_meta", ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), N, ptr(meta),
                  self._stream())
@@ -1087,8 +1090,8 @@ class Engine:
                      ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                      ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(K["teacher"]), K["teacher"].stride(0), ptr(K["trow"]),
                      ptr(K["tlse2"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1, self.beta2, self.eps, st)
-            elif self.lx3:
-                call("ader_tab_update", ptr(D["rep_bf"]), ptr(D["rep_lo"]), None, self.item_num, D["B"], D["Bp"], H, D["N"],
+            elif self.lx3 or (self.bf16_update == "resident" and not D.get("kd")):
+                call("ader_tab_update", ptr(D["rep_bf"]), ptr(D["rep_lo"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"],
                      ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                      ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
                      self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)

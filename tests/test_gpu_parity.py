@@ -528,6 +528,32 @@ def test_fused_table_adam_equals_unfused_step(cfg, ld):
     assert nerr(a2[1], b2[1]) < 1e-2 and np.abs(a2[0] - b2[0]).max() < 2.5e-3
 
 
+@pytest.mark.parametrize("cfg", [BF16_CFGS[0], BF16_CFGS[1]])
+def test_both_bf16_update_forms_agree(cfg):
+    """The two fused bf16 table updates -- k_tab16 (operand from the shadow rows, the default) and k_tab_upd (theta tile read once
+    and kept in LDS) -- compute the same update from the same state: identical operand values (bf16(theta) either way), the same
+    sparse lists; differences are MFMA shape / summation order only (Adam m, v 2e-5; shadow: last-bit flips)."""
+    item_num, T, H, L, heads, B, N = cfg
+    rs = np.random.RandomState(41)
+    seq = _seqs(rs, B, T, N)
+    seq[1, -3:] = seq[0, -1]
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    pos[2] = pos[3]
+    out = []
+    for form in ("sh", "resident"):
+        eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="bf16")
+        eng.bf16_update = form
+        eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+        torch.cuda.synchronize()
+        out.append((eng.theta.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(),
+                    eng.shadow.float().cpu().numpy().copy()))
+    a, b = out
+    assert nerr(a[1], b[1]) < 2e-5 and nerr(a[2], b[2]) < 2e-5
+    d = np.abs(a[0] - b[0])
+    assert np.mean(d < 2e-6) > 0.999 and d.max() < 1.1e-3
+    assert np.mean(a[3] != b[3]) < 1e-3
+
+
 def test_split_kd_step_matches_all_f32_kd_step():
     """Distilled step with a bf16 shadow (Engine.kd_split): train rows go through the bf16 flash logits + fused table update,
     the exemplar rows through the exact-f32 KD kernels whose table gradient enters the fused update as a dense term.  One
