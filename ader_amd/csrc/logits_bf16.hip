@@ -17,6 +17,11 @@
 //              dE[item,:] += P^T . rep with rep read k-major by ds_read_b64_tr_b16.  Each dE row is written once.
 //   k_lbf_target_fix  the sparse one-hot term: dE[label_b] -= w_b * rep_b.
 //
+// Measured and dropped (round 2, cfg-S, 0.36 ms for the kept form): (a) a software-pipelined form that issues block i+1's S MFMAs
+// before block i's softmax (0.40 ms: the second S accumulator costs the occupancy that hid the exp2 chain); (b) the same forward on
+// v_mfma_f32_16x16x32_bf16 with 8 waves x 16 batch rows (126 VGPRs, 16 waves per CU; bit-equal results): 0.43 ms -- every MFMA of
+// that shape fetches the same LDS operand bytes for half the flops, and the LDS pipe, not occupancy, is the limit here.
+//
 // LDS tiles are row-major bf16 with a 168-element (336 B) row stride: ds_read_b128 operand reads are conflict-free
 // (20 r mod 64 covers 16 distinct 4-bank slots).  gfx950 only.
 #include <stdlib.h>
