@@ -165,4 +165,22 @@ __device__ __forceinline__ float bload(const Out& o, uint32_t boff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o.r, (int)(boff - o.sub), 0, 0));
 }
 #define ROWJ(j) (((j) & 3) + 8 * ((j) >> 2))          // row of accumulator register j relative to 32mh + 4hh
+// In a pruned (last) block only row T-1 of the query / FFN path is consumed (rows are independent there; K and V still need every
+// row): the waves that do not own that row skip those products (act), and the owning waves run the epilogue for the ONE
+// accumulator register that holds it -- row T-1 = 32 mhT + 4 hhT + ROWJ(jT).  The other rows of the tiles keep stale contents
+// that nothing consumes.  Rebuilt per phase from a laundered T (scalar registers are scarce in these kernels).
+__device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+#define PRUNE_IDS                                                                      \
+    const int rT = opaque_s(T) - 1;                                                    \
+    const int mhT = rT >> 5, hhT = ((rT & 31) >> 2) & 1;                               \
+    const int jT = 4 * ((rT & 31) >> 3) + (rT & 3), rjT = (rT & 3) + 8 * ((rT & 31) >> 3); \
+    const bool act = !pruned || mh == mhT;                                             \
+    (void)hhT; (void)jT; (void)rjT
+// accumulator register j of a tile (j wave-uniform, known only at run time): a chain of 15 selects on a scalar condition
+__device__ __forceinline__ float pick16(const f32x16& a, int j) {
+    float v = a[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) v = (j == i) ? a[i] : v;
+    return v;
+}
 

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         const BlkPtr kp = blks + l;
 #define k (*kp)
         const bool pruned = k.pruned != 0;      // last block: only position T-1 of the query / FFN path is kept (ADER.py:85)
+        // In a pruned block only row T-1 of the query / FFN path is consumed (rows are independent there; K and V still need every
+        // row): the waves that do not own that row skip those products, and the owning waves run the epilogue for the ONE
+        // accumulator register that holds it -- row T-1 = 32 mhT + 4 hhT + ROWJ(jT).  The other rows of the tiles keep stale
+        // (finite or not: never consumed) contents.
         // small parameters of the block: requested now, consumed phases later
         float g1[10], be1[10], bias5[5];
         load10(k.ln1_g, H, lane & 15, g1); load10(k.ln1_b, H, lane & 15, be1);
@@ -137,13 +141,16 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                     bf16* T1 = R1 + t * LDR + sub;
                     const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) {
-                        const int c = sub + 16 * i;
-                        const float y = (valid && c < H) ? g1[i] * ((x[i] - mean) * rsd) + be1[i] : 0.0f;
-                        ys += y;
-                        put_split(T0, T0 + TR * LDR, 16 * i, x[i]);
-                        put_split(T1, T1 + TR * LDR, 16 * i, y);
-                        bstore(oq, (c < H) ? bo + 64u * i : OOB, y);
+                    for (int i = 0; i < 10; ++i) put_split(T0, T0 + TR * LDR, 16 * i, x[i]);
+                    if (!pruned || t == T - 1) {        // LN(x) feeds the query path only
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) {
+                            const int c = sub + 16 * i;
+                            const float y = (valid && c < H) ? g1[i] * ((x[i] - mean) * rsd) + be1[i] : 0.0f;
+                            ys += y;
+                            put_split(T1, T1 + TR * LDR, 16 * i, y);
+                            bstore(oq, (c < H) ? bo + 64u * i : OOB, y);
+                        }
                     }
                     ys = row16_sum(ys);
                     const float kmv = (valid && s != 0.0f) ? 1.0f : 0.0f, qmv = (valid && ys != 0.0f) ? 1.0f : 0.0f;
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         // ---- Q = LN(x).Wq + bq (modules.py:172) -> memory, hi/lo -> R1 (in place)
         {
             PHASE_IDS;
+            PRUNE_IDS;
             f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
             load_bfrags((const bf16*)k.w[1], nb, r, hh, bh, bl);
             const Out o = make_out(k.Q, b, T, H, pruned);
@@ -164,12 +172,19 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             bf16* Th = R1 + t0 * LDR + n;
             lds_barrier();                                              // every wave has read its R1 rows
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float v = (n < H) ? acc[j] + bias5[0] : 0.0f;
-                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
-                bstore(o, boff0 + ROWJ(j) * H4, v);
+#define Q_EPI(accv_, rj_)                                                                                  \
+            {                                                                                              \
+                const float v = (n < H) ? (accv_) + bias5[0] : 0.0f;                                       \
+                put_split(Th, Th + TR * LDR, (rj_) * LDR, v);                                              \
+                bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
+            if (!pruned) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) Q_EPI(acc[j], ROWJ(j));
+            } else if (act && hh == hhT) {
+                Q_EPI(pick16(acc, jT), rjT);
+            }
+#undef Q_EPI
         }
         // ---- K = x.Wk + bk (modules.py:173) -> memory, hi/lo -> R2 (the fp32 tile is dead)
         {
@@ -302,6 +317,8 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) O[j] = 0.0f;
             const int q4 = (lane_p & 15) >> 2, p4 = lane_p & 3, g1_ = (lane_p >> 4) & 1;
+            PRUNE_IDS;
+            if (act) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 ph = *(const bf16x8*)(Ph + (32 * mh + r) * LDP + 16 * ks + 8 * hh);
@@ -313,17 +330,24 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 O = mfma_bf16(ph, vl, O);
                 O = mfma_bf16(ph, vh, O);
             }
+            }
             load_bfrags((const bf16*)k.w[3], nb, r, hh, bh, bl);        // W1, consumed after LN2
             const Out o = make_out(k.x1, b, T, H, pruned);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             float* Xp = Xf + t0 * XS + n;
             // ---- x1 = O + LN(x) (modules.py:223); the K tile is dead since the first barrier of the phase: R2 is Xf again
+            if (!pruned) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float v = O[j] + qres[j];
-                Xp[ROWJ(j) * XS] = v;
-                bstore(o, boff0 + ROWJ(j) * H4, v);
+                for (int j = 0; j < 16; ++j) {
+                    const float v = O[j] + qres[j];
+                    Xp[ROWJ(j) * XS] = v;
+                    bstore(o, boff0 + ROWJ(j) * H4, v);
+                }
+            } else if (act && hh == hhT) {
+                const float v = pick16(O, jT) + bload(make_out(k.q_in, b, T, H, true), boff0 + rjT * H4);
+                Xp[rjT * XS] = v;
+                bstore(o, boff0 + rjT * H4, v);
             }
         }
         lds_barrier();
@@ -337,6 +361,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 const int t = 40 * pass + 4 * wave + rsub;
                 if (t < TR) {
                     const bool valid = t < T && (!pruned || t == T - 1);
+                    if (pruned && !valid) continue;     // (16-lane row groups diverge; nothing downstream reads these rows)
                     float x[10], s = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 10; ++i) {
@@ -374,6 +399,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         // ---- h1 = dropout(relu(y.W1 + b1)) (modules.py:254-257) -> memory, hi/lo -> R1
         {
             PHASE_IDS;
+            PRUNE_IDS;
             f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
             load_bfrags((const bf16*)k.w[4], nb, r, hh, bh, bl);
             const DropArgs d1 = drop_of(k.d_ffn1);
@@ -382,20 +408,28 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             const uint32_t didx0 = didx_row0 + (uint32_t)(t0 * H + n);
             bf16* Th = R1 + t0 * LDR + n;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int t = t0 + ROWJ(j);
-                float v = fmaxf(acc[j] + bias5[3], 0.0f);
-                v = drop_apply(d1, didx0 + ROWJ(j) * (uint32_t)H, v);
-                v = (n < H && t < T && (!pruned || t == T - 1)) ? v : 0.0f;
-                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
-                bstore(o, boff0 + ROWJ(j) * H4, v);
+#define F1_EPI(accv_, rj_)                                                                                 \
+            {                                                                                              \
+                const int t = t0 + (rj_);                                                                  \
+                float v = fmaxf((accv_) + bias5[3], 0.0f);                                                 \
+                v = drop_apply(d1, didx0 + (rj_) * (uint32_t)H, v);                                        \
+                v = (n < H && t < T) ? v : 0.0f;                                                           \
+                put_split(Th, Th + TR * LDR, (rj_) * LDR, v);                                              \
+                bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
+            if (!pruned) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) F1_EPI(acc[j], ROWJ(j));
+            } else if (act && hh == hhT) {
+                F1_EPI(pick16(acc, jT), rjT);
+            }
+#undef F1_EPI
         }
         lds_barrier();
         // ---- x2 = (dropout(h1.W2 + b2) + y) * (seq != 0) (modules.py:258-266, ADER.py:80)
         {
             PHASE_IDS;
+            PRUNE_IDS;
             f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
             if (l + 1 < a.L) load_bfrags((const bf16*)kp[1].w[0], nb, r, hh, bh, bl);
             const DropArgs d2 = drop_of(k.d_ffn2);
@@ -404,15 +438,22 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             const uint32_t didx0 = didx_row0 + (uint32_t)(t0 * H + n);
             float* Xp = Xf + t0 * XS + n;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int t = t0 + ROWJ(j);
-                float v = drop_apply(d2, didx0 + ROWJ(j) * (uint32_t)H, acc[j] + bias5[4]);
-                const float yv = (n < XS) ? Xp[ROWJ(j) * XS] : 0.0f;
-                v = (sq_l[t] != 0) ? v + yv : 0.0f;
-                if (n < XS) Xp[ROWJ(j) * XS] = v;
-                bstore(o, boff0 + ROWJ(j) * H4, v);
+#define F2_EPI(accv_, rj_)                                                                                 \
+            {                                                                                              \
+                const int t = t0 + (rj_);                                                                  \
+                float v = drop_apply(d2, didx0 + (rj_) * (uint32_t)H, (accv_) + bias5[4]);                 \
+                const float yv = (n < XS) ? Xp[(rj_) * XS] : 0.0f;                                         \
+                v = (sq_l[t] != 0) ? v + yv : 0.0f;                                                        \
+                if (n < XS) Xp[(rj_) * XS] = v;                                                            \
+                bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
+            if (!pruned) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) F2_EPI(acc[j], ROWJ(j));
+            } else if (act && hh == hhT) {
+                F2_EPI(pick16(acc, jT), rjT);
+            }
+#undef F2_EPI
         }
         lds_barrier();
 #undef k
