@@ -33,6 +33,7 @@
 #define PCS_ROW (LDR * 2 / 16)     // 16-byte pieces per bf16 operand row (21)
 #define NVEC 10                    // 16-byte vectors per thread covering a tile: 10 * 1024 floats >= 64 * 160 (+ 2 peeled)
 #define SPV 3                      // input-embedding gradient rows prefetched under the GEMM phase
+#define SPB 4                      // sparse-list entries per batch of the optimiser phase
 #define TM_LIST 18                 // ints per list in a tile record: [k0, k1, 8 x (id, row)]
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -316,19 +317,50 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
                     if (id < id_hi) F_l[(id - id_lo) * H + tid] += spv[i];
                 }
             }
-            for (int k = k0s + SPV, i = SPV; k < k1s; ++k, ++i) {
-                const int id = (i < 8) ? ms[2 + 2 * i] : f.sp_ids[k];
-                if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
-                const int row = (i < 8) ? ms[3 + 2 * i] : f.sp_rows[k];
-                F_l[(id - id_lo) * H + tid] += f.sp_src[(size_t)row * H + tid] * f.sp_scale;
+            // batches of SPB entries: ids and rows, then every gradient row, then the adds in entry order (one dependent memory
+            // round trip per entry made a hot item's workgroup the straggler of the launch; see table_update_sh.hip)
+            for (int k = k0s + SPV, i = SPV; k < k1s; k += SPB, i += SPB) {
+                int idv[SPB], rw[SPB];
+                float val[SPB];
+#pragma unroll
+                for (int u = 0; u < SPB; ++u) {
+                    const int ic = (i + u) < 8 ? (i + u) : 7;
+                    const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];
+                    const bool in = k + u < k1s;
+                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : f.sp_ids[k + u]);
+                    rw[u] = !in ? 0 : ((i + u < 8) ? row_c : f.sp_rows[k + u]);
+                }
+#pragma unroll
+                for (int u = 0; u < SPB; ++u)      // (ids beyond max_item have no table row)
+                    val[u] = (idv[u] < id_hi) ? f.sp_src[(size_t)rw[u] * H + tid] * f.sp_scale : 0.0f;
+#pragma unroll
+                for (int u = 0; u < SPB; ++u)
+                    if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] += val[u];
             }
-            for (int k = mg[0], k1 = mg[1], i = 0; k < k1; ++k, ++i) {
-                const int id = (i < 8) ? mg[2 + 2 * i] : f.tg_ids[k];
-                if (id >= id_hi) continue;      // (beyond max_item: no table row; entries of a bucket are in position order)
-                const int b = (i < 8) ? mg[3 + 2 * i] : f.tg_rows[k];
-                float rv = (float)a.rep_hi[(size_t)b * LDR + tid];
-                if (X3) rv += (float)a.rep_lo[(size_t)b * LDR + tid];
-                F_l[(id - id_lo) * H + tid] -= f.wrow[b] * rv;
+            for (int k = mg[0], k1 = mg[1], i = 0; k < k1; k += SPB, i += SPB) {
+                int idv[SPB], bw[SPB];
+                float val[SPB];
+#pragma unroll
+                for (int u = 0; u < SPB; ++u) {
+                    const int ic = (i + u) < 8 ? (i + u) : 7;
+                    const int id_c = mg[2 + 2 * ic], b_c = mg[3 + 2 * ic];
+                    const bool in = k + u < k1;
+                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : f.tg_ids[k + u]);
+                    bw[u] = !in ? 0 : ((i + u < 8) ? b_c : f.tg_rows[k + u]);
+                }
+#pragma unroll
+                for (int u = 0; u < SPB; ++u) {
+                    float rv = 0.0f;
+                    if (idv[u] < id_hi) {
+                        rv = (float)a.rep_hi[(size_t)bw[u] * LDR + tid];
+                        if (X3) rv += (float)a.rep_lo[(size_t)bw[u] * LDR + tid];
+                        rv *= f.wrow[bw[u]];
+                    }
+                    val[u] = rv;
+                }
+#pragma unroll
+                for (int u = 0; u < SPB; ++u)
+                    if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] -= val[u];
             }
         }
     }
