@@ -84,6 +84,22 @@ def test_two_ranks_match_single_process(logits, sharded):
     # same masks (dropout keyed by global row), same math; differences: summation order of the row reductions, Adam's
     # eps-scale sensitivity for ~zero gradients, and (second step) ReLU branch flips -- see test_gpu_parity
     assert np.mean(d < 5e-6) > 0.995 and d.max() < 2.5e-3
+    # ... and against the CPU restatement itself (oracle/ader_ref_cpu.py, bf16-operand aware where the logit kernels are), so the
+    # sharded schemes are not only compared with another run of the same kernels: two full-batch oracle steps with the same
+    # counter-keyed dropout masks.  Bound as in test_three_train_steps_track_the_oracle (Adam normalises tiny gradients to
+    # +-lr: compare on the scale of the accumulated update)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import ader_ref_cpu as R
+    eng0 = _engine(logits)
+    params = {k: v.to(torch.float32) for k, v in eng0.export_params().items()}
+    opt = R.TFAdam(params)
+    for step in range(2):
+        R.train_step(params, opt, seq, pos, N, L, HEADS, 5e-4, training=True, rate=0.3, seed=4, step=step,
+                     logits_bf16=(logits == "bf16"))
+    oemb = params["emb"].numpy().reshape(-1)[:(ITEMS + 1) * H]
+    do = np.abs(got - oemb)
+    assert do.max() < 3e-4 + 2.5e-3 * (logits == "bf16") and np.mean(do < 2e-5) > 0.99, (do.max(), np.mean(do < 2e-5))
 
 
 # ---------------------------------------------------------------------------------------------- distilled steps under DP
