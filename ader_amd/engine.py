@@ -155,7 +155,8 @@ def param_layout(item_num, T, H, L, align=64, table_rows_alloc=None):
 
 
 class Engine:
-    MAX_ROWS = 1024   # padded batch rows per launch (logits kernels keep per-row state in LDS)
+    MAX_ROWS = 1024        # padded batch rows per launch of the exact-f32 logit kernels (per-row state in LDS) and of the eval paths
+    MAX_ROWS_FAST = 4096   # ... of a train step whose logits run on the flash kernels (logits_dtype bf16 / x3): 128-row chunks
 
     def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0",
                  logits_dtype="f32", gemm="x3", dp_rank=0, dp_world=1):
@@ -671,7 +672,8 @@ class Engine:
         seq = self._dev_i32(seq)
         pos = self._dev_i32(pos)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
-        assert B <= self.MAX_ROWS, "at most %d rows per step" % self.MAX_ROWS
+        cap = self.MAX_ROWS_FAST if self.lfast else self.MAX_ROWS
+        assert B <= cap, "at most %d rows per step with logits_dtype=%s" % (cap, self.logits_dtype)
         n_train = pos.shape[0]
         n_ex = B - n_train
         N = int(max_item)
@@ -696,7 +698,7 @@ class Engine:
                         and N >= self._grad_hi and self.dp_world == 1 and self.kd_split)
         # ... or (default, bf16 and x3 modes): ALL rows on the flash path -- the exemplar rows as their own 128-row chunks whose softmax runs
         # over the first Np items, with the teacher term as a second readout (forward) and a subtraction inside the fused update
-        kd_rows_fit = ((n_train + 127) // 128 + (n_ex + 127) // 128) * 128 <= self.MAX_ROWS
+        kd_rows_fit = ((n_train + 127) // 128 + (n_ex + 127) // 128) * 128 <= cap
         kd_fast = bool(split_kd and self.kd_fast and kd_rows_fit)
         # the same forward without the fused update (data-parallel ranks, or no optimiser step): the table gradient is written
         # out (ader_tab_grad_kd) and takes the dense exchange

@@ -9,7 +9,9 @@
  * passed as void* (NULL = default stream).  Launchers only enqueue work (no sync, no allocation: graph-capturable);
  * they return 0 on success, a hipError_t value on a HIP error, or a negative code for unsupported shapes
  * (-2: dimension out of range, -3: bad enum).  Inputs are borrowed for the duration of the enqueued work.
- * Limits of this build: H (hidden_units) <= 159, maxlen T <= 64, padded batch rows Bp <= 1024 and Bp % 64 == 0.
+ * Limits of this build: H (hidden_units) <= 159, maxlen T <= 64; padded batch rows Bp % 64 == 0 and Bp <= 1024 for the exact-f32
+ * logit kernels (ader_logits_*: per-row state in LDS); the flash kernels (ader_lbf_*, ader_lx3_*, ader_tab_*) take Bp % 128 == 0 of
+ * any size (the engine allows 4096 rows per step).
  */
 #ifndef ADER_HIP_H
 #define ADER_HIP_H

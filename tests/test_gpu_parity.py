@@ -611,6 +611,38 @@ def test_kd_fast_x3_step_matches_exact_oracle(cfg, n_ex, Np):
         assert e < 6e-4, (k, e)
 
 
+@pytest.mark.parametrize("n_train,n_ex", [(1300, 0), (1100, 200)])
+def test_more_than_1024_rows_per_step_on_the_flash_path(n_train, n_ex):
+    """Steps with more than 1024 rows (reference --batch_size is free, main.py:94): the flash logit kernels work on 128-row chunks and
+    the fused update loops over the batch, so logits_dtype bf16 / x3 take up to Engine.MAX_ROWS_FAST rows (the exact-f32 logit
+    kernels keep per-row state in LDS: 1024, asserted).  x3 step, vanilla and distilled, against the float64 oracle at the bounds
+    of test_kd_fast_x3_step_matches_exact_oracle."""
+    item_num, T, H, L, heads, N, Np = 1500, 50, 150, 2, 1, 1400, 1200
+    rs = np.random.RandomState(6)
+    seq = _seqs(rs, n_train + n_ex, T, N)
+    pos = rs.randint(1, N + 1, size=n_train).astype(np.int32)
+    eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype="x3")
+    p64 = _params(eng, torch.float64)
+    eng.global_step = 2
+    kw, okw = {}, {}
+    if n_ex:
+        teacher = torch.from_numpy((rs.standard_normal((n_ex, Np)) * 2).astype(np.float32)).cuda()
+        kw = dict(teacher=teacher, ex_trow=np.arange(n_ex, dtype=np.int32), lambda_=0.7)
+        okw = dict(ex_logits=teacher.cpu().double(), lambda_=0.7)
+    loss = eng.train_step(seq, pos, N, 5e-4, rate=0.3, **kw)
+    torch.cuda.synchronize()
+    eng.check_status()
+    mk = relu_masks_of(eng)
+    ol, og = R.loss_and_grads(p64, seq, pos, N, L, heads, training=True, rate=0.3, seed=8, step=2, relu_masks=mk, **okw)
+    assert abs(float(loss.item()) - float(ol)) < 2e-5 * max(1.0, abs(float(ol)))
+    for k in eng.layout:
+        g = eng.view(eng.adam_m, k).cpu().numpy() / 0.1
+        e = nerr(g, og[k].numpy(), floor=1e-4)
+        assert e < 6e-4, (k, e)
+    with pytest.raises(AssertionError):            # the exact-f32 logit kernels: loud limit, no silent truncation
+        _engine(item_num, T, H, L, heads, seed=8, logits_dtype="f32").train_step(seq, pos, N, 5e-4, rate=0.3, **kw)
+
+
 @pytest.mark.parametrize("cfg,n_ex,Np", [(BF16_CFGS[1], 37, 4000), (BF16_CFGS[0], 70, 650), (BF16_CFGS[1], 200, 4321)])
 def test_kd_fast_step_matches_bf16_aware_oracle(cfg, n_ex, Np):
     """Distilled step with every row on the bf16 flash path (Engine.kd_fast: exemplar rows as their own chunks with the softmax
