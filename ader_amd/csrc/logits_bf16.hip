@@ -21,6 +21,9 @@
 // before block i's softmax (0.40 ms: the second S accumulator costs the occupancy that hid the exp2 chain); (b) the same forward on
 // v_mfma_f32_16x16x32_bf16 with 8 waves x 16 batch rows (126 VGPRs, 16 waves per CU; bit-equal results): 0.43 ms -- every MFMA of
 // that shape fetches the same LDS operand bytes for half the flops, and the LDS pipe, not occupancy, is the limit here.
+// (c) 64 batch rows per wave at one wave per SIMD (every table fragment feeds two MFMAs: half the LDS bytes per flop): 0.79 ms --
+// 160 accumulator registers of O plus the rep fragments exceed the 256 architectural VGPRs, the compiler parks O in AGPRs and
+// moves it back and forth for the softmax / rescale VALU work (~1900 v_accvgpr moves per three blocks), with no second wave to hide it.
 //
 // LDS tiles are row-major bf16 with a 168-element (336 B) row stride: ds_read_b128 operand reads are conflict-free
 // (20 r mod 64 covers 16 distinct 4-bank slots).  gfx950 only.
