@@ -35,6 +35,8 @@ struct FuseArgs128 {
 };
 
 #define SPV 3                      // input-embedding gradient rows prefetched under the GEMM phase
+#define HEAVY_N 32                 // a bucket with more entries than this in either list takes the heavy path
+#define HVB 16                     // gradient rows in flight per thread on the heavy path
 #define SPB 8                      // sparse-list entries per batch of the optimiser phase (loads of a batch are independent)
 #define AV 6                       // 16-byte vectors per thread and load round of the optimiser phase (x theta, m, v)
 
@@ -232,7 +234,11 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
     f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
     const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)tile0 * H : nullptr;
     int E[AV], RC[AV], NV[AV];
-    ROUND_LOAD();               // first round of theta/m/v: requested BEFORE the dE staging and the sparse terms
+    // A bucket that holds a hot item (Zipf ids: hundreds of entries) takes the HEAVY path below: its (id, row) lists are fetched
+    // cooperatively, 256 entries per round trip, and the gradient rows HVB at a time -- with the optimiser loads requested AFTER
+    // the sparse terms, so that the registers are free for the deeper batches (a workgroup-uniform choice; rare tiles).
+    const bool heavy = (meta_l[1] - meta_l[0] > HEAVY_N) || (meta_l[19] - meta_l[18] > HEAVY_N);
+    if (!heavy) { ROUND_LOAD(); }   // first round of theta/m/v: requested BEFORE the dE staging and the sparse terms
     lds_only_barrier();
 #pragma unroll
     for (int cb = 0; cb < 10; ++cb) {
@@ -246,7 +252,34 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
     {
         // sparse terms of the tile: item ids [tile0+1, tile0+65).  Thread c owns column c of every row.
         const int id_lo = tile0 + 1, id_hi = min(tile0 + 64, N) + 1;
-        if (tid < H && id_lo < id_hi) {
+        if (heavy) {
+            int* hv_l = (int*)(smem_raw + 64 * HP * sizeof(float));     // [2][256] (id, row) of the current chunk, behind F_l
+            // entries in list order (the same order, hence the same rounding, as the light path)
+#define HEAVY_LIST(K0_, K1_, IDS_, ROWS_, VAL_, OP_)                                                       \
+            for (int base_ = (K0_); base_ < (K1_); base_ += 256) {                                         \
+                const int n_ = min(256, (K1_) - base_);                                                    \
+                if (tid < n_) { hv_l[tid] = (IDS_)[base_ + tid]; hv_l[256 + tid] = (ROWS_)[base_ + tid]; } \
+                __syncthreads();                                                                           \
+                if (tid < H && id_lo < id_hi) {                                                            \
+                    for (int e0_ = 0; e0_ < n_; e0_ += HVB) {                                              \
+                        int idv[HVB];                                                                      \
+                        float val[HVB];                                                                    \
+                        _Pragma("unroll") for (int u = 0; u < HVB; ++u) {                                  \
+                            const bool in_ = e0_ + u < n_;                                                 \
+                            idv[u] = in_ ? hv_l[e0_ + u] : 0x7fffffff;                                     \
+                            const int rw = in_ ? hv_l[256 + e0_ + u] : 0;                                  \
+                            val[u] = (idv[u] < id_hi) ? (VAL_) : 0.0f;                                     \
+                        }                                                                                  \
+                        _Pragma("unroll") for (int u = 0; u < HVB; ++u)                                    \
+                            if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] OP_ val[u];                \
+                    }                                                                                      \
+                }                                                                                          \
+                __syncthreads();                                                                           \
+            }
+            HEAVY_LIST(meta_l[0], meta_l[1], f.sp_ids, f.sp_rows, f.sp_src[(size_t)rw * H + tid] * f.sp_scale, +=)
+            HEAVY_LIST(meta_l[18], meta_l[19], f.tg_ids, f.tg_rows, f.wrow[rw] * (float)a.rep_bf[(size_t)rw * LDR + tid], -=)
+#undef HEAVY_LIST
+        } else if (tid < H && id_lo < id_hi) {
             const int* ms = meta_l;
             const int* mg = meta_l + 18;
             const int k0s = ms[0], k1s = ms[1];
@@ -299,6 +332,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
             }
         }
     }
+    if (heavy) { ROUND_LOAD(); }
     lds_only_barrier();
     bf16* __restrict__ psh = f.sh1w + (size_t)tile0 * LDR;
 #define ADAM1(p_, m_, v_, g_)                                                                              \

@@ -529,6 +529,34 @@ def test_fused_table_adam_equals_unfused_step(cfg, ld):
     assert nerr(a2[1], b2[1]) < 3e-2 and np.abs(a2[0] - b2[0]).max() < 2.5e-3
 
 
+@pytest.mark.parametrize("ld", ["bf16", "x3"])
+def test_fused_update_with_a_hot_item_bucket(ld):
+    """One item in 600 input positions and 120 labels of the batch (popular items / Zipf ids): its 64-id bucket takes the heavy
+    path of the fused update (lists fetched 256 entries at a time, gradient rows in deep batches, more than one chunk).  One step
+    from identical state against the unfused path (dE materialised, float-atomic scatter, flat Adam): summation order only."""
+    item_num, T, H, L, heads, B, N = BF16_CFGS[1]
+    rs = np.random.RandomState(35)
+    seq = _seqs(rs, B, T, N)
+    seq[:200, -3:] = 77
+    seq[200:230, -1] = 78                              # a second busy id in the same bucket
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    pos[:120] = 77
+    pos[120:160] = 4000                                # ... and a busy label elsewhere
+    snaps = []
+    for fuse in (True, False):
+        eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype=ld)
+        eng.fuse_adam = fuse
+        eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+        torch.cuda.synchronize()
+        snaps.append((eng.theta.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy()))
+    a, b = snaps
+    assert nerr(a[1], b[1]) < 2e-5 and nerr(a[2], b[2]) < 2e-5
+    d = np.abs(a[0] - b[0])
+    assert np.mean(d < 2e-6) > 0.999 and d.max() < 1.1e-3
+    row = slice(77 * H, 78 * H)                        # the hot row itself received every term
+    assert np.abs(a[1][row]).max() > 0 and nerr(a[1][row], b[1][row]) < 2e-5
+
+
 @pytest.mark.parametrize("cfg", [BF16_CFGS[0], BF16_CFGS[1]])
 def test_both_bf16_update_forms_agree(cfg):
     """The two fused bf16 table updates -- k_tab16 (operand from the shadow rows, the default) and k_tab_upd (theta tile read once
