@@ -218,16 +218,21 @@ __global__ __launch_bounds__(256, 2) void k_lbf_fwd(LbfArgs a) {
     const int r = lane & 31, hh = lane >> 5;
     // chunks: Bp/128 softmax chunks, then one TEACHER-READOUT chunk per 128 KD rows (same item ranges, same XCD grouping, so
     // the table blocks they stream are shared through L2)
-    const int nsm = a.Bp >> 7, nkd = (a.Bp - a.kd_row0) >> 7, nchunk = nsm + nkd;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int range = xcd + 8 * (slot / nchunk);
-    int bc = slot % nchunk;
-    if (range >= a.ranges) return;
-    const bool readout = bc >= nsm;
-    if (readout) bc = (a.kd_row0 >> 7) + (bc - nsm);
+    // The readout chunks come after all softmax workgroups and have their OWN, finer partition of the item blocks (ranges2 >=
+    // ranges): a readout block costs ~1.5 softmax blocks (teacher loads + exp2 per element), and with a shared partition the
+    // readout workgroups were the stragglers of the launch (+128 exemplar rows at 900k columns: 0.85 ms -> see DESIGN.md).
+    const int nsm = a.Bp >> 7, nkd = (a.Bp - a.kd_row0) >> 7;
+    const int n_sm = a.ranges * nsm;                                  // softmax workgroups (a multiple of 8)
+    const bool readout = (int)blockIdx.x >= n_sm;
+    const int bid = readout ? blockIdx.x - n_sm : blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nranges = readout ? a.ranges2 : a.ranges;
+    const int range = xcd + 8 * (slot / (readout ? nkd : nsm));
+    int bc = readout ? (a.kd_row0 >> 7) + slot % nkd : slot % nsm;
+    if (range >= nranges) return;
     const int N = (bc * 128 >= a.kd_row0) ? a.Np : a.N;              // columns of this chunk's softmax
     const int nblk_all = (a.N + FB - 1) / FB;                         // ranges partition the blocks of the whole catalog
-    const int per = (nblk_all + a.ranges - 1) / a.ranges;
+    const int per = (nblk_all + nranges - 1) / nranges;
     const int blk_begin = range * per, blk_end = min((N + FB - 1) / FB, blk_begin + per);
     const int nb_blocks = max(0, blk_end - blk_begin);
     const int b0 = bc * 128 + wave * 32;
@@ -800,6 +805,9 @@ static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
 
 extern "C" {
 
+int ader_lbf_ranges_kd(int N, int Bp, int kd_row0);
+int ader_lbf_readout_ranges(int N, int Bp, int kd_row0);
+
 // shadow [rows][168] bf16 <- emb [rows][H] fp32  (initialisation / checkpoint load; ader_adam_step keeps it in sync afterwards)
 int ader_lbf_shadow_refresh(const float* emb, void* shadow, size_t rows, int H, void* stream) {
     if (rows == 0) return 0;
@@ -874,22 +882,33 @@ int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_tr
     LbfArgs a;
     a.sh1 = (const bf16*)shadow + LDR; a.vrows = item_num; a.tile_off = 0;
     a.rep_bf = (const bf16*)rep_bf; a.B = n_train + n_ex; a.Bp = Bp; a.H = H; a.N = N;
-    const int nchunk = Bp / 128 + (Bp - kd_row0) / 128;
-    a.ranges = ader_lbf_ranges(N, nchunk * 128);
+    const int nsm = Bp / 128, nkd = (Bp - kd_row0) / 128;
+    a.ranges = ader_lbf_ranges_kd(N, Bp, kd_row0);
     a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr;
     a.kd_row0 = kd_row0; a.Np = Np; a.n_train = n_train; a.n_ex = n_ex; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
-    a.pO2 = pO2; a.ranges2 = a.ranges;
+    a.pO2 = pO2; a.ranges2 = ader_lbf_readout_ranges(N, Bp, kd_row0);
     hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, (bf16*)nullptr, n_train, n_ex,
                        kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
-    hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * nchunk), dim3(256), kFwdLds, st, a);
+    hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * nsm + a.ranges2 * nkd), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        (const float*)nullptr, (const float*)nullptr);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
     HIP_LAUNCH_CHECK();
     return 0;
 }
-// ranges used by ader_lbf_fwd_kd (scratch sizing): pm / pl: R*Bp, pO: R*Bp*160, pO2: R*(Bp-kd_row0)*160
+// ranges used by ader_lbf_fwd_kd (scratch sizing): pm / pl: R*Bp, pO: R*Bp*160 with R = ader_lbf_ranges_kd; pO2: R2*(Bp-kd_row0)*160
+// with R2 = ader_lbf_readout_ranges (the readout chunks take the workgroup slots the softmax chunks leave of the 512 resident ones)
 int ader_lbf_ranges_kd(int N, int Bp, int kd_row0) { return ader_lbf_ranges(N, (Bp / 128 + (Bp - kd_row0) / 128) * 128); }
+int ader_lbf_readout_ranges(int N, int Bp, int kd_row0) {
+    const int nsm = Bp / 128, nkd = (Bp - kd_row0) / 128, R = ader_lbf_ranges_kd(N, Bp, kd_row0);
+    if (nkd < 1) return R;
+    const int nblk = (N + FB - 1) / FB;
+    int extra = ((512 - (nsm + nkd) * R) / nkd) / 8 * 8;
+    if (extra < 0) extra = 0;
+    int r2 = R + extra;
+    if (r2 > (nblk + 7) / 8 * 8) r2 = (nblk + 7) / 8 * 8;
+    return r2 < R ? R : r2;
+}
 
 // rep fp32 [B,H] -> rep_bf [Bp,168] bf16 (zero padded): the operand layout of the bf16 logit kernels
 int ader_lbf_prep(const float* rep, void* rep_bf, int B, int Bp, int H, void* stream) {

@@ -810,7 +810,7 @@ class Engine:
         if self.lx3:      # the x3 teacher readout is a launch of its own, with its own item ranges
             R, R2 = call("ader_lbf_ranges", N, Bp), call("ader_lx3_readout_ranges", Np, Bk)
         else:
-            R = R2 = call("ader_lbf_ranges_kd", N, Bp, Bt)
+            R, R2 = call("ader_lbf_ranges_kd", N, Bp, Bt), call("ader_lbf_readout_ranges", N, Bp, Bt)
         rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
         rep_lo = self.buf("lbf_rep_lo", (Bp * 168,), torch.bfloat16) if self.lx3 else None
         pm, pl = self.buf("lbf_pm", (R * Bp,)), self.buf("lbf_pl", (R * Bp,))

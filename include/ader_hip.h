@@ -211,12 +211,14 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
  * laid out [train rows padded to 128 | exemplar rows padded to 128] (Bp rows, kd_row0 = first exemplar row): lab / wrow / trow / tlse2
  * (written here) and lse / off / rowloss are [Bp] in that layout; drep is compact.  ex_trow[e]: row of `teacher` [*, ldt] for
  * exemplar e; tlse_all[r]: natural log-sum-exp of teacher row r over [0, Np).  w_train = 1/B_train, w_ex = lambda/B_ex.
- * Scratch: rep_bf Bp*168 bf16; R = ader_lbf_ranges_kd(N, Bp, kd_row0); pm, pl: R*Bp; pO: R*Bp*160; pO2: R*(Bp-kd_row0)*160 floats. */
+ * Scratch: rep_bf Bp*168 bf16; R = ader_lbf_ranges_kd(N, Bp, kd_row0); pm, pl: R*Bp; pO: R*Bp*160; pO2: R2*(Bp-kd_row0)*160 floats with
+ * R2 = ader_lbf_readout_ranges(N, Bp, kd_row0) (the teacher-readout chunks have their own, finer partition of the item blocks). */
 int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
                     int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all,
                     float w_train, float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_bf, float* pm, float* pl,
                     float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream);
 int ader_lbf_ranges_kd(int N, int Bp, int kd_row0);
+int ader_lbf_readout_ranges(int N, int Bp, int kd_row0);
 /* the same forward at float32 grade (x3): the fp32 table instead of the shadow, two operand planes rep_hi / rep_lo.  Scratch:
  * pm / pl / pO with R = ader_lbf_ranges(N, Bp); pO2: ader_lx3_readout_ranges(Np, Bp - kd_row0) * (Bp - kd_row0) * 160 floats (the
  * teacher readout is a launch of its own here) */
