@@ -48,7 +48,7 @@ __device__ __forceinline__ void flush_ln_partials(float (&dg)[10], float (&db)[1
 // keep_row(t): rows that exist (t < T, and only T-1 for a pruned block).  dx -> Xf in place and, if odx, to memory.
 template <bool STORE>
 __device__ __forceinline__ void ln_bwd_rows(float* Xf, const Out& ox, const Out& omean, const Out& ostd, const float (&gam)[10],
-                                            const Out& odx, int T, int H, bool pruned, int wave, int lane, float (&dg)[10],
+                                            const Out& odx, int T, int H, bool pruned, int tv0, int wave, int lane, float (&dg)[10],
                                             float (&db)[10]) {
     const int sub = lane & 15, rsub = lane >> 4;
 #pragma unroll 1
@@ -57,6 +57,15 @@ __device__ __forceinline__ void ln_bwd_rows(float* Xf, const Out& ox, const Out&
         if (t >= TR) continue;
         const bool valid = t < T && (!pruned || t == T - 1);
         const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
+        if (t < tv0) {      // leading padding: the forward wrote no x / mean / sd for these rows; their gradient is exactly zero
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int c = sub + 16 * i;
+                Xf[t * XS + c] = 0.0f;
+                if (STORE) bstore(odx, (c < H) ? bo + 64u * i : OOB, 0.0f);
+            }
+            continue;
+        }
         float xv[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) xv[i] = bload(ox, (sub + 16 * i < H) ? bo + 64u * i : OOB);
@@ -128,15 +137,34 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
     float gam[10];
     load10(a.ln2_g, H, lane & 15, gam);
     lds_barrier();
+    // leading padding (see seq_fwd.hip): rows [0, tv0) carry exactly zero gradient and the forward saved nothing for them -- they
+    // are not computed, their gradient rows are written as zeros (the weight-gradient products and the attention backward read
+    // every row)
+    int tv0;
+    {
+        const unsigned long long nz = __ballot(lane < T && sq_l[lane] != 0);
+        tv0 = nz ? (int)__ffsll((long long)nz) - 1 : T;
+    }
+    const bool skipw = mh == 0 && tv0 >= 32;
     // ---- g = dx2 * (seq != 0) -> Xf;  dh2 = g * keep * scale (modules.py:262-266, ADER.py:80) -> memory, hi/lo -> R0
     {
         const Out odx = make_out(a.dx2, b, T, H, pruned), odh = make_out(a.dh2, b, T, H, pruned);
-        const DropArgs d2 = drop_of(a.d_ffn2);
+        const SDrop d2 = sdrop_of(a.d_ffn2, didx_row0);
         const int sub = lane & 15, rsub = lane >> 4;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int t = 40 * pass + 4 * wave + rsub;
-            if (t < TR) {
+            if (t < tv0) {
+                const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
+                bf16* Tp = R0 + t * LDR + sub;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int c = sub + 16 * i;
+                    Xf[t * XS + c] = 0.0f;
+                    Tp[16 * i] = (bf16)0.0f; Tp[TR * LDR + 16 * i] = (bf16)0.0f;
+                    bstore(odh, (c < H) ? bo + 64u * i : OOB, 0.0f);
+                }
+            } else if (t < TR) {
                 const uint32_t bo = (uint32_t)(t * H + sub) * 4u;
                 float v[10];
 #pragma unroll
@@ -148,7 +176,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
                     const int c = sub + 16 * i;
                     const float g = live ? v[i] : 0.0f;
                     Xf[t * XS + c] = g;
-                    const float dh = drop_apply(d2, didx_row0 + (uint32_t)(t * H + c), g);
+                    const float dh = sdrop_apply(d2, didx_row0 + d2.off + (uint32_t)(t * H + c), g);
                     put_split(Tp, Tp + TR * LDR, 16 * i, dh);
                     bstore(odh, (c < H) ? bo + 64u * i : OOB, dh);
                 }
@@ -169,11 +197,16 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
         load_bfrags((const bf16*)a.w1 + 2 * WSZ, nb, r, hh, bh, bl);
         bf16* Th = R1 + t0 * LDR + n;
         const float sc1 = a.d_ffn1.scale;
+        if (skipw) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float v = (h1[j] != 0.0f) ? acc[j] * sc1 : 0.0f;
-            put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
-            bstore(oda, boff0 + ROWJ(j) * H4, v);
+            for (int j = 0; j < 16; ++j) bstore(oda, boff0 + ROWJ(j) * H4, 0.0f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = (h1[j] != 0.0f) ? acc[j] * sc1 : 0.0f;
+                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                bstore(oda, boff0 + ROWJ(j) * H4, v);
+            }
         }
     }
     lds_barrier();
@@ -182,8 +215,10 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
         PHASE_IDS;
         f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
         float* Xp = Xf + (32 * mh + 4 * hh) * XS + n;
+        if (!skipw) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Xp[ROWJ(j) * XS] += acc[j];
+            for (int j = 0; j < 16; ++j) Xp[ROWJ(j) * XS] += acc[j];
+        }
     }
     lds_barrier();
     // ---- LayerNorm2 backward -> dx1 (memory) + gamma/beta partials of the session
@@ -193,7 +228,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
     {
         const Out ox = make_out(a.x1, b, T, H, pruned), om = make_out(a.mean2, b, T, 1, pruned), os = make_out(a.std2, b, T, 1, pruned);
         const Out odx1 = make_out(a.dx1, b, T, H, pruned);
-        ln_bwd_rows<true>(Xf, ox, om, os, gam, odx1, T, H, pruned, wave, lane, dg, db);
+        ln_bwd_rows<true>(Xf, ox, om, os, gam, odx1, T, H, pruned, tv0, wave, lane, dg, db);
     }
     flush_ln_partials(dg, db, red_l, a.slab, b, H, tid);
 }
@@ -216,6 +251,12 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
         load_bfrags((const bf16*)a.wq + 2 * WSZ, nb, r, hh, bh, bl);
     }
     if (tid < TR) sq_l[tid] = (a.emb_bwd && tid < T) ? a.seq[(size_t)b * T + tid] : 1;
+    int tv0;                                    // leading padding rows (see k_seq_bwd_ffn)
+    {
+        const unsigned long long nz = __ballot(lane < T && a.seq[(size_t)b * T + (lane < T ? lane : 0)] != 0);
+        tv0 = nz ? (int)__ffsll((long long)nz) - 1 : T;
+    }
+    const bool skipw = mh == 0 && tv0 >= 32;
     float gam[10];
     load10(a.ln1_g, H, lane & 15, gam);
     // ---- dQ rows -> R0 (a pruned block has the row of position T-1 only), dK rows -> R1
@@ -238,8 +279,10 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
         f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
         load_bfrags((const bf16*)a.wk + 2 * WSZ, nb, r, hh, bh, bl);
         float* Xp = Xf + t0 * XS + n;
+        if (!skipw) {           // (an all-padding wave: its Xf rows are cleared by the LayerNorm backward below)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Xp[ROWJ(j) * XS] = acc[j] + res[j];
+            for (int j = 0; j < 16; ++j) Xp[ROWJ(j) * XS] = acc[j] + res[j];
+        }
     }
     lds_barrier();
     // ---- dV rows -> R0 (dQ is consumed); LayerNorm1 backward in place in Xf + gamma/beta partials
@@ -252,7 +295,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
         // x rows of the block input are [B*T,H] also for a pruned block; its statistics are compact
         Out ox = make_out(a.x, b, T, H, false);
         const Out om = make_out(a.mean1, b, T, 1, pruned), os = make_out(a.std1, b, T, 1, pruned);
-        ln_bwd_rows<false>(Xf, ox, om, os, gam, ox, T, H, pruned, wave, lane, dg, db);
+        ln_bwd_rows<false>(Xf, ox, om, os, gam, ox, T, H, pruned, tv0, wave, lane, dg, db);
     }
     lds_barrier();
     // ---- dx = LN1-backward + dK . Wk^T + dV . Wv^T  [block 0: * (seq != 0) * keep * scale of the embedding prologue]
@@ -273,19 +316,24 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
             }
         }
         const Out odx = make_out(a.dx, b, T, H, false);
-        const DropArgs d0 = drop_of(a.d_emb);
+        const SDrop d0 = sdrop_of(a.d_emb, (uint32_t)b * (uint32_t)T * (uint32_t)H);
         const int t0 = 32 * mh + 4 * hh;
         const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
-        const uint32_t didx0 = (uint32_t)b * (uint32_t)T * (uint32_t)H + (uint32_t)(t0 * H + n);
+        const uint32_t didx0 = (uint32_t)b * (uint32_t)T * (uint32_t)H + d0.off + (uint32_t)(t0 * H + n);
         const float* Xp = Xf + t0 * XS + n;
+        if (skipw) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float v = Xp[ROWJ(j) * XS] + acc[j];
-            if (a.emb_bwd) {
-                v = drop_apply(d0, didx0 + ROWJ(j) * (uint32_t)H, v);
-                v = (sq_l[t0 + ROWJ(j)] != 0) ? v : 0.0f;
+            for (int j = 0; j < 16; ++j) bstore(odx, boff0 + ROWJ(j) * H4, 0.0f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v = Xp[ROWJ(j) * XS] + acc[j];
+                if (a.emb_bwd) {
+                    v = sdrop_apply(d0, didx0 + ROWJ(j) * (uint32_t)H, v);
+                    v = (sq_l[t0 + ROWJ(j)] != 0) ? v : 0.0f;
+                }
+                bstore(odx, boff0 + ROWJ(j) * H4, v);
             }
-            bstore(odx, boff0 + ROWJ(j) * H4, v);
         }
     }
     flush_ln_partials(dg, db, red_l, a.slab, b, H, tid);

@@ -49,6 +49,22 @@ template <class D> __device__ __forceinline__ DropArgs drop_of(const D& d) {
     DropArgs o; o.key = d.key; o.thr = d.thr; o.scale = d.scale; o.base = d.base; o.split = d.split; o.base2 = d.base2;
     return o;
 }
+// Dropout of the session-tiled kernels: all elements of a workgroup lie in ONE row segment of the counter space (the segments
+// split at whole sessions), so the segment base is chosen once per phase and folded into the lane's base index, and the keep
+// decision is branch-free -- thr == 0 (dropout off) keeps everything at scale 1.  (The per-element "thr == 0?" branch of
+// drop_apply cut the 16-element epilogues into 16 basic blocks whose dependent chains -- two quarter-rate integer multiplies
+// each -- could not be interleaved: a wave took ~4 us per epilogue with the SIMD mostly idle.)  Same counters, same decisions.
+struct SDrop { uint32_t key, thr, off; float scale; };
+template <class D> __device__ __forceinline__ SDrop sdrop_of(const D& d, uint32_t first_idx) {
+    SDrop o;
+    o.key = d.key; o.thr = d.thr; o.scale = d.thr ? d.scale : 1.0f;
+    o.off = (first_idx >= d.split) ? d.base2 : d.base;
+    return o;
+}
+// idx_off = local element index + SDrop.off
+__device__ __forceinline__ float sdrop_apply(const SDrop& d, uint32_t idx_off, float x) {
+    return ((lowbias32(idx_off ^ d.key) >> 8) >= d.thr) ? x * d.scale : 0.0f;
+}
 __device__ __forceinline__ void put_split(bf16* Th, bf16* Tl, int off, float v) {
     const bf16 h = (bf16)v;
     Th[off] = h;

@@ -36,9 +36,10 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
     const BlkPtr blks = (BlkPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
                                  offsetof(AderSeqFwd, blk));
 
+    for (int i = tid; i < 2 * RSZ * (int)sizeof(bf16) / 16; i += 640) ((uint4*)R0)[i] = make_uint4(0u, 0u, 0u, 0u);   // R0, R1
     // ---- prologue (modules.py:118-130, ADER.py:41-60): x0 = dropout(E[seq]*sqrt(H) + P[t]) * (seq != 0)
     {
-        const DropArgs d0 = drop_of(a.d_emb);
+        const SDrop d0 = sdrop_of(a.d_emb, didx_row0);
         const Out ox0 = make_out(a.x0, b, T, H, false);
         int ids[7];
         float ev[7][3], pv[7][3];
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 for (int i = 0; i < 3; ++i) {
                     const int c = lane + 64 * i;
                     float v = ev[u][i] * a.sqrtH + pv[u][i];
-                    v = drop_apply(d0, didx_row0 + (uint32_t)(t * H + c), v);
+                    v = sdrop_apply(d0, didx_row0 + d0.off + (uint32_t)(t * H + c), v);
                     v = (ids[u] != 0 && t < T && c < H) ? v : 0.0f;
                     if (c < XS) Xf[t * XS + c] = v;
                     bstore(ox0, (c < H) ? (uint32_t)(t * H + c) * 4u : OOB, v);
@@ -88,6 +89,17 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         load_bfrags((const bf16*)blks[0].w[0], nb, r, hh, bh, bl);       // Wq of block 0 (in flight across the barrier)
     }
     lds_barrier();
+    // ---- leading padding.  Sessions are left-padded (util.py:161-169); on real data ~90 % of the positions are padding.  A padded
+    // position influences no real one -- its key is masked (modules.py:188-193), its outputs are re-zeroed (ADER.py:80) and its
+    // gradient is exactly zero -- so rows [0, tv0) are skipped: no LayerNorm, no epilogue, no activation store (the backward
+    // kernels skip the same rows and write their zero gradients).  Their tile rows keep stale but FINITE contents (the operand
+    // tiles are cleared once above), so they only ever produce finite garbage in rows nobody consumes.
+    int tv0;
+    {
+        const unsigned long long nz = __ballot(lane < T && sq_l[lane] != 0);
+        tv0 = nz ? (int)__ffsll((long long)nz) - 1 : T;
+    }
+    const bool skipw = mh == 0 && tv0 >= 32;          // this wave's 32 rows are all leading padding
 
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
@@ -116,7 +128,10 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
                 const int t = 40 * pass + 4 * wave + rsub;
-                if (t < TR) {
+                if (t < tv0) {                       // leading padding: only the masks exist (key mask 0)
+                    if (sub == 0) { km_l[t] = 0.0f; qm_l[t] = 0.0f; }
+                    bstore(okm, (sub == 0) ? (uint32_t)t * 4u : OOB, 0.0f);
+                } else if (t < TR) {
                     const bool valid = t < T;
                     float x[10], s = 0.0f;
 #pragma unroll
@@ -178,7 +193,8 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 put_split(Th, Th + TR * LDR, (rj_) * LDR, v);                                              \
                 bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
-            if (!pruned) {
+            if (skipw) {
+            } else if (!pruned) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) Q_EPI(acc[j], ROWJ(j));
             } else if (act && hh == hhT) {
@@ -195,11 +211,13 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             bf16* Th = R2 + t0 * LDR + n;
+            if (!skipw) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float v = (n < H) ? acc[j] + bias5[1] : 0.0f;
-                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
-                bstore(o, boff0 + ROWJ(j) * H4, v);
+                for (int j = 0; j < 16; ++j) {
+                    const float v = (n < H) ? acc[j] + bias5[1] : 0.0f;
+                    put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                    bstore(o, boff0 + ROWJ(j) * H4, v);
+                }
             }
         }
         // ---- V = x.Wv + bv (modules.py:174) -> memory, hi/lo -> R0 (in place)
@@ -211,11 +229,13 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             bf16* Th = R0 + t0 * LDR + n;
             lds_barrier();                                              // every wave has read its R0 rows
+            if (!skipw) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float v = (n < H && t0 + ROWJ(j) < T) ? acc[j] + bias5[2] : 0.0f;   // rows >= T: exact zeros (0 * V below)
-                put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
-                bstore(o, boff0 + ROWJ(j) * H4, v);
+                for (int j = 0; j < 16; ++j) {
+                    const float v = (n < H && t0 + ROWJ(j) < T) ? acc[j] + bias5[2] : 0.0f;   // rows >= T: exact zeros (0 * V below)
+                    put_split(Th, Th + TR * LDR, ROWJ(j) * LDR, v);
+                    bstore(o, boff0 + ROWJ(j) * H4, v);
+                }
             }
         }
         __syncthreads();        // full barrier: LN(x) rows written to memory by other waves are re-read after the attention
@@ -236,8 +256,8 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         bf16* Pl = R1 + TR * LDP;
         {
             PHASE_IDS;
-            const bool swave = wave < 4;
             const int mq = wave >> 1, kb = wave & 1;
+            const bool swave = wave < 4 && !(mq == 0 && tv0 >= 32);      // (queries 0..31 all leading padding: nobody reads their P rows)
             const int q = 32 * mq + r;
             const int key0 = 32 * kb + 4 * hh;           // key of register j: key0 + ROWJ(j)
             f32x16 S;
@@ -285,13 +305,13 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 sum += red_l[2 * TR + (kb ^ 1) * TR + q];
                 const float r_sum = 1.0f / sum;
                 const float qm = (q < T) ? qm_l[q] : 0.0f;                        // modules.py:208-211
-                const DropArgs da = drop_of(k.d_attn);
+                const SDrop da = sdrop_of(k.d_attn, (uint32_t)b * (uint32_t)T * (uint32_t)T);
                 // P^T [key][query] (pruned: the row of query T-1 only, [key])
                 const Out op = make_out(k.P, b, T, pruned ? 1 : T, false);
                 const uint32_t T4 = pruned ? 4u : (uint32_t)T * 4u;
                 uint32_t poff0 = pruned ? ((q == T - 1) ? 0u : OOB) : ((q < T) ? (uint32_t)q * 4u : OOB);
                 poff0 += (uint32_t)key0 * T4;
-                const uint32_t dbase = (uint32_t)b * (uint32_t)T * (uint32_t)T + (uint32_t)(q * T + key0);
+                const uint32_t dbase = (uint32_t)b * (uint32_t)T * (uint32_t)T + da.off + (uint32_t)(q * T + key0);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     bf16x4 h4, l4;
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                         const int j = 4 * jj + j2;
                         float p = S[j] * r_sum;
                         bstore(op, poff0 + (uint32_t)ROWJ(j) * T4, p);
-                        p = drop_apply(da, dbase + (uint32_t)ROWJ(j), p * qm);   // modules.py:214
+                        p = sdrop_apply(da, dbase + (uint32_t)ROWJ(j), p * qm);   // modules.py:214
                         p = (q < T && key0 + ROWJ(j) < T) ? p : 0.0f;
                         h4[j2] = (bf16)p;
                         l4[j2] = (bf16)(p - (float)h4[j2]);
@@ -337,7 +357,8 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             float* Xp = Xf + t0 * XS + n;
             // ---- x1 = O + LN(x) (modules.py:223); the K tile is dead since the first barrier of the phase: R2 is Xf again
-            if (!pruned) {
+            if (skipw) {
+            } else if (!pruned) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const float v = O[j] + qres[j];
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 const int t = 40 * pass + 4 * wave + rsub;
                 if (t < TR) {
                     const bool valid = t < T && (!pruned || t == T - 1);
-                    if (pruned && !valid) continue;     // (16-lane row groups diverge; nothing downstream reads these rows)
+                    if ((pruned && !valid) || t < tv0) continue;     // (16-lane row groups diverge; nothing downstream reads these rows)
                     float x[10], s = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 10; ++i) {
@@ -402,22 +423,21 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             PRUNE_IDS;
             f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
             load_bfrags((const bf16*)k.w[4], nb, r, hh, bh, bl);
-            const DropArgs d1 = drop_of(k.d_ffn1);
+            const SDrop d1 = sdrop_of(k.d_ffn1, didx_row0);
             const Out o = make_out(k.h1d, b, T, H, pruned);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
-            const uint32_t didx0 = didx_row0 + (uint32_t)(t0 * H + n);
+            const uint32_t didx0 = didx_row0 + d1.off + (uint32_t)(t0 * H + n);
             bf16* Th = R1 + t0 * LDR + n;
 #define F1_EPI(accv_, rj_)                                                                                 \
             {                                                                                              \
-                const int t = t0 + (rj_);                                                                  \
-                float v = fmaxf((accv_) + bias5[3], 0.0f);                                                 \
-                v = drop_apply(d1, didx0 + (rj_) * (uint32_t)H, v);                                        \
-                v = (n < H && t < T) ? v : 0.0f;                                                           \
+                /* columns >= H: zero weights and bias -> exactly 0; rows >= T: garbage nobody consumes */ \
+                const float v = sdrop_apply(d1, didx0 + (rj_) * (uint32_t)H, fmaxf((accv_) + bias5[3], 0.0f)); \
                 put_split(Th, Th + TR * LDR, (rj_) * LDR, v);                                              \
                 bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
-            if (!pruned) {
+            if (skipw) {
+            } else if (!pruned) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) F1_EPI(acc[j], ROWJ(j));
             } else if (act && hh == hhT) {
@@ -432,22 +452,23 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             PRUNE_IDS;
             f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
             if (l + 1 < a.L) load_bfrags((const bf16*)kp[1].w[0], nb, r, hh, bh, bl);
-            const DropArgs d2 = drop_of(k.d_ffn2);
+            const SDrop d2 = sdrop_of(k.d_ffn2, didx_row0);
             const Out o = make_out(k.x2, b, T, H, pruned);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
-            const uint32_t didx0 = didx_row0 + (uint32_t)(t0 * H + n);
+            const uint32_t didx0 = didx_row0 + d2.off + (uint32_t)(t0 * H + n);
             float* Xp = Xf + t0 * XS + n;
 #define F2_EPI(accv_, rj_)                                                                                 \
             {                                                                                              \
                 const int t = t0 + (rj_);                                                                  \
-                float v = drop_apply(d2, didx0 + (rj_) * (uint32_t)H, (accv_) + bias5[4]);                 \
+                float v = sdrop_apply(d2, didx0 + (rj_) * (uint32_t)H, (accv_) + bias5[4]);                \
                 const float yv = (n < XS) ? Xp[(rj_) * XS] : 0.0f;                                         \
                 v = (sq_l[t] != 0) ? v + yv : 0.0f;                                                        \
                 if (n < XS) Xp[(rj_) * XS] = v;                                                            \
                 bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
-            if (!pruned) {
+            if (skipw) {
+            } else if (!pruned) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) F2_EPI(acc[j], ROWJ(j));
             } else if (act && hh == hhT) {

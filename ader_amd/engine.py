@@ -353,10 +353,14 @@ class Engine:
         self.refresh_shadow()
 
     # ---------------------------------------------------------------------------------------- workspaces
-    def buf(self, name, shape, dtype=torch.float32):
+    def buf(self, name, shape, dtype=torch.float32, zero=False):
+        """Persistent workspace tensor.  zero=True clears it when it is (re)allocated: the session kernels skip a session's leading
+        padding rows, whose activation / gradient rows then keep whatever the buffer held -- stale values are harmless (every use
+        multiplies them by an exact zero), the NaN bit patterns of fresh memory are not.  (The clear is a torch fill on torch's
+        current stream: only for buffers first touched on the main stream -- the launchers' side streams are not torch's.)"""
         t = self._ws.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self._ws[name] = t
         return t
 
@@ -582,7 +586,7 @@ class Engine:
         d = _lib.AderSeqFwd()
         d0 = self._drop(step, SITE_EMB, rate, training, per_row)
         A["d_emb"] = d0
-        x = self.buf(tag + "x0", (rows, H))
+        x = self.buf(tag + "x0", (rows, H), zero=True)
         rep = self.buf(tag + "rep", (B, H))
         meanf, stdf = self.buf(tag + "mf", (B,)), self.buf(tag + "sf", (B,))
         d.seq, d.emb, d.pos, d.x0, d.status = ptr(seq), pp["emb"], pp["pos"], ptr(x), ptr(self.status)
@@ -599,14 +603,14 @@ class Engine:
             d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
             d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
             M, sfx = (B, "L") if pruned else (rows, "")
-            kmask = self.buf(n("km"), (rows,))
-            K, Vv = self.buf(n("K"), (rows, H)), self.buf(n("V"), (rows, H))
-            q_in = self.buf(n("qin" + sfx), (M, H))
-            mean1, std1, qmask = self.buf(n("m1" + sfx), (M,)), self.buf(n("s1" + sfx), (M,)), self.buf(n("qm" + sfx), (M,))
-            Q, x1, y = self.buf(n("Q" + sfx), (M, H)), self.buf(n("x1" + sfx), (M, H)), self.buf(n("y" + sfx), (M, H))
-            Pm = self.buf(n("P" + sfx), (B * self.heads * T * (1 if pruned else T),))
-            mean2, std2 = self.buf(n("m2" + sfx), (M,)), self.buf(n("s2" + sfx), (M,))
-            h1d, x2 = self.buf(n("h1" + sfx), (M, H)), self.buf(n("x2" + sfx), (M, H))
+            kmask = self.buf(n("km"), (rows,), zero=True)
+            K, Vv = self.buf(n("K"), (rows, H), zero=True), self.buf(n("V"), (rows, H), zero=True)
+            q_in = self.buf(n("qin" + sfx), (M, H), zero=True)
+            mean1, std1, qmask = self.buf(n("m1" + sfx), (M,), zero=True), self.buf(n("s1" + sfx), (M,), zero=True), self.buf(n("qm" + sfx), (M,), zero=True)
+            Q, x1, y = self.buf(n("Q" + sfx), (M, H), zero=True), self.buf(n("x1" + sfx), (M, H), zero=True), self.buf(n("y" + sfx), (M, H), zero=True)
+            Pm = self.buf(n("P" + sfx), (B * self.heads * T * (1 if pruned else T),), zero=True)
+            mean2, std2 = self.buf(n("m2" + sfx), (M,), zero=True), self.buf(n("s2" + sfx), (M,), zero=True)
+            h1d, x2 = self.buf(n("h1" + sfx), (M, H), zero=True), self.buf(n("x2" + sfx), (M, H), zero=True)
             k = d.blk[l]
             for i, w in enumerate(("wq", "wk", "wv", "w1", "w2")):
                 k.w[i] = self.wbf.data_ptr() + self._widx[p + w] * self._wplane
@@ -860,8 +864,8 @@ class Engine:
         wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))
         pp, gp = self._pp, self._gp
         xL = A["xL"]
-        dx = self.buf("dx_a", (rows, H))
-        dxn = self.buf("dx_b", (rows, H))
+        dx = self.buf("dx_a", (rows, H), zero=True)
+        dxn = self.buf("dx_b", (rows, H), zero=True)
         if self.prune_last:
             dxl = self.buf("dx_L", (B, H))        # gradient of the final block's output row T-1 (compact)
             call("ader_ln_bwd", ptr(drep), H, ptr(xL), H, pp["lnf_g"], ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dxl), H,
@@ -958,9 +962,9 @@ class Engine:
         pp, gp = self._pp, self._gp
         pruned = 1 if S["pruned"] else 0
         wp = lambda w: self.wbf.data_ptr() + self._widx[p + w] * self._wplane     # noqa: E731
-        dh2, da_ = self.buf("bw_dh2%d" % l, (M, H)), self.buf("bw_da%d" % l, (M, H))
-        dx1, dQ = self.buf("bw_dx1%d" % l, (M, H)), self.buf("bw_dQ%d" % l, (M, H))
-        dK, dV = self.buf("bw_dK%d" % l, (rows, H)), self.buf("bw_dV%d" % l, (rows, H))
+        dh2, da_ = self.buf("bw_dh2%d" % l, (M, H), zero=True), self.buf("bw_da%d" % l, (M, H), zero=True)
+        dx1, dQ = self.buf("bw_dx1%d" % l, (M, H), zero=True), self.buf("bw_dQ%d" % l, (M, H), zero=True)
+        dK, dV = self.buf("bw_dK%d" % l, (rows, H), zero=True), self.buf("bw_dV%d" % l, (rows, H), zero=True)
         slab2, slab1 = self.buf("ln_slab%d_2" % l, (B * 2 * H,)), self.buf("ln_slab%d_1" % l, (B * 2 * H,))
         f = _lib.AderSeqBwdFfn()
         f.seq, f.dx2, f.h1d, f.x1, f.mean2, f.std2 = ptr(seq), ptr(dxo), ptr(S["h1d"]), ptr(S["x1"]), ptr(S["mean2"]), ptr(S["std2"])

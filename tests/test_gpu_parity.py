@@ -366,8 +366,26 @@ def test_one_launch_forward_equals_per_op_forward(shape, prune):
                     d["%d.%s" % (l, k2)] = v.cpu().numpy().copy()
         acts.append(d)
     assert acts[0].keys() == acts[1].keys()
+    # Leading padding rows: the one-launch kernel skips them (their keys are masked, their outputs re-zeroed, their gradient is
+    # exactly zero: nothing consumes what the per-op chain computes there), so their saved rows are unspecified -- compared from the
+    # first real position on.  Compact tensors of a pruned block hold row T-1 (padding only in the all-padding session).
+    tv0 = np.array([int(np.argmax(r != 0)) if (r != 0).any() else T for r in seq])
+    padrow = (np.arange(T)[None, :] < tv0[:, None])                      # [B, T]
+
+    def drop_pad(x, k2):
+        x = x.copy()
+        if k2.endswith(".P") and x.size == B * T * T:                   # P^T [b][key][query]: padding QUERIES
+            x.reshape(B, T, T)[np.broadcast_to(padrow[:, None, :], (B, T, T))] = 0
+        elif x.shape[0] == B * T:
+            x.reshape(B, T, -1)[padrow] = 0
+        elif x.shape[0] == B and k2 not in ("rep", "meanf", "stdf"):
+            x.reshape(B, -1)[tv0 == T] = 0
+        elif k2.endswith(".P") and x.size == B * T:                     # pruned: the row of query T-1
+            x.reshape(B, T)[tv0 == T] = 0
+        return x
+
     for k2 in acts[0]:
-        a, b = acts[0][k2], acts[1][k2]
+        a, b = drop_pad(acts[0][k2], k2), drop_pad(acts[1][k2], k2)
         assert a.shape == b.shape, k2
         if k2.endswith("mask"):
             assert np.array_equal(a, b), k2
@@ -409,6 +427,43 @@ def test_session_tiled_step_equals_per_op_step(shape, prune):
         # differences: fp32 summation order, ReLU branch flips of ~zero pre-activations (cf. the x3 oracle test: 6e-4).
         # The key bias has an exactly-zero true gradient (softmax is shift invariant): both paths hold ~1e-8 rounding noise
         fl = 1e-3 if k.endswith(".bk") else 1e-4
+        assert nerr(out[0][1][k], out[1][1][k], floor=fl) < 6e-4, (k, nerr(out[0][1][k], out[1][1][k], floor=fl))
+
+
+def test_stale_rows_of_skipped_padding_are_harmless():
+    """The session-tiled kernels skip a session's leading padding rows (forward: nothing stored; backward: zero gradient rows written).
+    What the activation buffers hold there is stale -- here: the rows of a previous step whose sessions were LONGER, scaled up to
+    1e3 to make any leak visible.  Loss and every gradient of the second step must equal the per-op chain's, which computes every
+    row."""
+    item_num, T, H, L, B, N = 700, 50, 150, 2, 70, 650
+    rs = np.random.RandomState(12)
+    long_seq = _seqs(rs, B, T, N, full=True)
+    short_seq = np.zeros_like(long_seq)
+    for b in range(B):
+        ln = 1 + b % 19                               # 1 .. 19 items: some sessions reach into rows < 32, most do not
+        short_seq[b, T - ln:] = rs.randint(1, N + 1, size=ln)
+    pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+    out = []
+    for fused in (True, False):
+        eng = _engine(item_num, T, H, L, 1, seed=9)
+        eng.seq_fused = fused
+        eng.global_step = 3
+        eng.loss_and_grad(long_seq, pos, N, rate=0.3)
+        torch.cuda.synchronize()
+        if fused:                                     # blow up what step 1 left in the saved-activation buffers
+            for name, t in eng._ws.items():
+                if t.dtype == torch.float32 and name[:1] == "t" and t.dim() == 2:
+                    t.mul_(1e3)
+        eng.global_step = 4
+        loss = eng.loss_and_grad(short_seq, pos, N, rate=0.3)
+        torch.cuda.synchronize()
+        out.append((float(loss.item()), {k: eng.gradient(k).cpu().numpy().copy() for k in eng.layout},
+                    eng._last_g.cpu().numpy().copy()))
+    assert np.isfinite(out[0][0]) and abs(out[0][0] - out[1][0]) < 2e-5 * max(1.0, abs(out[1][0]))
+    assert nerr(out[0][2], out[1][2], floor=1e-6) < 2e-3
+    for k in out[0][1]:
+        fl = 1e-3 if k.endswith(".bk") else 1e-4
+        assert np.isfinite(out[0][1][k]).all(), k
         assert nerr(out[0][1][k], out[1][1][k], floor=fl) < 6e-4, (k, nerr(out[0][1][k], out[1][1][k], floor=fl))
 
 
