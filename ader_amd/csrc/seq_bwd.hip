@@ -176,7 +176,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
                     const int c = sub + 16 * i;
                     const float g = live ? v[i] : 0.0f;
                     Xf[t * XS + c] = g;
-                    const float dh = sdrop_apply(d2, didx_row0 + d2.off + (uint32_t)(t * H + c), g);
+                    const float dh = sdrop_apply1(d2, didx_row0 + d2.off + (uint32_t)(t * H + c), g);
                     put_split(Tp, Tp + TR * LDR, 16 * i, dh);
                     bstore(odh, (c < H) ? bo + 64u * i : OOB, dh);
                 }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
             for (int j = 0; j < 16; ++j) {
                 float v = Xp[ROWJ(j) * XS] + acc[j];
                 if (a.emb_bwd) {
-                    v = sdrop_apply(d0, didx0 + ROWJ(j) * (uint32_t)H, v);
+                    v = sdrop_apply1(d0, didx0 + ROWJ(j) * (uint32_t)H, v);
                     v = (sq_l[t0 + ROWJ(j)] != 0) ? v : 0.0f;
                 }
                 bstore(odx, boff0 + ROWJ(j) * H4, v);

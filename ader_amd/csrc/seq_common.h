@@ -61,9 +61,15 @@ template <class D> __device__ __forceinline__ SDrop sdrop_of(const D& d, uint32_
     o.off = (first_idx >= d.split) ? d.base2 : d.base;
     return o;
 }
-// idx_off = local element index + SDrop.off
-__device__ __forceinline__ float sdrop_apply(const SDrop& d, uint32_t idx_off, float x) {
+// idx_off = local element index + SDrop.off.  ON is the workgroup-uniform "dropout enabled" decision, taken ONCE per phase by
+// the caller (two copies of the unrolled loop): evaluation, herding and finetune runs must not pay for the hash.
+template <bool ON> __device__ __forceinline__ float sdrop_apply(const SDrop& d, uint32_t idx_off, float x) {
+    if (!ON) return x;
     return ((lowbias32(idx_off ^ d.key) >> 8) >= d.thr) ? x * d.scale : 0.0f;
+}
+// single elements (not worth a second code path)
+__device__ __forceinline__ float sdrop_apply1(const SDrop& d, uint32_t idx_off, float x) {
+    return d.thr ? sdrop_apply<true>(d, idx_off, x) : x;
 }
 __device__ __forceinline__ void put_split(bf16* Th, bf16* Tl, int off, float v) {
     const bf16 h = (bf16)v;

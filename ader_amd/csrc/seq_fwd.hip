@@ -67,22 +67,23 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 pv[u][i] = ok ? a.pos[(size_t)t * H + c] : 0.0f;
             }
         }
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const int t = wave + 10 * u;
-            if (t < TR) {
-                if (lane == 0) sq_l[t] = ids[u];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int c = lane + 64 * i;
-                    float v = ev[u][i] * a.sqrtH + pv[u][i];
-                    v = sdrop_apply(d0, didx_row0 + d0.off + (uint32_t)(t * H + c), v);
-                    v = (ids[u] != 0 && t < T && c < H) ? v : 0.0f;
-                    if (c < XS) Xf[t * XS + c] = v;
-                    bstore(ox0, (c < H) ? (uint32_t)(t * H + c) * 4u : OOB, v);
-                }
-            }
+#define PRO_ROWS(DR_)                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < 7; ++u) {                                                    \
+            const int t = wave + 10 * u;                                                                   \
+            if (t < TR) {                                                                                  \
+                if (lane == 0) sq_l[t] = ids[u];                                                           \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                            \
+                    const int c = lane + 64 * i;                                                           \
+                    float v = ev[u][i] * a.sqrtH + pv[u][i];                                               \
+                    v = sdrop_apply<DR_>(d0, didx_row0 + d0.off + (uint32_t)(t * H + c), v);               \
+                    v = (ids[u] != 0 && t < T && c < H) ? v : 0.0f;                                        \
+                    if (c < XS) Xf[t * XS + c] = v;                                                        \
+                    bstore(ox0, (c < H) ? (uint32_t)(t * H + c) * 4u : OOB, v);                            \
+                }                                                                                          \
+            }                                                                                              \
         }
+        if (d0.thr) { PRO_ROWS(true) } else { PRO_ROWS(false) }
+#undef PRO_ROWS
     }
     {
         const int r = lane & 31, hh = lane >> 5;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                         const int j = 4 * jj + j2;
                         float p = S[j] * r_sum;
                         bstore(op, poff0 + (uint32_t)ROWJ(j) * T4, p);
-                        p = sdrop_apply(da, dbase + (uint32_t)ROWJ(j), p * qm);   // modules.py:214
+                        p = sdrop_apply1(da, dbase + (uint32_t)ROWJ(j), p * qm);  // modules.py:214
                         p = (q < T && key0 + ROWJ(j) < T) ? p : 0.0f;
                         h4[j2] = (bf16)p;
                         l4[j2] = (bf16)(p - (float)h4[j2]);
@@ -429,19 +430,24 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             const uint32_t didx0 = didx_row0 + d1.off + (uint32_t)(t0 * H + n);
             bf16* Th = R1 + t0 * LDR + n;
-#define F1_EPI(accv_, rj_)                                                                                 \
+#define F1_EPI(accv_, rj_, DR_)                                                                               \
             {                                                                                              \
                 /* columns >= H: zero weights and bias -> exactly 0; rows >= T: garbage nobody consumes */ \
-                const float v = sdrop_apply(d1, didx0 + (rj_) * (uint32_t)H, fmaxf((accv_) + bias5[3], 0.0f)); \
+                const float v = DR_(d1, didx0 + (rj_) * (uint32_t)H, fmaxf((accv_) + bias5[3], 0.0f));     \
                 put_split(Th, Th + TR * LDR, (rj_) * LDR, v);                                              \
                 bstore(o, boff0 + (rj_) * H4, v);                                                          \
             }
             if (skipw) {
             } else if (!pruned) {
+                if (d1.thr) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) F1_EPI(acc[j], ROWJ(j));
+                    for (int j = 0; j < 16; ++j) F1_EPI(acc[j], ROWJ(j), sdrop_apply<true>);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) F1_EPI(acc[j], ROWJ(j), sdrop_apply<false>);
+                }
             } else if (act && hh == hhT) {
-                F1_EPI(pick16(acc, jT), rjT);
+                F1_EPI(pick16(acc, jT), rjT, sdrop_apply1);
             }
 #undef F1_EPI
         }
@@ -458,10 +464,10 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             const uint32_t didx0 = didx_row0 + d2.off + (uint32_t)(t0 * H + n);
             float* Xp = Xf + t0 * XS + n;
-#define F2_EPI(accv_, rj_)                                                                                 \
+#define F2_EPI(accv_, rj_, DR_)                                                                               \
             {                                                                                              \
                 const int t = t0 + (rj_);                                                                  \
-                float v = sdrop_apply(d2, didx0 + (rj_) * (uint32_t)H, (accv_) + bias5[4]);                \
+                float v = DR_(d2, didx0 + (rj_) * (uint32_t)H, (accv_) + bias5[4]);                        \
                 const float yv = (n < XS) ? Xp[(rj_) * XS] : 0.0f;                                         \
                 v = (sq_l[t] != 0) ? v + yv : 0.0f;                                                        \
                 if (n < XS) Xp[(rj_) * XS] = v;                                                            \
@@ -469,10 +475,15 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             }
             if (skipw) {
             } else if (!pruned) {
+                if (d2.thr) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) F2_EPI(acc[j], ROWJ(j));
+                    for (int j = 0; j < 16; ++j) F2_EPI(acc[j], ROWJ(j), sdrop_apply<true>);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) F2_EPI(acc[j], ROWJ(j), sdrop_apply<false>);
+                }
             } else if (act && hh == hhT) {
-                F2_EPI(pick16(acc, jT), rjT);
+                F2_EPI(pick16(acc, jT), rjT, sdrop_apply1);
             }
 #undef F2_EPI
         }
