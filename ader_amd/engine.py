@@ -219,6 +219,7 @@ class Engine:
         self.split_rows, self.row0_ex = None, 0     # ... and of the first local exemplar row (set per step under data parallelism)
         self._grad_hi = 0
         self._ws = {}
+        self._ws_store = {}
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
         # data-parallel dense path: called right after the logits backward has written the table gradient's dense term (99.8 % of
         # the gradient bytes) so that its all-reduce runs UNDER the blocks backward; returns the pending collectives
@@ -359,9 +360,19 @@ class Engine:
         multiplies them by an exact zero), the NaN bit patterns of fresh memory are not.  (The clear is a torch fill on torch's
         current stream: only for buffers first touched on the main stream -- the launchers' side streams are not torch's.)"""
         t = self._ws.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self._ws[name] = t
+        if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype:
+            return t
+        # a new shape: a view of the name's backing store, which only ever grows (batches whose row count alternates -- the
+        # exemplar sampler's ragged batches -- must not reallocate, let alone refill, ~40 buffers per step)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        flat = self._ws_store.get(name)
+        if flat is None or flat.dtype != dtype or flat.numel() < n:
+            flat = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=dtype, device=self.device)
+            self._ws_store[name] = flat
+        t = flat[:n].view(shape)
+        self._ws[name] = t
         return t
 
     def _stream(self):
