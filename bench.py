@@ -171,7 +171,7 @@ def main():
         torch.cuda.synchronize()
 
     # Per-section HIP events (on the launch stream) cost stream time: the full breakdown is taken on the last warmup steps,
-    # and the timed region records only the dominant section (every 4th step), whose duration feeds the roofline line.
+    # and the timed region records only the dominant section (every 8th step), whose duration feeds the roofline line.
     sections_all = {}
     for i in range(5):        # engine initialisation (workspace allocation, kernel attributes, side streams): never timed
         seq, pos = batches[i % nbatch]
@@ -188,8 +188,8 @@ def main():
         skip = ("grad_exchange", "param_allgather")
         dom_names = [k for k in sections_all if k not in skip]
         # (a timing event pair around the kernel breaks its overlap with the side stream and costs ~60 us of the step: the
-        #  dominant kernel is therefore timed on every 4th step of the timed region)
-        eng.timer = SectionTimer(only={max(dom_names, key=lambda k: sections_all[k])} if dom_names else None, every=4)
+        #  dominant kernel is therefore timed on every 8th step of the timed region)
+        eng.timer = SectionTimer(only={max(dom_names, key=lambda k: sections_all[k])} if dom_names else None, every=8)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -240,7 +240,7 @@ def main():
         for i in range(5 + args.warmup):
             seq, pos = batches[i % nbatch]
             eng3.train_step(seq, pos, N, lr, **kw)
-        eng3.timer = SectionTimer(only={"logits_bwd_adam", "logits_fwd"}, every=4)
+        eng3.timer = SectionTimer(only={"logits_bwd_adam", "logits_fwd"}, every=8)
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
