@@ -181,7 +181,7 @@ __device__ __forceinline__ Out make_out(const void* base, int b, int T, int row_
     return o;
 }
 __device__ __forceinline__ void bstore(const Out& o, uint32_t boff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), o.r, (int)(boff - o.sub), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), o.r, (int)(boff - o.sub), 0, 2);
 }
 __device__ __forceinline__ float bload(const Out& o, uint32_t boff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o.r, (int)(boff - o.sub), 0, 0));
