@@ -7,6 +7,7 @@ the saved activations, and issues the HIP launchers of include/ader_hip.h on tor
 
 Nothing here computes on the CPU: without libader_hip.so / a GPU the constructor raises.
 """
+import collections
 import ctypes
 import math
 import os
@@ -360,18 +361,21 @@ class Engine:
         multiplies them by an exact zero), the NaN bit patterns of fresh memory are not.  (The clear is a torch fill on torch's
         current stream: only for buffers first touched on the main stream -- the launchers' side streams are not torch's.)"""
         t = self._ws.get(name)
-        if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype:
+        key = (tuple(int(d) for d in shape), dtype)
+        if t is not None and tuple(t.shape) == key[0] and t.dtype == dtype:
             return t
-        # a new shape: a view of the name's backing store, which only ever grows (batches whose row count alternates -- the
-        # exemplar sampler's ragged batches -- must not reallocate, let alone refill, ~40 buffers per step)
-        n = 1
-        for d in shape:
-            n *= int(d)
-        flat = self._ws_store.get(name)
-        if flat is None or flat.dtype != dtype or flat.numel() < n:
-            flat = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=dtype, device=self.device)
-            self._ws_store[name] = flat
-        t = flat[:n].view(shape)
+        # A name keeps one tensor PER SHAPE (the few most recent): batches whose row count alternates -- the exemplar sampler's
+        # ragged batches -- must not reallocate, let alone refill, ~40 buffers per step; and two shapes of one name that are live in
+        # the same step (local and global batch of the data-parallel schemes) must not share memory.
+        per = self._ws_store.setdefault(name, collections.OrderedDict())
+        t = per.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(key[0], dtype=dtype, device=self.device)
+            per[key] = t
+            while len(per) > 4:
+                per.popitem(last=False)
+        else:
+            per.move_to_end(key)
         self._ws[name] = t
         return t
 
@@ -1054,6 +1058,10 @@ class Engine:
 
     def _lists_async(self, seq, lab, N):
         main = self._main
+        # flat, contiguous int32 copies are made HERE, by torch on the main stream and before the side stream is told to wait for it:
+        # a strided view (the catalog-sharded step passes ids_g[:, :n_pos]) would otherwise be materialised inside _sparse_lists --
+        # a torch kernel on the main stream that the list kernels on the side stream do not wait for
+        seq, lab = seq.reshape(-1).to(torch.int32).contiguous(), lab.reshape(-1).to(torch.int32).contiguous()
         if not self.lists_side_stream:
             self._lists = self._sparse_lists(seq, lab, N)
             return

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ITEMS, T, H, L, HEADS, N, B = 900, 50, 150, 2, 1, 830, 96
 
 
-def _data():
+def _data(B=B):
     rs = np.random.RandomState(5)
     seq = np.zeros((B, T), dtype=np.int32)
     for b in range(B):
@@ -39,11 +39,11 @@ def _engine(logits, rank=0, world=1):
     return eng
 
 
-def _worker(rank, world, port, out, logits, sharded):
+def _worker(rank, world, port, out, logits, sharded, B=B):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ader_amd import dist as adist
-    seq, pos = _data()
+    seq, pos = _data(B)
     eng = _engine(logits, rank, world)
     eng.dp_sharded = bool(sharded)
     dp = adist.DataParallel(eng, rank, world)
@@ -62,18 +62,20 @@ def _worker(rank, world, port, out, logits, sharded):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("logits,sharded", [("f32", False), ("bf16", False), ("bf16", True), ("bf16", "catalog"),
-                                            ("bf16", "catalog_packed")])
-def test_two_ranks_match_single_process(logits, sharded):
+@pytest.mark.parametrize("logits,sharded,B", [("f32", False, B), ("bf16", False, B), ("bf16", True, B), ("bf16", "catalog", B),
+                                              ("bf16", "catalog_packed", B), ("bf16", True, 1400), ("bf16", "catalog", 1400)])
+def test_two_ranks_match_single_process(logits, sharded, B):
+    # (B = 1400: a GLOBAL batch beyond 1024 rows -- the row-sharded update and the catalog-sharded forward run on all 1408 padded
+    #  rows of both ranks, as the 8-GPU configuration does with 4096)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "theta.pt")
-        mp.spawn(_worker, args=(2, port, out, logits, sharded), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, out, logits, sharded, B), nprocs=2, join=True)
         got = torch.load(out).numpy()
-    seq, pos = _data()
+    seq, pos = _data(B)
     eng = _engine(logits)
     eng.fuse_adam = False
     for step in range(2):
