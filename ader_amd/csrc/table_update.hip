@@ -325,14 +325,19 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
 #pragma unroll
                 for (int u = 0; u < SPB; ++u) {
                     const int ic = (i + u) < 8 ? (i + u) : 7;
-                    const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];
+                    const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];     // the first 8 entries: from the LDS record
                     const bool in = k + u < k1s;
-                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : f.sp_ids[k + u]);
-                    rw[u] = !in ? 0 : ((i + u < 8) ? row_c : f.sp_rows[k + u]);
+                    int id_g = 0, row_g = 0;
+                    if (i + SPB > 8) {                           // (batch-uniform) later entries: from the global lists,
+                        const int ke = in ? k + u : k0s;         //  UNCONDITIONAL loads of an always-valid entry
+                        id_g = f.sp_ids[ke]; row_g = f.sp_rows[ke];
+                    }
+                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : id_g);
+                    rw[u] = !in ? 0 : ((i + u < 8) ? row_c : row_g);
                 }
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)      // (ids beyond max_item have no table row)
-                    val[u] = (idv[u] < id_hi) ? f.sp_src[(size_t)rw[u] * H + tid] * f.sp_scale : 0.0f;
+                    val[u] = f.sp_src[(size_t)rw[u] * H + tid] * ((idv[u] < id_hi) ? f.sp_scale : 0.0f);
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)
                     if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] += val[u];
@@ -345,18 +350,21 @@ __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
                     const int ic = (i + u) < 8 ? (i + u) : 7;
                     const int id_c = mg[2 + 2 * ic], b_c = mg[3 + 2 * ic];
                     const bool in = k + u < k1;
-                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : f.tg_ids[k + u]);
-                    bw[u] = !in ? 0 : ((i + u < 8) ? b_c : f.tg_rows[k + u]);
+                    int id_g = 0, b_g = 0;
+                    if (i + SPB > 8) {
+                        const int ke = in ? k + u : mg[0];
+                        id_g = f.tg_ids[ke]; b_g = f.tg_rows[ke];
+                    }
+                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : id_g);
+                    bw[u] = !in ? 0 : ((i + u < 8) ? b_c : b_g);
                 }
 #pragma unroll
                 for (int u = 0; u < SPB; ++u) {
-                    float rv = 0.0f;
-                    if (idv[u] < id_hi) {
-                        rv = (float)a.rep_hi[(size_t)bw[u] * LDR + tid];
-                        if (X3) rv += (float)a.rep_lo[(size_t)bw[u] * LDR + tid];
-                        rv *= f.wrow[bw[u]];
-                    }
-                    val[u] = rv;
+                    // (unconditional loads -- row 0 for entries that do not count: a load under a per-entry branch is waited for
+                    //  at the branch's end, one memory round trip per ENTRY instead of per batch)
+                    float rv = (float)a.rep_hi[(size_t)bw[u] * LDR + tid];
+                    if (X3) rv += (float)a.rep_lo[(size_t)bw[u] * LDR + tid];
+                    val[u] = rv * f.wrow[bw[u]] * ((idv[u] < id_hi) ? 1.0f : 0.0f);
                 }
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)

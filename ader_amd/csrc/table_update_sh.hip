@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
                             const bool in_ = e0_ + u < n_;                                                 \
                             idv[u] = in_ ? hv_l[e0_ + u] : 0x7fffffff;                                     \
                             const int rw = in_ ? hv_l[256 + e0_ + u] : 0;                                  \
-                            val[u] = (idv[u] < id_hi) ? (VAL_) : 0.0f;                                     \
+                            val[u] = (VAL_) * ((idv[u] < id_hi) ? 1.0f : 0.0f);                            \
                         }                                                                                  \
                         _Pragma("unroll") for (int u = 0; u < HVB; ++u)                                    \
                             if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] OP_ val[u];                \
@@ -293,21 +293,27 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
             // entries SPV..7 of the bucket are in the LDS record, the rest in the global lists.  Batches of SPB entries: ids and
             // rows first, then every gradient row, then the adds in entry order (the order fixes the rounding) -- a hot item's
             // bucket holds hundreds of entries, and one dependent memory round trip per ENTRY made its workgroup the straggler of
-            // the launch (Zipf ids: 1.02 ms against 0.84 ms for uniform ids)
+            // the launch (Zipf ids: 1.02 ms against 0.84 ms for uniform ids).  The loads are UNCONDITIONAL (row 0 for entries that do
+            // not count): under a per-entry branch hipcc waits for each load at the end of its branch -- one round trip per entry
             for (int k = k0s + SPV, i = SPV; k < k1s; k += SPB, i += SPB) {
                 int idv[SPB], rw[SPB];
                 float val[SPB];
 #pragma unroll
                 for (int u = 0; u < SPB; ++u) {
                     const int ic = (i + u) < 8 ? (i + u) : 7;
-                    const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];
+                    const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];     // the first 8 entries: from the LDS record
                     const bool in = k + u < k1s;
-                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : f.sp_ids[k + u]);
-                    rw[u] = !in ? 0 : ((i + u < 8) ? row_c : f.sp_rows[k + u]);
+                    int id_g = 0, row_g = 0;
+                    if (i + SPB > 8) {                           // (batch-uniform) later entries: from the global lists,
+                        const int ke = in ? k + u : k0s;         //  UNCONDITIONAL loads of an always-valid entry
+                        id_g = f.sp_ids[ke]; row_g = f.sp_rows[ke];
+                    }
+                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : id_g);
+                    rw[u] = !in ? 0 : ((i + u < 8) ? row_c : row_g);
                 }
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)      // (ids beyond max_item have no table row)
-                    val[u] = (idv[u] < id_hi) ? f.sp_src[(size_t)rw[u] * H + tid] * f.sp_scale : 0.0f;
+                    val[u] = f.sp_src[(size_t)rw[u] * H + tid] * ((idv[u] < id_hi) ? f.sp_scale : 0.0f);
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)
                     if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] += val[u];
@@ -320,12 +326,17 @@ __global__ __launch_bounds__(256, 3) void k_tab16(ShArgs a, FuseArgs128 f) {
                     const int ic = (i + u) < 8 ? (i + u) : 7;
                     const int id_c = mg[2 + 2 * ic], b_c = mg[3 + 2 * ic];
                     const bool in = k + u < k1;
-                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : f.tg_ids[k + u]);
-                    bw[u] = !in ? 0 : ((i + u < 8) ? b_c : f.tg_rows[k + u]);
+                    int id_g = 0, b_g = 0;
+                    if (i + SPB > 8) {
+                        const int ke = in ? k + u : mg[0];
+                        id_g = f.tg_ids[ke]; b_g = f.tg_rows[ke];
+                    }
+                    idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : id_g);
+                    bw[u] = !in ? 0 : ((i + u < 8) ? b_c : b_g);
                 }
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)
-                    val[u] = (idv[u] < id_hi) ? f.wrow[bw[u]] * (float)a.rep_bf[(size_t)bw[u] * LDR + tid] : 0.0f;
+                    val[u] = f.wrow[bw[u]] * (float)a.rep_bf[(size_t)bw[u] * LDR + tid] * ((idv[u] < id_hi) ? 1.0f : 0.0f);
 #pragma unroll
                 for (int u = 0; u < SPB; ++u)
                     if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] -= val[u];

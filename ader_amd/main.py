@@ -105,6 +105,11 @@ def run(args, log=print):
     dev_index = (local % max(torch.cuda.device_count(), 1)) if world > 1 else args.device_num
     model = (Ewc if args.ewc else Ader)(item_num, args, device="cuda:%d" % dev_index, dp_rank=rank, dp_world=world)   # main.py:144
     dp = adist.DataParallel(model.engine, rank, world)
+    # the cyclic collector walks everything torch imported (~40 ms per full pass, tens of times per period once the loop below
+    # churns Python lists): freeze what exists now, so later passes see only the loop's own objects
+    import gc
+    gc.collect()
+    gc.freeze()
     baseline = args.finetune or args.dropout or args.joint
     dataloader = DataLoader(args.dataset, root=args.data_root)
     n_periods = dataloader.num_periods() - 1

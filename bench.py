@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -190,6 +191,11 @@ def main():
         # (a timing event pair around the kernel breaks its overlap with the side stream and costs ~60 us of the step: the
         #  dominant kernel is therefore timed on every 8th step of the timed region)
         eng.timer = SectionTimer(only={max(dom_names, key=lambda k: sections_all[k])} if dom_names else None, every=8)
+    # The interpreter's cyclic collector walks every object torch has imported (~40 ms per full pass): a pass that lands in the
+    # timed region is host noise of the same size as the region.  Collect now and freeze what exists (the steps themselves create
+    # no cycles); a training loop does the same once at start-up (ader_amd/main.py).
+    gc.collect()
+    gc.freeze()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -241,6 +247,8 @@ def main():
             seq, pos = batches[i % nbatch]
             eng3.train_step(seq, pos, N, lr, **kw)
         eng3.timer = SectionTimer(only={"logits_bwd_adam", "logits_fwd"}, every=8)
+        gc.collect()
+        gc.freeze()
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
