@@ -294,6 +294,15 @@ __global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
     const size_t pbase = ((size_t)b * a.heads + head) * T;
     f32x16 Pv[2];
     float dot = 0.0f;
+    // the 32 saved probabilities of this lane: UNCONDITIONAL loads (element 0 of the block where the entry does not exist) issued
+    // together -- a load under the per-element branch below was waited for inside it: 32 serial memory round trips per wave
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int key = 32 * kb + acc_row(j, hh);
+            Pv[kb][j] = a.PT[(key < T && q < T) ? (pbase + key) * T + q : pbase * T];
+        }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
             const int key = 32 * kb + acc_row(j, hh);
             float p = 0.0f, dp = 0.0f, pd = 0.0f;
             if (key < T && q < T) {
-                p = a.PT[(pbase + key) * T + q];
+                p = Pv[kb][j];
                 float f = qm;
                 if (a.drop.thr != 0) f = drop_keep(a.drop, (uint32_t)((pbase + q) * T + key)) ? f * a.drop.scale : 0.0f;
                 dp = X[kb][j] * f;
