@@ -57,3 +57,18 @@ struct FuseArgs {
     float lr_t, omb1, omb2, eps;
     const float* extra1;        // EXTRA: dense gradient rows to add (row of item 1; [.,H] fp32), e.g. distilled rows' term
 };
+
+// arguments of the 64-row table-update kernels (table_update.hip: k_tab_upd, table_update_x3.hip: k_tab16x3)
+struct TabArgs {
+    const float* emb1;      // fp32 table, row of item 1: GEMM operand source (and the parameters, FuseArgs.emb1 == this)
+    int vrows;              // table rows that exist from emb1 on (item_num)
+    const bf16* rep_hi;     // [Bp][LDR] bf16(rep), zero padded
+    const bf16* rep_lo;     // [Bp][LDR] bf16(rep - hi)   (X3)
+    const float* off;       // [Bp] log2(w_b) - lse2_b; -inf for rows without a loss term
+    int Bp, H, N, tile_off;
+    float* demb1;           // !ADAM: gradient row of item 1
+    // KD rows (ADER.py:132-137): batch rows [kd_row0, Bp) are distilled exemplar rows: dlogit = w (softmax(s[:Np]) - softmax(t)),
+    // zero for items >= Np.  kd_row0 % 128 == 0; = Bp: none.  trow / tlse2: [Bp] as written by ader_lx3_fwd_kd.
+    int kd_row0, Np;
+    const float* teacher; long ldt; const int* trow; const float* tlse2;
+};

@@ -39,19 +39,6 @@
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-struct TabArgs {
-    const float* emb1;      // fp32 table, row of item 1: GEMM operand source (and the parameters, FuseArgs.emb1 == this)
-    int vrows;              // table rows that exist from emb1 on (item_num)
-    const bf16* rep_hi;     // [Bp][LDR] bf16(rep), zero padded
-    const bf16* rep_lo;     // [Bp][LDR] bf16(rep - hi)   (X3)
-    const float* off;       // [Bp] log2(w_b) - lse2_b; -inf for rows without a loss term
-    int Bp, H, N, tile_off;
-    float* demb1;           // !ADAM: gradient row of item 1
-    // KD rows (ADER.py:132-137): batch rows [kd_row0, Bp) are distilled exemplar rows: dlogit = w (softmax(s[:Np]) - softmax(t)),
-    // zero for items >= Np.  kd_row0 % 128 == 0; = Bp: none.  trow / tlse2: [Bp] as written by ader_lx3_fwd_kd.
-    int kd_row0, Np;
-    const float* teacher; long ldt; const int* trow; const float* tlse2;
-};
 
 template <bool X3, bool ADAM, bool EXTRA, bool KD = false>
 __global__ __launch_bounds__(256, 2) void k_tab_upd(TabArgs a, FuseArgs f) {
@@ -498,6 +485,15 @@ static int tab_launch(const TabArgs& a, const FuseArgs& fa, int tiles, size_t ld
     return 0;
 }
 
+// the x3 fused update of table_update_x3.hip (k_tab16x3: 16x16x32 tiles, three workgroups per CU, LDS-DMA rep pipeline)
+int tab16x3_launch(const TabArgs& a, const FuseArgs& fa, int tiles, bool extra, bool kd, void* stream);
+// ADER_X3_UPDATE=old selects the round-2 kernel (k_tab_upd<X3>) for A/B timing and kernel-vs-kernel tests
+static bool x3_update_old() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ADER_X3_UPDATE"); v = (e && e[0] == 'o') ? 1 : 0; }
+    return v == 1;
+}
+
 extern "C" {
 
 // Per-tile records of the id-sorted sparse lists for ader_tab_update: rec [ceil(N/64)][2][18] ints (ader_tab_meta_ints(N)).
@@ -601,7 +597,8 @@ int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int it
     const bool x3 = rep_lo != nullptr;
     const size_t lds = tab_lds(Bp, H, x3, true);
     int rc;
-    if (x3) rc = extra_grad ? tab_launch<true, true, true>(a, fa, te - tb, lds, st) : tab_launch<true, true, false>(a, fa, te - tb, lds, st);
+    if (x3 && !x3_update_old()) rc = tab16x3_launch(a, fa, te - tb, extra_grad != nullptr, false, stream);
+    else if (x3) rc = extra_grad ? tab_launch<true, true, true>(a, fa, te - tb, lds, st) : tab_launch<true, true, false>(a, fa, te - tb, lds, st);
     else rc = extra_grad ? tab_launch<false, true, true>(a, fa, te - tb, lds, st) : tab_launch<false, true, false>(a, fa, te - tb, lds, st);
     if (rc) return rc;
     HIP_LAUNCH_CHECK();
@@ -631,7 +628,8 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
     fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = nullptr;
     fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
     fa.extra1 = nullptr;
-    int rc = tab_launch<true, true, false, true>(a, fa, (N + TI - 1) / TI, tab_lds(Bp, H, true, true), (hipStream_t)stream);
+    int rc = x3_update_old() ? tab_launch<true, true, false, true>(a, fa, (N + TI - 1) / TI, tab_lds(Bp, H, true, true), (hipStream_t)stream)
+                             : tab16x3_launch(a, fa, (N + TI - 1) / TI, false, true, stream);
     if (rc) return rc;
     HIP_LAUNCH_CHECK();
     return 0;
