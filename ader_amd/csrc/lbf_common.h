@@ -64,6 +64,8 @@ struct TabArgs {
     int vrows;              // table rows that exist from emb1 on (item_num)
     const bf16* rep_hi;     // [Bp][LDR] bf16(rep), zero padded
     const bf16* rep_lo;     // [Bp][LDR] bf16(rep - hi)   (X3)
+    const void* rep_img;    // k_tab16x3: LDS images of the rep chunks (ader_x3_rep_image); NULL elsewhere
+    int ko;                 // timing-only knock-outs (ADER_X3_KO; 0 in every real run): 1 no theta/m/v traffic, 2 no GEMM, 4 no DMA, 8 no barrier
     const float* off;       // [Bp] log2(w_b) - lse2_b; -inf for rows without a loss term
     int Bp, H, N, tile_off;
     float* demb1;           // !ADAM: gradient row of item 1

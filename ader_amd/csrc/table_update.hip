@@ -485,15 +485,6 @@ static int tab_launch(const TabArgs& a, const FuseArgs& fa, int tiles, size_t ld
     return 0;
 }
 
-// the x3 fused update of table_update_x3.hip (k_tab16x3: 16x16x32 tiles, three workgroups per CU, LDS-DMA rep pipeline)
-int tab16x3_launch(const TabArgs& a, const FuseArgs& fa, int tiles, bool extra, bool kd, void* stream);
-// ADER_X3_UPDATE=old selects the round-2 kernel (k_tab_upd<X3>) for A/B timing and kernel-vs-kernel tests
-static bool x3_update_old() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ADER_X3_UPDATE"); v = (e && e[0] == 'o') ? 1 : 0; }
-    return v == 1;
-}
-
 extern "C" {
 
 // Per-tile records of the id-sorted sparse lists for ader_tab_update: rec [ceil(N/64)][2][18] ints (ader_tab_meta_ints(N)).
@@ -519,7 +510,7 @@ int ader_tab_grad(const void* rep_hi, const void* rep_lo, const float* emb, int 
     hipStream_t st = (hipStream_t)stream;
     TabArgs a;
     a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
-    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = demb + H;
+    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.rep_img = nullptr; a.demb1 = demb + H;
     a.kd_row0 = Bp; a.Np = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
     FuseArgs fa = {};
     const int tiles = (N + TI - 1) / TI;
@@ -543,7 +534,7 @@ int ader_tab_grad_kd(const void* rep_hi, const void* rep_lo, const float* emb, i
     hipStream_t st = (hipStream_t)stream;
     TabArgs a;
     a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
-    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = demb + H;
+    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.rep_img = nullptr; a.demb1 = demb + H;
     a.kd_row0 = kd_row0; a.Np = Np; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
     FuseArgs fa = {};
     fa.wrow = wrow;
@@ -576,7 +567,7 @@ int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int it
     if (extra_grad && ((uintptr_t)extra_grad & 15) != ph) return -2;
     TabArgs a;
     a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
-    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = nullptr;
+    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.rep_img = nullptr; a.demb1 = nullptr;
     a.kd_row0 = Bp; a.Np = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
     FuseArgs fa;
     fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
@@ -597,8 +588,7 @@ int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int it
     const bool x3 = rep_lo != nullptr;
     const size_t lds = tab_lds(Bp, H, x3, true);
     int rc;
-    if (x3 && !x3_update_old()) rc = tab16x3_launch(a, fa, te - tb, extra_grad != nullptr, false, stream);
-    else if (x3) rc = extra_grad ? tab_launch<true, true, true>(a, fa, te - tb, lds, st) : tab_launch<true, true, false>(a, fa, te - tb, lds, st);
+    if (x3) rc = extra_grad ? tab_launch<true, true, true>(a, fa, te - tb, lds, st) : tab_launch<true, true, false>(a, fa, te - tb, lds, st);
     else rc = extra_grad ? tab_launch<false, true, true>(a, fa, te - tb, lds, st) : tab_launch<false, true, false>(a, fa, te - tb, lds, st);
     if (rc) return rc;
     HIP_LAUNCH_CHECK();
@@ -619,7 +609,7 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
     if ((ph & 7) || ((uintptr_t)adam_m & 15) != ph || ((uintptr_t)adam_v & 15) != ph) return -2;
     TabArgs a;
     a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.off = off;
-    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = nullptr;
+    a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.rep_img = nullptr; a.demb1 = nullptr;
     a.kd_row0 = kd_row0; a.Np = Np; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
     FuseArgs fa;
     fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
@@ -628,8 +618,7 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
     fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = nullptr;
     fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
     fa.extra1 = nullptr;
-    int rc = x3_update_old() ? tab_launch<true, true, false, true>(a, fa, (N + TI - 1) / TI, tab_lds(Bp, H, true, true), (hipStream_t)stream)
-                             : tab16x3_launch(a, fa, (N + TI - 1) / TI, false, true, stream);
+    int rc = tab_launch<true, true, false, true>(a, fa, (N + TI - 1) / TI, tab_lds(Bp, H, true, true), (hipStream_t)stream);
     if (rc) return rc;
     HIP_LAUNCH_CHECK();
     return 0;

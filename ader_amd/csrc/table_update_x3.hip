@@ -9,23 +9,35 @@
 // workgroups in different phases that overlap the two.  What differs from the bf16 kernel:
 //   * there is no bf16 shadow in x3 mode: the E operand (hi and lo fragments, 40 registers) is cut from the fp32 theta tile, which
 //     passes through LDS once at the start of the tile;
-//   * rep (hi and lo planes, [Bp][168] bf16 each) is streamed in chunks of 32 batch rows by LDS-DMA (global_load_lds_dwordx4, no
-//     staging registers) into a double buffer: the chunk after the current one is in flight under the current chunk's 60 MFMAs,
-//     one workgroup barrier per chunk (the round-2 kernel loaded, staged and waited for both planes of every chunk synchronously:
-//     1.43-1.53 ms per 10^6 rows);
+//   * rep (hi and lo planes) is streamed in chunks of 32 batch rows by LDS-DMA (global_load_lds_dwordx4, no staging registers)
+//     into a double buffer: the chunk after the current one is in flight under the current chunk's 60 MFMAs, one workgroup barrier
+//     per chunk (the round-2 kernel loaded, staged and waited for both planes of every chunk synchronously: 1.43-1.53 ms per 10^6
+//     rows).  The DMA copies a ready-made LDS IMAGE of the chunk (k_x3_rep_image): 16-byte k-chunks [kc][row][8 elements] placed
+//     so that BOTH operand reads are free of bank conflicts -- with the row-major 336-byte rows of the other kernels the
+//     ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads of the 16x16x32 operand maps are two-way conflicts
+//     (SQ_LDS_BANK_CONFLICT 30 % of the kernel, the LDS pipe busier than the matrix pipe: 1.16 ms);
 //   * 32-row chunks: one K = 32 MFMA per (16-channel block, term) -- the A fragment of lane (item c16, k-group g) is its own p
 //     values of the chunk's two S blocks (rows 4g..4g+3 of each), the B fragment reads exactly those rep rows k-major with
 //     ds_read_b64_tr_b16.
 // The optimiser phase (dE staging tile, sparse terms from the bucketed lists in list order -- no atomics, bit-reproducible --, TF-Adam
 // over the tile's flat [64*H] block of theta/m/v in 16-byte vectors) is the one of k_tab16 without the shadow rows.  gfx950 only.
+#include <stdlib.h>
 #include "lbf_common.h"
 #include "../../include/ader_hip.h"
 
 #define TI 64                      // table rows per workgroup
 #define X3_CH 32                   // batch rows per rep chunk
-#define X3_PLANE (X3_CH * LDR)     // bf16 elements of one plane of a chunk (5376 = 10,752 B)
-#define X3_BUF (2 * X3_PLANE)      // elements of one LDS buffer: hi plane, lo plane (21,504 B = 21 LDS-DMA pieces of 1 KiB)
-#define X3_PIECES ((X3_BUF * 2) / 1024)
+// LDS image of one plane of a chunk: 20 k-chunks (8 channels = 16 B per row) of [32 rows][16 B] = 512 B each, in quads of four:
+//   byte offset of k-chunk kc = 2176 (kc >> 2) + 1152 ((kc >> 1) & 1) + 512 (kc & 1)
+// k-chunks kc, kc+1 (kc even) are 512 B apart: the ds_read_b128 row read of lane (row c16, k-group g) at k-chunk 4 ks + g puts the
+// 16 lanes of a read group (all 16 rows, two adjacent g) on 16 different 16-byte slots; k-chunks kc, kc+2 are 1152 B = 128 (mod 256)
+// apart: the transposed read of a 4-row x 16-channel block built from k-chunks (kc, kc+2) covers all 64 banks once per 32 lanes.
+#define X3_QUAD 2176
+#define X3_PLANE_B (5 * X3_QUAD)   // bytes of one plane image (10,880)
+#define X3_IMG_B 22528             // bytes of a chunk image in memory and in LDS: hi plane, lo plane, zero padding to 22 KiB
+#define X3_BUF (X3_IMG_B / 2)      // bf16 elements of one LDS buffer
+#define X3_PIECES (X3_IMG_B / 1024)
+__host__ __device__ __forceinline__ constexpr int x3_kc_off(int kc) { return X3_QUAD * (kc >> 2) + 1152 * ((kc >> 1) & 1) + 512 * (kc & 1); }
 #define TM_LIST 18                 // ints per list in a tile record: [k0, k1, 8 x (id, row)]
 #define NVEC 10                    // 16-byte vectors per thread covering a tile: 10 * 1024 floats >= 64 * 160
 
@@ -33,7 +45,9 @@
 #define HEAVY_N 32                 // a bucket with more entries than this in either list takes the heavy path
 #define HVB 16                     // gradient rows in flight per thread on the heavy path
 #define SPB 8                      // sparse-list entries per batch of the optimiser phase (loads of a batch are independent)
+#ifndef AV
 #define AV 6                       // 16-byte vectors per thread and load round of the optimiser phase (x theta, m, v)
+#endif
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -43,23 +57,39 @@ __device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// One chunk of rep (32 rows of the hi plane, then 32 rows of the lo plane: two contiguous runs of 10,752 B in memory) -> LDS buffer,
-// as 21 LDS-DMA pieces of 1 KiB dealt round-robin to the 4 waves.  The LDS image is the two runs back to back; piece 10 straddles
-// them (its lanes 0-31 read the end of the hi run, lanes 32-63 the start of the lo run: the SOURCE address is per lane).
-__device__ __forceinline__ void x3_dma_chunk(const bf16* __restrict__ rep_hi, const bf16* __restrict__ rep_lo, int c, bf16* buf,
-                                             int wave_u, int lane) {
-    const char* hi = (const char*)(rep_hi + (size_t)c * X3_PLANE);
-    const char* lo = (const char*)(rep_lo + (size_t)c * X3_PLANE);
+__device__ int x3_cu_arrivals[4096];
+
+// One chunk image (22 KiB, contiguous in memory) -> LDS buffer, as 22 LDS-DMA pieces of 1 KiB dealt round-robin to the 4 waves.
+// The DMA is issued from inline asm ON PURPOSE: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 it cannot tell apart from the destination -- in the middle of the
+// chunk, which drained the prefetch half a chunk after it was issued.  Hidden from the compiler, the pieces are waited for by the
+// explicit vmcnt(0) at the head of the next chunk only (cdna_hip_programming.md 5.7: M0 saved, written and restored in ONE statement).
+__device__ __forceinline__ void x3_glds16(const char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void x3_dma_chunk(const char* __restrict__ img, int c, bf16* buf, int wave_u, int lane) {
+    const char* src0 = img + (size_t)c * X3_IMG_B + 16 * lane;
+    const unsigned dst0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)buf;
 #pragma unroll
     for (int i = 0; i < (X3_PIECES + 3) / 4; ++i) {
         const int p = wave_u + 4 * i;                       // wave-uniform
-        if (p < X3_PIECES) {
-            const int byte = 1024 * p + 16 * lane;
-            const char* src = (byte < X3_PLANE * 2) ? hi + byte : lo + (byte - X3_PLANE * 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)((char*)buf + 1024 * p), 16, 0, 0);
-        }
+        if (p < X3_PIECES) x3_glds16(src0 + 1024 * p, __builtin_amdgcn_readfirstlane(dst0 + 1024 * p));
     }
+}
+
+// LDS image of rep for k_tab16x3: img [Bp / 32 chunks][X3_IMG_B]; thread = one 16-byte slot (plane, k-chunk, row) of a chunk
+__global__ __launch_bounds__(256) void k_x3_rep_image(const bf16* __restrict__ rep_hi, const bf16* __restrict__ rep_lo, int Bp,
+                                                      char* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * 20 * X3_CH;
+    if (i >= (Bp / X3_CH) * per) return;
+    const int c = i / per, s_ = i - c * per;
+    const int plane = s_ / (20 * X3_CH), t = s_ - plane * (20 * X3_CH);
+    const int row = t / 20, kc = t - row * 20;              // consecutive threads: consecutive 16-byte pieces of a source row
+    const bf16* src = (plane ? rep_lo : rep_hi) + (size_t)(c * X3_CH + row) * LDR + 8 * kc;
+    *(uint4*)(img + (size_t)c * X3_IMG_B + plane * X3_PLANE_B + x3_kc_off(kc) + 16 * row) = *(const uint4*)src;
 }
 
 // one round of theta / m / v vectors of the tile's flat [64*H] block: all loads issued before any math or store
@@ -81,8 +111,8 @@ _Pragma("unroll") for (int u = 0; u < AV; ++u) {                                
 template <bool EXTRA, bool KD>
 __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* R_l = (bf16*)smem_raw;                                // [2 buffers][hi, lo][32][LDR]; first the theta tile, last the dE tile
-    float* off_l = (float*)(smem_raw + 2 * X3_BUF * sizeof(bf16));     // [Bp]
+    bf16* R_l = (bf16*)smem_raw;                                // [2 buffers][chunk image]; first the theta tile, last the dE tile
+    float* off_l = (float*)(smem_raw + 2 * X3_IMG_B);           // [Bp]
     int* meta_l = (int*)(off_l + a.Bp);                         // the tile's list record [2][TM_LIST] (ader_tab_tile_meta)
     float* toff_l = (float*)(meta_l + 2 * TM_LIST);             // KD: [Bp - kd_row0] log2(w_b) - tlse2_b (-inf: no teacher term)
     int* trow_l = (int*)(toff_l + (a.Bp - a.kd_row0));          // KD: [Bp - kd_row0] teacher row (0 for padding rows)
@@ -101,7 +131,32 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     const int ph = (int)(((uintptr_t)gsrc & 15) >> 2);
     const int head = ph ? 4 - ph : 0;
     float* T_l = (float*)(smem_raw + 4 * ph);                   // theta tile, flat [64*H]
-
+    // ---- phase stagger of the first generation of workgroups (speed only): all tiles cost the same, so the three
+    // workgroups of a CU would run their matrix phases together and their HBM phases together for the whole launch
+    if ((a.ko >> 16) && blockIdx.x < 768) {
+        const int mode = (a.ko >> 8) & 15;
+        int k;
+        if (mode == 3) {        // arrival order on this CU (HW_ID: cu 11:8, sh 12, se 15:13; XCC_ID 3:0)
+            int kk = 0;
+            if (tid == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+                const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID
+                const unsigned cu = ((hw >> 8) & 0xff) | ((xcc & 15) << 8);
+                kk = atomicAdd(&x3_cu_arrivals[cu & 4095], 1) % 3;
+            }
+            k = __shfl(kk, 0, 64);
+            k = __builtin_amdgcn_readfirstlane(k);
+            __shared__ int k_sh;
+            if (tid == 0) k_sh = k;
+            __syncthreads();
+            k = k_sh;
+        } else k = mode == 0 ? (int)(blockIdx.x >> 8) : (mode == 1 ? (int)((blockIdx.x >> 3) % 3) : (int)(blockIdx.x % 3));
+        if (k) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long dt = (unsigned long long)k * (a.ko >> 16) * 100ull;      // 100 MHz ticks
+            while (__builtin_amdgcn_s_memrealtime() - t0 < dt) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     // ---- theta tile -> LDS (zero beyond the table's last row); the per-row constants and the tile's list record beside it
     {
         f32x4_t t4[NVEC];
@@ -163,14 +218,17 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     for (int cb = 0; cb < 10; ++cb) dE[cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     const int nch = a.Bp / X3_CH;
     const int q4 = c16 >> 2, p4 = c16 & 3;
-    x3_dma_chunk(a.rep_hi, a.rep_lo, 0, R_l, wave, lane);
-    for (int c = 0; c < nch; ++c) {
+    const char* img = (const char*)a.rep_img;
+    // per-lane byte offsets into a chunk image: row read of (row c16, k-group g); transposed read of (row 4g + q4, 4 channels p4)
+    const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
+    const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
+    x3_dma_chunk(img, 0, R_l, wave, lane);
+    for (int c = 0; c < ((a.ko & 2) ? 0 : nch); ++c) {
         // this wave's pieces of chunk c have landed and its LDS reads of chunk c-1 are done; after the barrier that holds for every
         // wave, so chunk c can be read and the other buffer (chunk c-1's) can be refilled
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c + 1 < nch) x3_dma_chunk(a.rep_hi, a.rep_lo, c + 1, R_l + ((c + 1) & 1) * X3_BUF, wave, lane);
-        const bf16* Bh = R_l + (c & 1) * X3_BUF;
-        const bf16* Bl = Bh + X3_PLANE;
+        if (!(a.ko & 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 1 < nch && !(a.ko & 4)) x3_dma_chunk(img, c + 1, R_l + ((c + 1) & 1) * X3_BUF, wave, lane);
+        const char* Bh = (const char*)(R_l + (c & 1) * X3_BUF);
         const int b0 = c * X3_CH;
         // KD rows: this lane's 8 teacher logits (item it0 + c16, batch rows b0 + 16 rb + 4 g + j), requested ahead of the MFMAs
         float tv[KD ? 8 : 1];
@@ -180,21 +238,43 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             for (int j = 0; j < 8; ++j)
                 tv[KD ? j : 0] = a.teacher[(size_t)trow_l[b0 - a.kd_row0 + 16 * (j >> 2) + 4 * g + (j & 3)] * a.ldt + it0 + c16];
         }
-        // S block rb = 16 batch rows x 16 items: A = rep rows (lane: row c16 of the block, k = 8g..8g+7), B = this wave's E fragments
+        // S block rb = 16 batch rows x 16 items: A = rep rows (lane: row c16 of the block, k = 8g..8g+7), B = this wave's E fragments.
+        // The operand reads are software-pipelined by hand, two k-steps ahead of the MFMAs that consume them (left to itself hipcc
+        // reloads ONE register set just before its use and every pair of MFMAs waits out a full LDS latency: each wave ran its
+        // chunk at a quarter of the matrix rate and a workgroup in its optimiser phase took its share of the pipe with it)
+#define X3_LOADA(set_, ks_)                                                                               \
+        { const char* ap_ = Bh + a_off + X3_QUAD * (ks_);     /* k-chunk 4 ks + g, row c16 (S block 1: + 16 rows = 256 B) */ \
+          set_[0] = *(const bf16x8*)ap_; set_[1] = *(const bf16x8*)(ap_ + X3_PLANE_B);                    \
+          set_[2] = *(const bf16x8*)(ap_ + 256); set_[3] = *(const bf16x8*)(ap_ + X3_PLANE_B + 256); }
+        // transposed reads of channel block cb = (quad Q = cb >> 1, o = cb & 1): k-chunks 4Q + o and 4Q + o + 2, i.e. lane c16 <->
+        // channel 32 Q + 8 o + 16 (c16 >> 3) + (c16 & 7); set = {hi rows 4g.., hi rows 16+4g.., lo rows 4g.., lo rows 16+4g..}
+#define X3_LOADT(set_, cb_)                                                                               \
+        { const bf16* tp_ = (const bf16*)(Bh + t_off + X3_QUAD * ((cb_) >> 1) + 512 * ((cb_) & 1));         \
+          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 128);                                           \
+          set_[2] = tr_read(tp_ + X3_PLANE_B / 2); set_[3] = tr_read(tp_ + X3_PLANE_B / 2 + 128); }
         f32x4v S0 = (f32x4v){0.f, 0.f, 0.f, 0.f}, S1 = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[2][4];
+        X3_LOADA(fa[0], 0);
+        X3_LOADA(fa[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
-            const bf16x8 ah0 = *(const bf16x8*)(Bh + c16 * LDR + 32 * ks + 8 * g);
-            const bf16x8 al0 = *(const bf16x8*)(Bl + c16 * LDR + 32 * ks + 8 * g);
-            const bf16x8 ah1 = *(const bf16x8*)(Bh + (16 + c16) * LDR + 32 * ks + 8 * g);
-            const bf16x8 al1 = *(const bf16x8*)(Bl + (16 + c16) * LDR + 32 * ks + 8 * g);
-            S0 = mfma16_bf16(al0, e_hi[ks], S0);
-            S1 = mfma16_bf16(al1, e_hi[ks], S1);
-            S0 = mfma16_bf16(ah0, e_lo[ks], S0);
-            S1 = mfma16_bf16(ah1, e_lo[ks], S1);
-            S0 = mfma16_bf16(ah0, e_hi[ks], S0);
-            S1 = mfma16_bf16(ah1, e_hi[ks], S1);
+            bf16x8* A_ = fa[ks & 1];                             // {ah0, al0, ah1, al1}
+            S0 = mfma16_bf16(A_[1], e_hi[ks], S0);
+            S1 = mfma16_bf16(A_[3], e_hi[ks], S1);
+            S0 = mfma16_bf16(A_[0], e_lo[ks], S0);
+            S1 = mfma16_bf16(A_[2], e_lo[ks], S1);
+            S0 = mfma16_bf16(A_[0], e_hi[ks], S0);
+            S1 = mfma16_bf16(A_[2], e_hi[ks], S1);
+            if (ks + 2 < 5) X3_LOADA(fa[ks & 1], ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // the first transposed reads of the P^T.rep phase do not depend on S: in flight under the exp2 section
+        bf16x4 ft[3][4];
+        X3_LOADT(ft[0], 0);
+        X3_LOADT(ft[1], 1);
+        X3_LOADT(ft[2], 2);
+        __builtin_amdgcn_sched_barrier(0);
         // rows of S are batch rows: p = w_b * softmax = exp2(S*log2e + off_b)
         {
             const float4 o0 = *(const float4*)(off_l + b0 + 4 * g);
@@ -222,26 +302,30 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             ph_[j] = h0; ph_[4 + j] = h1;
             pl_[j] = (bf16)(S0[j] - (float)h0); pl_[4 + j] = (bf16)(S1[j] - (float)h1);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cb = 0; cb < 10; ++cb) {
-            const bf16* base = Bh + (4 * g + q4) * LDR + 16 * cb + 4 * p4;
-            const bf16x4 t0 = tr_read(base), t1 = tr_read(base + 16 * LDR);
-            const bf16x4 u0 = tr_read(base + X3_PLANE), u1 = tr_read(base + X3_PLANE + 16 * LDR);
+            bf16x4* T_ = ft[cb % 3];
             bf16x8 bh, bl;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { bh[j] = t0[j]; bh[4 + j] = t1[j]; bl[j] = u0[j]; bl[4 + j] = u1[j]; }
+            for (int j = 0; j < 4; ++j) { bh[j] = T_[0][j]; bh[4 + j] = T_[1][j]; bl[j] = T_[2][j]; bl[4 + j] = T_[3][j]; }
             dE[cb] = mfma16_bf16(pl_, bh, dE[cb]);
             dE[cb] = mfma16_bf16(ph_, bl, dE[cb]);
             dE[cb] = mfma16_bf16(ph_, bh, dE[cb]);
+            if (cb + 3 < 10) X3_LOADT(ft[cb % 3], cb + 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef X3_LOADA
+#undef X3_LOADT
     // ---- optimiser phase: the tile's rows are ONE contiguous block of 64*H floats in theta / m / v (and in F_l)
     float* F_l = (float*)smem_raw;
     const int rows_valid = min(TI, N - tile0);
-    const int n_el = rows_valid > 0 ? rows_valid * H : 0;
-    float* __restrict__ gp = f.emb1 + (size_t)tile0 * H;
-    float* __restrict__ gm = f.m1 + (size_t)tile0 * H;
-    float* __restrict__ gv = f.v1 + (size_t)tile0 * H;
+    const int n_el = (rows_valid > 0 && !(a.ko & 1)) ? rows_valid * H : 0;
+    const size_t tq = (a.ko & 16) ? (size_t)(tile & 63) * TI : (size_t)tile0;    // ko 16: optimiser traffic served by L2 (timing only)
+    float* __restrict__ gp = f.emb1 + tq * H;
+    float* __restrict__ gm = f.m1 + tq * H;
+    float* __restrict__ gv = f.v1 + tq * H;
     const int head2 = (((uintptr_t)gp) & 15) ? 2 : 0;
     int e = head2 + 4 * tid;
     f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
@@ -255,7 +339,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     lds_only_barrier();             // every wave is done with the last rep chunk
 #pragma unroll
     for (int cb = 0; cb < 10; ++cb) {
-        const int h = 16 * cb + c16;
+        const int h = 32 * (cb >> 1) + 8 * (cb & 1) + 16 * (c16 >> 3) + (c16 & 7);
         if (h < H) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) F_l[(wave * 16 + 4 * g + j) * H + h] = dE[cb][j];
@@ -370,7 +454,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
         *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
     }
 #pragma unroll 1
-    for (int k0 = 0; k0 < 12; k0 += AV) {                 // 12 * 1024 floats >= 64 * 160; round 0 is already in flight
+    for (int k0 = 0; k0 < NVEC; k0 += AV) {               // 10 * 1024 floats >= 64 * 150; round 0 is already in flight
         if (k0) { ROUND_LOAD(); }
 #pragma unroll
         for (int u = 0; u < AV; ++u) {
@@ -398,7 +482,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
 
 // ============================================================================================= launch (C ABI: table_update.hip)
 static size_t tab16x3_lds(int Bp, int Bk) {
-    return (size_t)2 * X3_BUF * sizeof(bf16) + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int) + (size_t)Bk * 8;
+    return (size_t)2 * X3_IMG_B + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int) + (size_t)Bk * 8;
 }
 
 template <bool EXTRA, bool KD>
@@ -413,12 +497,94 @@ static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, siz
     return 0;
 }
 
-// x3 fused update of `tiles` 64-row tiles from a.tile_off on (called by ader_tab_update / ader_tab_update_kd)
-int tab16x3_launch(const TabArgs& a, const FuseArgs& fa, int tiles, bool extra, bool kd, void* stream) {
-    if (a.Bp % X3_CH != 0 || (kd && a.kd_row0 % X3_CH != 0)) return -2;
+static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, bool kd, void* stream) {
+    { static int ko = -1; if (ko < 0) { const char* e = getenv("ADER_X3_KO"); ko = e ? atoi(e) : 0; const char* s_ = getenv("ADER_X3_STAGGER"); ko |= (s_ ? atoi(s_) : 0) << 16; } a.ko = ko; }
+    if (a.Bp % X3_CH != 0 || (kd && a.kd_row0 % X3_CH != 0) || !a.rep_img || ((uintptr_t)a.rep_img & 15)) return -2;
     const size_t lds = tab16x3_lds(a.Bp, kd ? a.Bp - a.kd_row0 : 0);
     hipStream_t st = (hipStream_t)stream;
     if (kd) return tab16x3_launch_t<false, true>(a, fa, tiles, lds, st);
     if (extra) return tab16x3_launch_t<true, false>(a, fa, tiles, lds, st);
     return tab16x3_launch_t<false, false>(a, fa, tiles, lds, st);
 }
+
+extern "C" {
+
+// LDS image of the x3 operand rows for ader_tab_update_x3[_kd]: img = ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned, built from
+// the two planes rep_hi / rep_lo [Bp,168] that ader_lx3_prep / ader_lx3_fwd[_kd] leave (Bp % 32 == 0).
+int ader_x3_rep_image_bytes(int Bp) { return (Bp / X3_CH) * X3_IMG_B; }
+int ader_x3_rep_image(const void* rep_hi, const void* rep_lo, int Bp, void* img, void* stream) {
+    if (Bp <= 0) return 0;
+    if (Bp % X3_CH != 0 || ((uintptr_t)img & 15)) return -2;
+    const int n = (Bp / X3_CH) * 2 * 20 * X3_CH;
+    hipLaunchKernelGGL(k_x3_rep_image, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)rep_hi,
+                       (const bf16*)rep_lo, Bp, (char*)img);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// The fused table update at float32 grade (gradient GEMM + sparse rows + TF-Adam on table rows 1..N in one pass, ADER.py:91-96):
+// arguments as ader_tab_update with rep_lo != NULL, plus rep_img = ader_x3_rep_image of the same two planes; no shadow.
+int ader_tab_update_x3(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int B, int Bp, int H, int N,
+                       const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                       const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, float* emb,
+                       float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                       int tile_count, const float* extra_grad, void* stream) {
+    if (B <= 0) return 0;
+    if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || !rep_lo) return -2;
+    const uintptr_t ph = (uintptr_t)emb & 15;
+    if ((ph & 7) || ((uintptr_t)adam_m & 15) != ph || ((uintptr_t)adam_v & 15) != ph) return -2;
+    if (extra_grad && ((uintptr_t)extra_grad & 15) != ph) return -2;
+    TabArgs a;
+    a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.rep_img = rep_img;
+    a.off = off; a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = nullptr;
+    a.kd_row0 = Bp; a.Np = 0; a.teacher = nullptr; a.ldt = 0; a.trow = nullptr; a.tlse2 = nullptr;
+    FuseArgs fa;
+    fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
+    fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
+    fa.tile_meta = tile_meta;
+    fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = nullptr;
+    fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
+    fa.extra1 = extra_grad ? extra_grad + H : nullptr;
+    // tiles [tile_begin, tile_begin + tile_count) of the ceil(N/128) 128-item tiles (tile_count < 0: all) = two 64-row tiles each
+    const int all = (N + TI - 1) / TI;
+    int tb = (tile_begin < 0 ? 0 : tile_begin) * 2;
+    int te = tile_count < 0 ? all : tb + tile_count * 2;
+    if (te > all) te = all;
+    if (te <= tb) return 0;
+    a.tile_off = tb;
+    int rc = tab16x3_launch(a, fa, te - tb, extra_grad != nullptr, false, stream);
+    if (rc) return rc;
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... and for a DISTILLED step (ADER.py:132-137): arguments as ader_tab_update_kd plus rep_img.
+int ader_tab_update_x3_kd(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int Bp, int kd_row0, int H, int N,
+                          int Np, const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src,
+                          float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow,
+                          const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
+                          float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream) {
+    if (Bp <= 0) return 0;
+    if (Bp % 128 != 0 || kd_row0 % 128 != 0 || kd_row0 >= Bp || H > HP || (H & 1) || H < 2 || N > item_num || !rep_lo || !teacher ||
+        !trow || !tlse2 || Np < 1 || Np > N) return -2;
+    const uintptr_t ph = (uintptr_t)emb & 15;
+    if ((ph & 7) || ((uintptr_t)adam_m & 15) != ph || ((uintptr_t)adam_v & 15) != ph) return -2;
+    TabArgs a;
+    a.emb1 = emb + H; a.vrows = item_num; a.rep_hi = (const bf16*)rep_hi; a.rep_lo = (const bf16*)rep_lo; a.rep_img = rep_img;
+    a.off = off; a.Bp = Bp; a.H = H; a.N = N; a.tile_off = 0; a.demb1 = nullptr;
+    a.kd_row0 = kd_row0; a.Np = Np; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
+    FuseArgs fa;
+    fa.sp_ids = sp_ids; fa.sp_rows = sp_rows; fa.n_sp = n_sp; fa.sp_src = sp_src; fa.sp_scale = sp_scale;
+    fa.tg_ids = tg_ids; fa.tg_rows = tg_rows; fa.n_tg = n_tg; fa.wrow = wrow;
+    fa.tile_meta = tile_meta;
+    fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = nullptr;
+    fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
+    fa.extra1 = nullptr;
+    int rc = tab16x3_launch(a, fa, (N + TI - 1) / TI, false, true, stream);
+    if (rc) return rc;
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -248,6 +248,9 @@ class Engine:
         # bf16 mode, fused table update: "sh" = k_tab16 (operand from the shadow rows, three workgroups per CU: the faster form),
         # "resident" = k_tab_upd (theta tile read once and kept in LDS, no shadow read: 8 % fewer bytes, 10 % slower)
         self.bf16_update = "sh"
+        # x3 mode, fused table update: "tab16" = k_tab16x3 (16x16x32 tiles, three workgroups per CU, rep chunks by LDS-DMA as
+        # conflict-free LDS images: the faster form), "tab32" = the round-2 kernel k_tab_upd<X3> (kept for kernel-vs-kernel tests)
+        self.x3_update = os.environ.get("ADER_X3_UPDATE", "tab16")
         self._table_stale = False
         self._mv_sharded = False   # dp: Adam m/v of the table are current only for the rank's own rows (see _gather_if_sharded)
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
@@ -1109,12 +1112,21 @@ class Engine:
             with Engine._OnStream(self, self._side):
                 small_update()
         with self._sec("logits_bwd_adam"):
+            if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
+                img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", D["Bp"]),), torch.uint8, zero=True)
+                call("ader_x3_rep_image", ptr(D["rep_bf"]), ptr(D["rep_lo"]), D["Bp"], ptr(img), st)
             if self.lx3 and D.get("kd"):
                 K = D["kd"]
-                call("ader_tab_update_kd", ptr(D["rep_bf"]), ptr(D["rep_lo"]), self.item_num, D["Bp"], K["row0"], H, D["N"], K["Np"],
+                call("ader_tab_update_x3_kd" if self.x3_update == "tab16" else "ader_tab_update_kd", ptr(D["rep_bf"]), ptr(D["rep_lo"]),
+                     *((ptr(img),) if self.x3_update == "tab16" else ()), self.item_num, D["Bp"], K["row0"], H, D["N"], K["Np"],
                      ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
                      ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(K["teacher"]), K["teacher"].stride(0), ptr(K["trow"]),
                      ptr(K["tlse2"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1, self.beta2, self.eps, st)
+            elif self.lx3 and self.x3_update == "tab16":
+                call("ader_tab_update_x3", ptr(D["rep_bf"]), ptr(D["rep_lo"]), ptr(img), self.item_num, D["B"], D["Bp"], H, D["N"],
+                     ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),
+                     ptr(torder), tids.numel(), ptr(tmeta), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
+                     self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
             elif self.lx3 or (self.bf16_update == "resident" and not D.get("kd")):
                 call("ader_tab_update", ptr(D["rep_bf"]), ptr(D["rep_lo"]), ptr(self.shadow), self.item_num, D["B"], D["Bp"], H, D["N"],
                      ptr(D["off"]), ptr(ids), ptr(order), ids.numel(), ptr(D["g"]), float(np.sqrt(np.float32(H))), ptr(tids),

@@ -286,6 +286,23 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
                        const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow,
                        const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
                        float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
+/* The float32-grade (x3) fused update on 16x16x32 tiles, three workgroups per CU (csrc/table_update_x3.hip: k_tab16x3): same
+ * arithmetic and arguments as ader_tab_update(rep_lo != NULL) / ader_tab_update_kd, plus rep_img: the operand rows rearranged into
+ * the bank-conflict-free LDS images that the kernel streams by LDS-DMA (ader_x3_rep_image from the two planes rep_hi / rep_lo
+ * [Bp,168]; ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned; Bp % 32 == 0).  Replaces the dense-Adam + table-gradient op
+ * sites ADER.py:91-96 for the item table, as ader_tab_update does. */
+int ader_x3_rep_image_bytes(int Bp);
+int ader_x3_rep_image(const void* rep_hi, const void* rep_lo, int Bp, void* img, void* stream);
+int ader_tab_update_x3(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int B, int Bp, int H, int N,
+                       const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                       const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, float* emb,
+                       float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                       int tile_count, const float* extra_grad, void* stream);
+int ader_tab_update_x3_kd(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int Bp, int kd_row0, int H,
+                          int N, int Np, const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src,
+                          float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta,
+                          const float* wrow, const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb,
+                          float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
 /* The bf16-mode form over 128-row tiles: the GEMM operand is the tile's bf16 shadow rows (`shadow` is read AND rewritten) and the
  * sorted lists are addressed through their 64-id bucket offsets sp_start / tg_start.  Faster than ader_tab_update(rep_lo = NULL) at
  * H = 150 on MI355X although it reads 336 B more per row (measurements: DESIGN.md). */
