@@ -74,3 +74,16 @@ struct TabArgs {
     int kd_row0, Np;
     const float* teacher; long ldt; const int* trow; const float* tlse2;
 };
+
+// arguments of the x3 flash forward kernels (logits_bf16.hip: k_lx3_fwd, logits_x3.hip: k_lx3f)
+struct Lx3Args {
+    const float* emb1;          // fp32 table, row of item 1
+    int vrows;                  // table rows available from emb1 (item_num)
+    const bf16* rep_hi; const bf16* rep_lo;     // [Bp][LDR]
+    int Bp, H, N, ranges;
+    float* pm; float* pl; float* pO;
+    // distilled rows (as LbfArgs): rows [kd_row0, Bp) take the softmax over the first Np items and have a teacher readout chunk
+    int kd_row0, Np;
+    const float* teacher; long ldt; const int* trow; const float* tlse2; float* pO2;
+    int ranges2;                // item ranges of the readout launch (it is a launch of its own in x3 mode: its own partition)
+};

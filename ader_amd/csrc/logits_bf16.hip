@@ -535,17 +535,6 @@ __global__ __launch_bounds__(256) void k_lx3_prep(const float* __restrict__ rep,
     rep_lo[i] = (bf16)(x - (float)h);
 }
 
-struct Lx3Args {
-    const float* emb1;          // fp32 table, row of item 1
-    int vrows;                  // table rows available from emb1 (item_num)
-    const bf16* rep_hi; const bf16* rep_lo;     // [Bp][LDR]
-    int Bp, H, N, ranges;
-    float* pm; float* pl; float* pO;
-    // distilled rows (as LbfArgs): rows [kd_row0, Bp) take the softmax over the first Np items and have a teacher readout chunk
-    int kd_row0, Np;
-    const float* teacher; long ldt; const int* trow; const float* tlse2; float* pO2;
-    int ranges2;                // item ranges of the readout launch (it is a launch of its own in x3 mode: its own partition)
-};
 
 #define XPPT 5                     // 16-byte fp32 vectors per thread per 32-item block (5 * 1024 floats >= 32 * 160)
 // XRD = register ring depth, OCC = workgroups per CU the register budget is sized for (256 / 512 registers per lane)
@@ -800,6 +789,21 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
     }
 }
 
+// the 16x16x32 x3 forward of logits_x3.hip (k_lx3f): three workgroups per CU, conflict-free block images, no register ring
+int lx3f_ranges(int N, int Bp);
+bool lx3f_supports(int H);
+int lx3f_launch(const Lx3Args& x, void* stream);
+int lx3g_launch(const Lx3Args& x, void* stream);
+// ADER_X3_FWD = old | f | g: the round-2 kernel (k_lx3_fwd), the 16x16x32 form (k_lx3f) or the 32x32x16 form (k_lx3g; default)
+static int lx3_kind(int H, int Bp) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 2 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : 2)); }
+    if (!lx3f_supports(H)) return 0;
+    if (v == 1 && Bp % 64 == 0) return 1;
+    if (v == 2 && Bp % 128 == 0) return 2;
+    return 0;
+}
+
 // ============================================================================================= C ABI
 static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
 
@@ -998,13 +1002,15 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
     hipStream_t st = (hipStream_t)stream;
     Lx3Args x;
     x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
-    x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
+    const int nk = lx3_kind(H, Bp);
+    x.Bp = Bp; x.H = H; x.N = N; x.ranges = nk == 1 ? lx3f_ranges(N, Bp) : ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
     x.kd_row0 = Bp; x.Np = 0; x.teacher = nullptr; x.ldt = 0; x.trow = nullptr; x.tlse2 = nullptr; x.pO2 = nullptr; x.ranges2 = 0;
     LbfArgs a;
     a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
     a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H);
-    hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
+    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3g_launch(x, stream); if (rc) return rc; }
+    else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
@@ -1030,7 +1036,8 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     hipStream_t st = (hipStream_t)stream;
     Lx3Args x;
     x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
-    x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
+    const int nk = lx3_kind(H, Bp);
+    x.Bp = Bp; x.H = H; x.N = N; x.ranges = nk == 1 ? lx3f_ranges(N, Bp) : ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
     x.kd_row0 = kd_row0; x.Np = Np; x.teacher = teacher; x.ldt = ldt; x.trow = trow; x.tlse2 = tlse2; x.pO2 = pO2;
     x.ranges2 = ader_lx3_readout_ranges(Np, Bp - kd_row0);
     LbfArgs a;
@@ -1040,7 +1047,8 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     a.pO2 = pO2; a.ranges2 = x.ranges2;
     hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, n_train, n_ex,
                        kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
-    hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
+    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3g_launch(x, stream); if (rc) return rc; }
+    else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        emb + H, rep);

@@ -1,0 +1,489 @@
+// Full-catalog logits + softmax cross-entropy at float32 grade, flash forward on 16x16x32 tiles (k_lx3f).
+// Reference: ADER.py:88-93 (logits = rep . item_emb^T, one-hot softmax CE) in float32: every product as three bf16 MFMAs on hi/lo
+// operand splits (hi.hi + lo.hi + hi.lo, ~2^-16 relative, fp32 accumulate, fp32 softmax).
+//
+// Same algorithm as k_lx3_fwd (logits_bf16.hip): per 32-item block S^T = E.rep^T, online max / sum-exp, and the probabilities go
+// back into the matrix core as the A operand of O[b,:] += P^T.E (the softmax-weighted readout = dRep up to the target term), so
+// nothing [rows, N]-sized is ever written.  What is different is the shape, chosen for what the round-2 kernel was short of:
+//   * 64 batch rows per workgroup, 16 per wave, on v_mfma_f32_16x16x32_bf16: rep fragments (hi + lo) 40 registers and O 40 instead
+//     of 80 + 80, no register ring of table blocks beyond the ONE block in flight -- <= 168 registers, three workgroups per CU and no
+//     scratch (k_lx3_fwd sat at 256 registers with spills inside the block loop and reloaded every operand right before its MFMA);
+//   * the table block is split into hi/lo on its way into LDS as the bank-conflict-free image of x3_image.h (16-byte k-chunks
+//     [kc][item][8 channels]; one ds_write_b128 per plane and slot instead of eight 4-byte stores with conflicts), and both operand
+//     reads -- ds_read_b128 rows for S^T, ds_read_b64_tr_b16 k-major for the readout -- are pipelined by hand two steps ahead
+//     of their MFMAs;
+//   * three independent workgroups per SIMD-set keep the matrix pipe fed while one of them converts / stores its next block.
+// Output partials (pm, pl, pO per item range) and the merge (k_lbf_combine<true>) are those of k_lx3_fwd.  gfx950 only.
+#include "lbf_common.h"
+#include "x3_image.h"
+#include "../../include/ader_hip.h"
+
+#define F3_ROWS 64                 // batch rows per workgroup (4 waves x 16)
+#define F3_FB 32                   // items per streamed block
+#define F3_RND 3                   // staging rounds: 12 units of (8 items x 8 k-chunks), 4 waves
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(8))) F3Vec { f32x4_t v; };      // 16-byte vector at an 8-byte aligned address (rows are 8 H bytes)
+
+template <int HT>       // HT: hidden size known at compile time (150: the reference default, main.py:104) or 0 = a.H
+__global__ __launch_bounds__(256, 3) void k_lx3f(Lx3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [2 buffers][block image]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int nchunk = a.Bp / F3_ROWS;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot / nchunk);           // the row chunks of an item range sit on one XCD: the table block is
+    const int bc = slot % nchunk;                          // fetched from HBM once and served to the others by that XCD's L2
+    if (range >= a.ranges) return;
+    const int H = HT ? HT : a.H;
+    const int N = (bc * F3_ROWS >= a.kd_row0) ? a.Np : a.N;            // columns of this chunk's softmax (distilled rows: first Np)
+    const int nblk_all = (a.N + F3_FB - 1) / F3_FB;
+    const int per = (nblk_all + a.ranges - 1) / a.ranges;
+    const int blk_begin = range * per, blk_end = min((N + F3_FB - 1) / F3_FB, blk_begin + per);
+    const int nb_blocks = max(0, blk_end - blk_begin);
+    const int b0 = bc * F3_ROWS + wave * 16;
+    // pads of both images (k-chunks >= ceil(H/8), bytes between the quads) stay zero: the block stores never touch them
+    for (int i = tid; i < 2 * X3_IMG_B / 16; i += 256) ((uint4*)smem_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // rep fragments: lane (batch row c16, k-group g) holds rep[b0 + c16][32 ks + 8 g + 0..7]
+    bf16x8 rh[5], rl[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        rh[ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + c16) * LDR + 32 * ks + 8 * g);
+        rl[ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + c16) * LDR + 32 * ks + 8 * g);
+    }
+    f32x4v O[10];
+#pragma unroll
+    for (int cb = 0; cb < 10; ++cb) O[cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    // ---- staging: a block = 32 table rows of H floats.  Round r (0..2) of wave w covers items 8 w.. and k-chunks 8 r..:
+    // lane l -> item + (l & 7), k-chunk + (l >> 3): the 8 lanes of an LDS write group store 8 consecutive 16-byte
+    // slots (conflict-free), and a wave's two 16-byte loads per slot touch 2 cache lines per table row.
+    const int nfull = H >> 3, rem = H & 7;                 // full k-chunks; channels of the partial one (0, 4 or 6: see launcher)
+    // round r of this lane: item it_ (= 8 wave + (lane & 7): a wave stages the same 8 items in every round), k-chunk 8 r + kc0
+    const int it_ = 8 * wave + (lane & 7), kc0 = lane >> 3;
+    const int voff = 4 * (it_ * H + 8 * kc0);              // byte offset inside the block (round r: + 256 r)
+    const int voffp = voff + 4 * (rem - 4);                // second vector of the partial k-chunk: ends with the row
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.emb1, 0, a.vrows * H * 4, 0x00020000);
+    const int dst0 = x3_kc_off(kc0) + 16 * it_;            // byte offset inside a plane (round r: + 2 quads r)
+#define F3_KC(r_) (8 * (r_) + kc0)
+#define F3_PART(r_) (rem && F3_KC(r_) == nfull)
+#define F3_VALID(r_) (F3_KC(r_) < nfull || F3_PART(r_))
+    f32x4_t sa[F3_RND], sb[F3_RND];
+    // Block loads through a buffer descriptor of the table (base in scalar registers, ONE 32-bit per-lane offset, the block's
+    // offset as the scalar offset, the round's as the instruction's immediate): no 64-bit per-lane pointers, and rows beyond the
+    // table's last one (only in its last block; their items are >= N: outside the softmax) come back as zeros from the hardware
+    // range check.  Lanes without a k-chunk read whatever follows their row (never stored).  NOTHING is selected on the loaded data
+    // here -- a select would make hipcc wait for each load right behind its issue.
+#define F3_LOAD(blk_)                                                                                     \
+    {                                                                                                     \
+        const int so_ = (blk_) * (F3_FB * 4) * H;              /* byte offset of the block (< 2^31: checked by the launcher) */ \
+        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
+            const u32x4_t va_ = __builtin_amdgcn_raw_buffer_load_b128(trs, voff + 256 * r, so_, 0);         \
+            const u32x4_t vb_ = __builtin_amdgcn_raw_buffer_load_b128(trs, (F3_PART(r) ? voffp : voff + 16) + 256 * r, so_, 0); \
+            sa[r] = __builtin_bit_cast(f32x4_t, va_); sb[r] = __builtin_bit_cast(f32x4_t, vb_);           \
+        }                                                                                                 \
+    }
+    // hi = bf16(x), lo = bf16(x - hi), 8 channels -> one 16-byte slot per plane
+#define F3_STORE(buf_)                                                                                    \
+    {                                                                                                     \
+        unsigned char* dst_ = smem_raw + (buf_) * X3_IMG_B;                                               \
+        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
+            float x_[8];                                                                                  \
+            x_[0] = sa[r][0]; x_[1] = sa[r][1]; x_[2] = sa[r][2]; x_[3] = sa[r][3];                       \
+            if (F3_PART(r)) {       /* rem = 6: channels 4,5 are elements 2,3 of the shifted vector; rem = 4: none */ \
+                x_[4] = (rem == 6) ? sb[r][2] : 0.f; x_[5] = (rem == 6) ? sb[r][3] : 0.f; x_[6] = 0.f; x_[7] = 0.f; \
+            } else { x_[4] = sb[r][0]; x_[5] = sb[r][1]; x_[6] = sb[r][2]; x_[7] = sb[r][3]; }            \
+            bf16x8 h_, l_;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
+            if (F3_VALID(r)) {                                                                            \
+                *(bf16x8*)(dst_ + dst0 + 2 * X3_QUAD * r) = h_;                                           \
+                *(bf16x8*)(dst_ + X3_PLANE_B + dst0 + 2 * X3_QUAD * r) = l_;                              \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+    const int q4 = c16 >> 2, p4 = c16 & 3;
+    // per-lane byte offsets into a block image: row read of (item c16, k-group g); transposed read of (item 4g + q4, 4 channels p4)
+    const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
+    const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
+    if (nb_blocks > 0) F3_LOAD(blk_begin);
+    __syncthreads();                                       // zero fill done
+    if (nb_blocks > 0) F3_STORE(0);
+    if (nb_blocks > 1) F3_LOAD(blk_begin + 1);
+    for (int i = 0; i < nb_blocks; ++i) {
+        __syncthreads();                                   // block i is in LDS; every wave is done with block i-1
+        if (i + 1 < nb_blocks) F3_STORE((i + 1) & 1);      // (its loads were issued one iteration ago)
+        if (i + 2 < nb_blocks) F3_LOAD(blk_begin + i + 2);
+        const char* Bh = (const char*)(smem_raw + (i & 1) * X3_IMG_B);
+        const int i0 = (blk_begin + i) * F3_FB;
+        // S^T block ib = 16 items x 16 batch rows: A = table rows (lane: item c16 of the block, k = 8g..8g+7), B = rep fragments
+#define F3_LOADA(set_, ks_)                                                                               \
+        { const char* ap_ = Bh + a_off + X3_QUAD * (ks_);      /* k-chunk 4 ks + g, item c16 (block 1: + 16 items = 256 B) */ \
+          set_[0] = *(const bf16x8*)ap_; set_[1] = *(const bf16x8*)(ap_ + X3_PLANE_B);                    \
+          set_[2] = *(const bf16x8*)(ap_ + 256); set_[3] = *(const bf16x8*)(ap_ + X3_PLANE_B + 256); }
+#define F3_LOADT(set_, cb_)                                                                               \
+        { const bf16* tp_ = (const bf16*)(Bh + t_off + X3_QUAD * ((cb_) >> 1) + 512 * ((cb_) & 1));         \
+          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 128);                                           \
+          set_[2] = tr_read(tp_ + X3_PLANE_B / 2); set_[3] = tr_read(tp_ + X3_PLANE_B / 2 + 128); }
+        f32x4v S0 = (f32x4v){0.f, 0.f, 0.f, 0.f}, S1 = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[2][4];
+        F3_LOADA(fa[0], 0);
+        F3_LOADA(fa[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            bf16x8* A_ = fa[ks & 1];                             // {hi items 0-15, lo items 0-15, hi items 16-31, lo items 16-31}
+            S0 = mfma16_bf16(A_[1], rh[ks], S0);
+            S1 = mfma16_bf16(A_[3], rh[ks], S1);
+            S0 = mfma16_bf16(A_[0], rl[ks], S0);
+            S1 = mfma16_bf16(A_[2], rl[ks], S1);
+            S0 = mfma16_bf16(A_[0], rh[ks], S0);
+            S1 = mfma16_bf16(A_[2], rh[ks], S1);
+            if (ks + 2 < 5) F3_LOADA(fa[ks & 1], ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the first transposed reads of the readout do not depend on S: in flight under the softmax section
+        bf16x4 ft[2][4];
+        F3_LOADT(ft[0], 0);
+        F3_LOADT(ft[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // lane (batch row c16, g) holds the logits of items i0 + 4g + j (S0) and i0 + 16 + 4g + j (S1)
+        if (i0 + F3_FB > N) {                              // tail block: items >= N are outside the softmax
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i0 + 4 * g + j >= N) S0[j] = -INFINITY;
+                if (i0 + 16 + 4 * g + j >= N) S1[j] = -INFINITY;
+            }
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(S0[0], S0[1]), fmaxf(S0[2], S0[3])), fmaxf(fmaxf(S1[0], S1[1]), fmaxf(S1[2], S1[3])));
+        // the four lanes (c16, g = 0..3) hold different items of the SAME batch row; m_run is kept equal in all four, so the
+        // cross-lane exchange is only needed on the (rare) rescale path
+        float t2 = tmax * LOG2E;
+        if (__any(t2 > m_run + RESCALE_THR)) {
+            t2 = fmaxf(t2, __shfl_xor(t2, 16, 64));
+            t2 = fmaxf(t2, __shfl_xor(t2, 32, 64));
+            const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ar = __shfl(alpha, 4 * g + j, 64);          // O rows are batch rows 4g + j: their state is in lane 4g + j
+#pragma unroll
+                for (int cb = 0; cb < 10; ++cb) O[cb][j] *= ar;
+            }
+        }
+        const float nm = -m_run;
+        float ls = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S0[j] = __builtin_amdgcn_exp2f(fmaf(S0[j], LOG2E, nm)); ls += S0[j];
+            S1[j] = __builtin_amdgcn_exp2f(fmaf(S1[j], LOG2E, nm)); ls += S1[j];
+        }
+        l_run += ls;
+        bf16x8 ph_, pl_;        // k order of the fragment: items 4g..4g+3 of S block 0, then of S block 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16 h0 = (bf16)S0[j], h1 = (bf16)S1[j];
+            ph_[j] = h0; ph_[4 + j] = h1;
+            pl_[j] = (bf16)(S0[j] - (float)h0); pl_[4 + j] = (bf16)(S1[j] - (float)h1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cb = 0; cb < 10; ++cb) {
+            bf16x4* T_ = ft[cb & 1];
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bh[j] = T_[0][j]; bh[4 + j] = T_[1][j]; bl[j] = T_[2][j]; bl[4 + j] = T_[3][j]; }
+            O[cb] = mfma16_bf16(pl_, bh, O[cb]);
+            O[cb] = mfma16_bf16(ph_, bl, O[cb]);
+            O[cb] = mfma16_bf16(ph_, bh, O[cb]);
+            if (cb + 2 < 10) F3_LOADT(ft[cb & 1], cb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef F3_LOADA
+#undef F3_LOADT
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    if (g == 0) {
+        a.pm[(size_t)range * a.Bp + b0 + c16] = m_run;
+        a.pl[(size_t)range * a.Bp + b0 + c16] = l_tot;
+    }
+    // O[cb][j] = readout of batch row b0 + 4g + j, channel x3_channel(cb, c16) (< 160 always; channels >= H are zero)
+    float* o = a.pO + ((size_t)range * a.Bp + b0) * HP;
+#pragma unroll
+    for (int cb = 0; cb < 10; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[(size_t)(4 * g + j) * HP + x3_channel(cb, c16)] = O[cb][j];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same forward on v_mfma_f32_32x32x16_bf16 with 32 batch rows per wave (128 per workgroup, two workgroups per CU): every LDS
+// operand fragment feeds twice the flops of the 16x16x32 form, whose 16-row waves keep the LDS pipe as busy as the matrix pipe
+// (reads 1,920 + block stores 940 of the 2,880 clocks the MFMAs of a block take on a SIMD; measured 1.16-1.20 ms against
+// 1.05-1.08 ms for k_lx3_fwd).  Register plan (<= 256): rep fragments 80, O 80, S / P 16, one block in flight 24, operand sets 16 / 32.
+#define G3_ROWS 128
+#ifdef G3_STAMP     // diagnostic build only (tools/build_variant.sh ... -DG3_STAMP): per-segment clocks of wave 0 of every workgroup
+__device__ unsigned long long g3_dbg[8 * 1024];
+#define STAMP(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                    __builtin_amdgcn_sched_barrier(0); seg[k_] += t_ - tprev; tprev = t_; }
+extern "C" int ader_dbg_read(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g3_dbg), (size_t)n * 8); }
+#else
+#define STAMP(k_)
+#endif
+template <int HT>
+__global__ __launch_bounds__(256, 2) void k_lx3g(Lx3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [2 buffers][block image]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int nchunk = a.Bp / G3_ROWS;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot / nchunk);           // the row chunks of an item range sit on one XCD: the table block is
+    const int bc = slot % nchunk;                          // fetched from HBM once and served to the others by that XCD's L2
+    if (range >= a.ranges) return;
+    const int H = HT ? HT : a.H;
+    const int N = (bc * G3_ROWS >= a.kd_row0) ? a.Np : a.N;            // columns of this chunk's softmax (distilled rows: first Np)
+    const int nblk_all = (a.N + F3_FB - 1) / F3_FB;
+    const int per = (nblk_all + a.ranges - 1) / a.ranges;
+    const int blk_begin = range * per, blk_end = min((N + F3_FB - 1) / F3_FB, blk_begin + per);
+    const int nb_blocks = max(0, blk_end - blk_begin);
+    const int b0 = bc * G3_ROWS + wave * 32;
+    // pads of both images (k-chunks >= ceil(H/8), bytes between the quads) stay zero: the block stores never touch them
+    for (int i = tid; i < 3 * X3B_IMG_B / 16; i += 256) ((uint4*)smem_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // rep fragments: lane (batch row r32, k-half hh) holds rep[b0 + r32][16 ks + 8 hh + 0..7]
+    bf16x8 rh[10], rl[10];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+        rh[ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + r32) * LDR + 16 * ks + 8 * hh);
+        rl[ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + r32) * LDR + 16 * ks + 8 * hh);
+    }
+    f32x16 O[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    // ---- staging: a block = 32 table rows of H floats.  Round r (0..2) of wave w covers items 8 w.. and k-chunks 8 r..:
+    // lane l -> item + (l & 7), k-chunk + (l >> 3): the 8 lanes of an LDS write group store 8 consecutive 16-byte
+    // slots (conflict-free), and a wave's two 16-byte loads per slot touch 2 cache lines per table row.
+    const int nfull = H >> 3, rem = H & 7;                 // full k-chunks; channels of the partial one (0, 4 or 6: see launcher)
+    // round r of this lane: item it_ (= 8 wave + (lane & 7): a wave stages the same 8 items in every round), k-chunk 8 r + kc0
+    const int it_ = 8 * wave + (lane & 7), kc0 = lane >> 3;
+    const int voff = 4 * (it_ * H + 8 * kc0);              // byte offset inside the block (round r: + 256 r)
+    const int voffp = voff + 4 * (rem - 4);                // second vector of the partial k-chunk: ends with the row
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.emb1, 0, a.vrows * H * 4, 0x00020000);
+    const int dst0 = X3B_KC * kc0 + 16 * it_;               // byte offset inside a plane (round r: + 8 k-chunks)
+#define F3_KC(r_) (8 * (r_) + kc0)
+#define F3_PART(r_) (rem && F3_KC(r_) == nfull)
+#define F3_VALID(r_) (F3_KC(r_) < nfull || F3_PART(r_))
+    f32x4_t sa[F3_RND], sb[F3_RND];
+    // Block loads through a buffer descriptor of the table (base in scalar registers, ONE 32-bit per-lane offset, the block's
+    // offset as the scalar offset, the round's as the instruction's immediate): no 64-bit per-lane pointers, and rows beyond the
+    // table's last one (only in its last block; their items are >= N: outside the softmax) come back as zeros from the hardware
+    // range check.  Lanes without a k-chunk read whatever follows their row (never stored).  NOTHING is selected on the loaded data
+    // here -- a select would make hipcc wait for each load right behind its issue.
+#define F3_LOAD(blk_)                                                                                     \
+    {                                                                                                     \
+        const int so_ = (blk_) * (F3_FB * 4) * H;              /* byte offset of the block (< 2^31: checked by the launcher) */ \
+        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
+            const u32x4_t va_ = __builtin_amdgcn_raw_buffer_load_b128(trs, voff + 256 * r, so_, 0);         \
+            const u32x4_t vb_ = __builtin_amdgcn_raw_buffer_load_b128(trs, (F3_PART(r) ? voffp : voff + 16) + 256 * r, so_, 0); \
+            sa[r] = __builtin_bit_cast(f32x4_t, va_); sb[r] = __builtin_bit_cast(f32x4_t, vb_);           \
+        }                                                                                                 \
+    }
+    // hi = bf16(x), lo = bf16(x - hi), 8 channels -> one 16-byte slot per plane
+#define F3_STORE(buf_)                                                                                    \
+    {                                                                                                     \
+        unsigned char* dst_ = smem_raw + (buf_) * X3B_IMG_B;                                               \
+        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
+            float x_[8];                                                                                  \
+            x_[0] = sa[r][0]; x_[1] = sa[r][1]; x_[2] = sa[r][2]; x_[3] = sa[r][3];                       \
+            if (F3_PART(r)) {       /* rem = 6: channels 4,5 are elements 2,3 of the shifted vector; rem = 4: none */ \
+                x_[4] = (rem == 6) ? sb[r][2] : 0.f; x_[5] = (rem == 6) ? sb[r][3] : 0.f; x_[6] = 0.f; x_[7] = 0.f; \
+            } else { x_[4] = sb[r][0]; x_[5] = sb[r][1]; x_[6] = sb[r][2]; x_[7] = sb[r][3]; }            \
+            bf16x8 h_, l_;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
+            if (F3_VALID(r)) {                                                                            \
+                *(bf16x8*)(dst_ + dst0 + 8 * X3B_KC * r) = h_;                                            \
+                *(bf16x8*)(dst_ + X3B_PLANE_B + dst0 + 8 * X3B_KC * r) = l_;                              \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    // per-lane byte offsets into a block image: row read of (item r32, k-half hh); transposed read of (item 4 hh + q4, channels
+    // 16 g1 + 4 p4.. of a 32-channel block = k-chunks 2 g1 + (p4 >> 1) of its four)
+    const int a_off = X3B_KC * hh + 16 * r32;
+    const int t_off = X3B_KC * (2 * g1 + (p4 >> 1)) + 16 * (4 * hh + q4) + 8 * (p4 & 1);
+    // three LDS buffers: block i is read from buffer i % 3 while block i + 1 (stored during iteration i - 1) waits in the next one and
+    // block i + 2 -- requested at the head of iteration i, converted and stored between its two MFMA phases -- goes into the third:
+    // the 24 staging registers are live only under the S^T phase, where the operand sets are small
+    if (nb_blocks > 0) F3_LOAD(blk_begin);
+    __syncthreads();                                       // zero fill done
+    if (nb_blocks > 0) F3_STORE(0);
+    if (nb_blocks > 1) { F3_LOAD(blk_begin + 1); F3_STORE(1); }
+    int bcur = 0;                                          // i % 3
+#ifdef G3_STAMP
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#endif
+    for (int i = 0; i < nb_blocks; ++i) {
+        STAMP(0)
+        __syncthreads();                                   // blocks i and i + 1 are in LDS; every wave is done with block i - 1
+        STAMP(1)
+        const bool more = i + 2 < nb_blocks;
+        if (more) F3_LOAD(blk_begin + i + 2);
+        STAMP(2)
+        const char* Bh = (const char*)(smem_raw + bcur * X3B_IMG_B);
+        const int bnew = bcur == 0 ? 2 : bcur - 1;         // (i + 2) % 3
+        const int i0 = (blk_begin + i) * F3_FB;
+        // S^T = 32 items x 32 batch rows: A = table rows (lane: item r32, k = 8 hh..8 hh + 7 of the k-step), B = rep fragments
+#define G3_LOADA(set_, ks_)                                                                               \
+        { const char* ap_ = Bh + a_off + 2 * X3B_KC * (ks_);                                              \
+          set_[0] = *(const bf16x8*)ap_; set_[1] = *(const bf16x8*)(ap_ + X3B_PLANE_B); }
+        // transposed reads of the 32-channel block nb: {hi: items 4hh.., 8 + 4hh.., 16 + 4hh.., 24 + 4hh..; lo: the same}
+#define G3_LOADT(set_, nb_, pl_)                                                                          \
+        { const bf16* tp_ = (const bf16*)(Bh + t_off + 4 * X3B_KC * (nb_) + (pl_) * X3B_PLANE_B);            \
+          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 64); set_[2] = tr_read(tp_ + 128); set_[3] = tr_read(tp_ + 192); }
+        f32x16 S;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) S[j] = 0.0f;
+        bf16x8 fa[2][2];
+        G3_LOADA(fa[0], 0);
+        G3_LOADA(fa[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) {
+            bf16x8* A_ = fa[ks & 1];                             // {hi, lo}
+            S = mfma_bf16(A_[1], rh[ks], S);
+            S = mfma_bf16(A_[0], rl[ks], S);
+            S = mfma_bf16(A_[0], rh[ks], S);
+            if (ks + 2 < 10) G3_LOADA(fa[ks & 1], ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP(3)
+        if (more) F3_STORE(bnew);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(4)
+        // the first transposed reads of the readout do not depend on S: in flight under the softmax section
+        bf16x4 ft[3][4];        // half sets: {items 4hh.., 8 + 4hh.., 16 + 4hh.., 24 + 4hh..} of ONE plane; hi, lo, hi, lo ...
+        G3_LOADT(ft[0], 0, 0);
+        G3_LOADT(ft[1], 0, 1);
+        G3_LOADT(ft[2], 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i0 + F3_FB > N) {                              // tail block: items >= N are outside the softmax
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (i0 + acc_row(j, hh) >= N) S[j] = -INFINITY;
+        }
+        float tmax = S[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, S[j]);
+        // the two half-waves of a lane pair (l, l + 32) hold different items of the SAME batch row; m_run is kept equal in both, so
+        // the cross-half exchange is only needed on the (rare) rescale path
+        float t2 = tmax * LOG2E;
+        if (__any(t2 > m_run + RESCALE_THR)) {
+            t2 = fmaxf(t2, __shfl_xor(t2, 32, 64));
+            const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float ar = __shfl(alpha, acc_row(j, hh), 64);     // O rows are batch rows
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) O[nb][j] *= ar;
+            }
+        }
+        const float nm = -m_run;
+        float ls = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { S[j] = __builtin_amdgcn_exp2f(fmaf(S[j], LOG2E, nm)); ls += S[j]; }
+        l_run += ls;
+        const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);
+        bf16x8 pl0, pl1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pl0[j] = (bf16)(S[j] - (float)pa0[j]); pl1[j] = (bf16)(S[8 + j] - (float)pa1[j]); }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(5)
+#pragma unroll
+        for (int hs = 0; hs < 10; ++hs) {                        // half step: (channel block nb = hs >> 1, plane hs & 1)
+            bf16x4* T_ = ft[hs % 3];
+            bf16x8 v0, v1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[j] = T_[0][j]; v0[4 + j] = T_[1][j]; v1[j] = T_[2][j]; v1[4 + j] = T_[3][j]; }
+            if ((hs & 1) == 0) {                                 // hi plane of the table: P lo and P hi
+                O[hs >> 1] = mfma_bf16(pl0, v0, O[hs >> 1]);
+                O[hs >> 1] = mfma_bf16(pl1, v1, O[hs >> 1]);
+                O[hs >> 1] = mfma_bf16(pa0, v0, O[hs >> 1]);
+                O[hs >> 1] = mfma_bf16(pa1, v1, O[hs >> 1]);
+            } else {                                             // lo plane: P hi
+                O[hs >> 1] = mfma_bf16(pa0, v0, O[hs >> 1]);
+                O[hs >> 1] = mfma_bf16(pa1, v1, O[hs >> 1]);
+            }
+            if (hs + 3 < 10) G3_LOADT(ft[hs % 3], (hs + 3) >> 1, (hs + 3) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bcur = bcur == 2 ? 0 : bcur + 1;
+        STAMP(6)
+    }
+#ifdef G3_STAMP
+    if (tid == 0 && blockIdx.x < 1024) { for (int k_ = 0; k_ < 8; ++k_) g3_dbg[blockIdx.x * 8 + k_] = seg[k_]; g3_dbg[blockIdx.x * 8 + 7] = nb_blocks; }
+#endif
+#undef G3_LOADA
+#undef G3_LOADT
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (hh == 0) {
+        a.pm[(size_t)range * a.Bp + b0 + r32] = m_run;
+        a.pl[(size_t)range * a.Bp + b0 + r32] = l_tot;
+    }
+    float* o = a.pO + ((size_t)range * a.Bp + b0) * HP;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r32] = O[nb][j];
+}
+
+// item ranges of k_lx3f per 64-row chunk: a multiple of 8 (blocks b and b + 8 share an XCD: the chunks of a range are placed on
+// one), as many as keep ranges * chunks within the 768 resident workgroups (3 per CU), at least one 32-item block each
+int lx3f_ranges(int N, int Bp) {
+    const int nblk = (N + F3_FB - 1) / F3_FB;
+    const int nchunk = Bp / F3_ROWS;
+    int r = (768 / (nchunk < 1 ? 1 : nchunk)) / 8 * 8;
+    if (r > (nblk + 7) / 8 * 8) r = (nblk + 7) / 8 * 8;
+    if (r < 8) r = 8;
+    return r;
+}
+bool lx3f_supports(int H) { return (H & 1) == 0 && H >= 8 && H <= HP && ((H & 7) == 0 || (H & 7) == 4 || (H & 7) == 6); }
+
+// x.ranges must be lx3f_ranges(x.N, x.Bp); Bp % 64 == 0
+int lx3g_launch(const Lx3Args& x, void* stream) {
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lx3g<150>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3B_IMG_B);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_lx3g<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3B_IMG_B);
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    if ((long)x.vrows * x.H * 4 >= (1l << 31)) return -2;          // the block offsets of the buffer loads are 32-bit
+    if (x.H == 150) hipLaunchKernelGGL(k_lx3g<150>, dim3(x.ranges * (x.Bp / G3_ROWS)), dim3(256), 3 * X3B_IMG_B, (hipStream_t)stream, x);
+    else hipLaunchKernelGGL(k_lx3g<0>, dim3(x.ranges * (x.Bp / G3_ROWS)), dim3(256), 3 * X3B_IMG_B, (hipStream_t)stream, x);
+    return 0;
+}
+
+int lx3f_launch(const Lx3Args& x, void* stream) {
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lx3f<150>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_IMG_B);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_lx3f<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_IMG_B);
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    if ((long)x.vrows * x.H * 4 >= (1l << 31)) return -2;          // the block offsets of the buffer loads are 32-bit
+    if (x.H == 150) hipLaunchKernelGGL(k_lx3f<150>, dim3(x.ranges * (x.Bp / F3_ROWS)), dim3(256), 2 * X3_IMG_B, (hipStream_t)stream, x);
+    else hipLaunchKernelGGL(k_lx3f<0>, dim3(x.ranges * (x.Bp / F3_ROWS)), dim3(256), 2 * X3_IMG_B, (hipStream_t)stream, x);
+    return 0;
+}

@@ -23,21 +23,11 @@
 // over the tile's flat [64*H] block of theta/m/v in 16-byte vectors) is the one of k_tab16 without the shadow rows.  gfx950 only.
 #include <stdlib.h>
 #include "lbf_common.h"
+#include "x3_image.h"
 #include "../../include/ader_hip.h"
 
 #define TI 64                      // table rows per workgroup
 #define X3_CH 32                   // batch rows per rep chunk
-// LDS image of one plane of a chunk: 20 k-chunks (8 channels = 16 B per row) of [32 rows][16 B] = 512 B each, in quads of four:
-//   byte offset of k-chunk kc = 2176 (kc >> 2) + 1152 ((kc >> 1) & 1) + 512 (kc & 1)
-// k-chunks kc, kc+1 (kc even) are 512 B apart: the ds_read_b128 row read of lane (row c16, k-group g) at k-chunk 4 ks + g puts the
-// 16 lanes of a read group (all 16 rows, two adjacent g) on 16 different 16-byte slots; k-chunks kc, kc+2 are 1152 B = 128 (mod 256)
-// apart: the transposed read of a 4-row x 16-channel block built from k-chunks (kc, kc+2) covers all 64 banks once per 32 lanes.
-#define X3_QUAD 2176
-#define X3_PLANE_B (5 * X3_QUAD)   // bytes of one plane image (10,880)
-#define X3_IMG_B 22528             // bytes of a chunk image in memory and in LDS: hi plane, lo plane, zero padding to 22 KiB
-#define X3_BUF (X3_IMG_B / 2)      // bf16 elements of one LDS buffer
-#define X3_PIECES (X3_IMG_B / 1024)
-__host__ __device__ __forceinline__ constexpr int x3_kc_off(int kc) { return X3_QUAD * (kc >> 2) + 1152 * ((kc >> 1) & 1) + 512 * (kc & 1); }
 #define TM_LIST 18                 // ints per list in a tile record: [k0, k1, 8 x (id, row)]
 #define NVEC 10                    // 16-byte vectors per thread covering a tile: 10 * 1024 floats >= 64 * 160
 
@@ -51,11 +41,6 @@ __host__ __device__ __forceinline__ constexpr int x3_kc_off(int kc) { return X3_
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
 
 __device__ int x3_cu_arrivals[4096];
 
