@@ -34,33 +34,47 @@
 #define SPV 3                      // input-embedding gradient rows prefetched under the GEMM phase
 #define HEAVY_N 32                 // a bucket with more entries than this in either list takes the heavy path
 #define HVB 16                     // gradient rows in flight per thread on the heavy path
-#define SPB 8                      // sparse-list entries per batch of the optimiser phase (loads of a batch are independent)
+#define SPB 4                      // sparse-list entries per batch of the optimiser phase (loads of a batch are independent)
 #ifndef AV
 #define AV 6                       // 16-byte vectors per thread and load round of the optimiser phase (x theta, m, v)
 #endif
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(8))) F16B { f32x4_t v; };       // 16-byte vector at an 8-byte aligned address
 
 __device__ int x3_cu_arrivals[4096];
+#ifdef T3_STAMP     // diagnostic build only (tools/build_variant.sh ... -DT3_STAMP): per-segment clocks of wave 0 of every workgroup
+__device__ unsigned long long t3_dbg[12 * 1024];
+#define STAMP(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                    __builtin_amdgcn_sched_barrier(0); seg[k_] += t_ - tprev; tprev = t_; }
+extern "C" int ader_dbg_read(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(t3_dbg), (size_t)n * 8); }
+#else
+#define STAMP(k_)
+#endif
 
-// One chunk image (22 KiB, contiguous in memory) -> LDS buffer, as 22 LDS-DMA pieces of 1 KiB dealt round-robin to the 4 waves.
+// One chunk image (22 KiB, contiguous in memory) -> LDS buffer, as 22 LDS-DMA pieces of 1 KiB.
 // The DMA is issued from inline asm ON PURPOSE: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
 // s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 it cannot tell apart from the destination -- in the middle of the
 // chunk, which drained the prefetch half a chunk after it was issued.  Hidden from the compiler, the pieces are waited for by the
 // explicit vmcnt(0) at the head of the next chunk only (cdna_hip_programming.md 5.7: M0 saved, written and restored in ONE statement).
-__device__ __forceinline__ void x3_glds16(const char* gsrc, unsigned lds_dst) {
+// (scalar base + one 32-bit per-lane offset: no vector instruction per piece)
+__device__ __forceinline__ void x3_glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// wave w moves pieces [6 w, 6 w + 6) of the 22 (wave 3: four): one scalar branch per chunk
 __device__ __forceinline__ void x3_dma_chunk(const char* __restrict__ img, int c, bf16* buf, int wave_u, int lane) {
-    const char* src0 = img + (size_t)c * X3_IMG_B + 16 * lane;
-    const unsigned dst0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)buf;
+    const char* src0 = img + (size_t)c * X3_IMG_B + 6144 * wave_u;          // scalar
+    const unsigned dst0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)buf) + 6144 * wave_u;
+    const unsigned vo = 16 * lane;
 #pragma unroll
-    for (int i = 0; i < (X3_PIECES + 3) / 4; ++i) {
-        const int p = wave_u + 4 * i;                       // wave-uniform
-        if (p < X3_PIECES) x3_glds16(src0 + 1024 * p, __builtin_amdgcn_readfirstlane(dst0 + 1024 * p));
+    for (int i = 0; i < 4; ++i) x3_glds16(src0 + 1024 * i, vo, dst0 + 1024 * i);
+    if (wave_u < 3) {
+        x3_glds16(src0 + 4096, vo, dst0 + 4096);
+        x3_glds16(src0 + 5120, vo, dst0 + 5120);
     }
 }
 
@@ -75,22 +89,6 @@ __global__ __launch_bounds__(256) void k_x3_rep_image(const bf16* __restrict__ r
     const int row = t / 20, kc = t - row * 20;              // consecutive threads: consecutive 16-byte pieces of a source row
     const bf16* src = (plane ? rep_lo : rep_hi) + (size_t)(c * X3_CH + row) * LDR + 8 * kc;
     *(uint4*)(img + (size_t)c * X3_IMG_B + plane * X3_PLANE_B + x3_kc_off(kc) + 16 * row) = *(const uint4*)src;
-}
-
-// one round of theta / m / v vectors of the tile's flat [64*H] block: all loads issued before any math or store
-#define ROUND_LOAD()                                                                                       \
-_Pragma("unroll") for (int u = 0; u < AV; ++u) {                                                           \
-    E[u] = e;                                                                                              \
-    NV[u] = (e + 3 < n_el) ? 2 : ((e + 1 < n_el) ? 1 : 0);                                                 \
-    if (NV[u] == 2) {                                                                                      \
-        P[u] = *(const f32x4_t*)(gp + e); M[u] = *(const f32x4_t*)(gm + e); V[u] = *(const f32x4_t*)(gv + e); \
-        if (EXTRA) G[u] = __builtin_nontemporal_load((const f32x4_t*)(gx + e));                            \
-    } else if (NV[u] == 1) {                                                                               \
-        if (EXTRA) { const f32x2_t g_ = *(const f32x2_t*)(gx + e); G[u] = (f32x4_t){g_[0], g_[1], 0.f, 0.f}; } \
-        const f32x2_t p = *(const f32x2_t*)(gp + e), m = *(const f32x2_t*)(gm + e), v = *(const f32x2_t*)(gv + e); \
-        P[u] = (f32x4_t){p[0], p[1], 0.f, 0.f}; M[u] = (f32x4_t){m[0], m[1], 0.f, 0.f}; V[u] = (f32x4_t){v[0], v[1], 0.f, 0.f}; \
-    }                                                                                                      \
-    e += 1024;                                                                                             \
 }
 
 template <bool EXTRA, bool KD>
@@ -111,11 +109,10 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     const int rows_avail = min(TI, a.vrows - tile0);
     const int n_av = rows_avail > 0 ? rows_avail * H : 0;
     const float* __restrict__ gsrc = a.emb1 + (size_t)tile0 * H;
-    // the tile starts 0 or 8 bytes past a 16-byte boundary (H even): `head` floats are peeled so that vector u of thread t,
-    // floats e = head + 4 t + 1024 u, is 16-byte aligned in memory AND in LDS (the LDS image starts at the same phase)
-    const int ph = (int)(((uintptr_t)gsrc & 15) >> 2);
-    const int head = ph ? 4 - ph : 0;
-    float* T_l = (float*)(smem_raw + 4 * ph);                   // theta tile, flat [64*H]
+#ifdef T3_STAMP
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#endif
     // ---- phase stagger of the first generation of workgroups (speed only): all tiles cost the same, so the three
     // workgroups of a CU would run their matrix phases together and their HBM phases together for the whole launch
     if ((a.ko >> 16) && blockIdx.x < 768) {
@@ -142,18 +139,25 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             while (__builtin_amdgcn_s_memrealtime() - t0 < dt) __builtin_amdgcn_s_sleep(64);
         }
     }
-    // ---- theta tile -> LDS (zero beyond the table's last row); the per-row constants and the tile's list record beside it
+    // ---- the first rep chunk is requested before anything else; the per-row constants and the tile's list record go to LDS
+    const char* img = (const char*)a.rep_img;
+    const int nch = a.Bp / X3_CH;
+    if (!(a.ko & 2)) x3_dma_chunk(img, 0, R_l, wave, lane);
+    // ---- operand fragments straight from memory: lane (item c16 of this wave's 16, k-group g) holds E[item][32 ks + 8 g + 0..7] as
+    // hi + lo.  Two 16-byte loads per k-step at 8-byte aligned addresses; rows beyond the table's last one read zeros (range check);
+    // channels >= H of the last k-step read what follows the row -- finite parameters that only ever meet the zero K-padding of rep.
+    // (The round-3a kernel passed the tile through LDS: load, store, barrier, cut, barrier, and only then the first rep chunk --
+    // three dependent latencies at the head of every tile.)
+    bf16x8 e_hi[5], e_lo[5];
     {
-        f32x4_t t4[NVEC];
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)gsrc, 0, (unsigned)n_av * 4u, 0x00020000);
+        const int vt = 4 * ((wave * 16 + c16) * H + 8 * g);
+        f32x4_t x0[5], x1[5];
 #pragma unroll
-        for (int u = 0; u < NVEC; ++u) {
-            const int e = head + 4 * tid + 1024 * u;
-            t4[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (e + 3 < n_av) t4[u] = *(const f32x4_t*)(gsrc + e);
-            else if (e + 1 < n_av) { const f32x2_t t2 = *(const f32x2_t*)(gsrc + e); t4[u][0] = t2[0]; t4[u][1] = t2[1]; }
+        for (int ks = 0; ks < 5; ++ks) {
+            x0[ks] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rt, vt, 128 * ks, 0));
+            x1[ks] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rt, vt, 128 * ks + 16, 0));
         }
-        f32x2_t h2 = (f32x2_t){0.f, 0.f};
-        if (head && tid == 0 && n_av > 0) h2 = *(const f32x2_t*)gsrc;
         for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
         if (KD) {
             for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
@@ -165,54 +169,45 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
         }
         if (tid < 2 * TM_LIST) meta_l[tid] = f.tile_meta[(size_t)tile * (2 * TM_LIST) + tid];
 #pragma unroll
-        for (int u = 0; u < NVEC; ++u) {
-            const int e = head + 4 * tid + 1024 * u;
-            if (e < TI * H) {
-                if (e + 3 < TI * H) *(f32x4_t*)(T_l + e) = t4[u];
-                else *(f32x2_t*)(T_l + e) = (f32x2_t){t4[u][0], t4[u][1]};
+        for (int ks = 0; ks < 5; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // (channels >= H: zero, so that the cut equals the one of a zero-padded row whatever follows the row in memory)
+                const bool in0 = 32 * ks + 8 * g + j < H, in1 = 32 * ks + 8 * g + 4 + j < H;
+                const float v0 = in0 ? x0[ks][j] : 0.0f, v1 = in1 ? x1[ks][j] : 0.0f;
+                const bf16 h0 = (bf16)v0, h1 = (bf16)v1;
+                e_hi[ks][j] = h0; e_hi[ks][4 + j] = h1;
+                e_lo[ks][j] = (bf16)(v0 - (float)h0); e_lo[ks][4 + j] = (bf16)(v1 - (float)h1);
             }
         }
-        if (head && tid == 0) *(f32x2_t*)T_l = h2;
     }
-    __syncthreads();
+    STAMP(0)
+    __syncthreads();                                            // off_l / meta_l are in LDS
+    STAMP(1)
     // the first input-embedding gradient rows of the tile (thread c holds column c), requested now, used after the GEMM
     float spv[SPV];
 #pragma unroll
-    for (int i = 0; i < SPV; ++i)
-        spv[i] = (tid < H && meta_l[0] + i < meta_l[1]) ? f.sp_src[(size_t)meta_l[3 + 2 * i] * H + tid] * f.sp_scale : 0.0f;
-    // ---- operand fragments: lane (item c16 of this wave's 16, k-group g) holds E[item][32 ks + 8 g + 0..7] as hi + lo
-    bf16x8 e_hi[5], e_lo[5];
-    {
-        const float* row = T_l + (wave * 16 + c16) * H;
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                const int col = 32 * ks + 8 * g + 2 * j2;
-                f32x2_t x = (f32x2_t){0.f, 0.f};
-                if (col < H) x = *(const f32x2_t*)(row + col);
-                const bf16 h0 = (bf16)x[0], h1 = (bf16)x[1];
-                e_hi[ks][2 * j2] = h0; e_hi[ks][2 * j2 + 1] = h1;
-                e_lo[ks][2 * j2] = (bf16)(x[0] - (float)h0); e_lo[ks][2 * j2 + 1] = (bf16)(x[1] - (float)h1);
-            }
-        }
+    for (int i = 0; i < SPV; ++i) {     // unconditional loads (row 0, column 0 when there is no entry): a load under a branch is waited
+        const bool on = tid < H && meta_l[0] + i < meta_l[1];        // for at the end of its branch -- three round trips in a row
+        spv[i] = f.sp_src[on ? (size_t)meta_l[3 + 2 * i] * H + tid : 0] * (on ? f.sp_scale : 0.0f);
     }
-    __syncthreads();                                            // every wave has cut its fragments: the area is free for rep
+    STAMP(2)
+    STAMP(3)
     f32x4v dE[10];
 #pragma unroll
     for (int cb = 0; cb < 10; ++cb) dE[cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    const int nch = a.Bp / X3_CH;
     const int q4 = c16 >> 2, p4 = c16 & 3;
-    const char* img = (const char*)a.rep_img;
     // per-lane byte offsets into a chunk image: row read of (row c16, k-group g); transposed read of (row 4g + q4, 4 channels p4)
     const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
     const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
-    x3_dma_chunk(img, 0, R_l, wave, lane);
+    // (s_setprio 2 around this loop -- matrix phases ahead of the other workgroups' vector phases -- measured 2-3 % SLOWER: it starves
+    //  the phases that request the next tile's memory)
     for (int c = 0; c < ((a.ko & 2) ? 0 : nch); ++c) {
         // this wave's pieces of chunk c have landed and its LDS reads of chunk c-1 are done; after the barrier that holds for every
         // wave, so chunk c can be read and the other buffer (chunk c-1's) can be refilled
+        STAMP(4)
         if (!(a.ko & 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c + 1 < nch && !(a.ko & 4)) x3_dma_chunk(img, c + 1, R_l + ((c + 1) & 1) * X3_BUF, wave, lane);
+        STAMP(5)
         const char* Bh = (const char*)(R_l + (c & 1) * X3_BUF);
         const int b0 = c * X3_CH;
         // KD rows: this lane's 8 teacher logits (item it0 + c16, batch rows b0 + 16 rb + 4 g + j), requested ahead of the MFMAs
@@ -242,6 +237,9 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
         X3_LOADA(fa[0], 0);
         X3_LOADA(fa[1], 1);
         __builtin_amdgcn_sched_barrier(0);
+        // (the next chunk's DMA is issued behind the first operand reads: its scalar issue sequence runs under their latency)
+        if (c + 1 < nch && !(a.ko & 4)) x3_dma_chunk(img, c + 1, R_l + ((c + 1) & 1) * X3_BUF, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
             bf16x8* A_ = fa[ks & 1];                             // {ah0, al0, ah1, al1}
@@ -254,6 +252,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             if (ks + 2 < 5) X3_LOADA(fa[ks & 1], ks + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(6)
         // the first transposed reads of the P^T.rep phase do not depend on S: in flight under the exp2 section
         bf16x4 ft[3][4];
         X3_LOADT(ft[0], 0);
@@ -288,6 +287,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             pl_[j] = (bf16)(S0[j] - (float)h0); pl_[4 + j] = (bf16)(S1[j] - (float)h1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(7)
 #pragma unroll
         for (int cb = 0; cb < 10; ++cb) {
             bf16x4* T_ = ft[cb % 3];
@@ -311,16 +311,33 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     float* __restrict__ gp = f.emb1 + tq * H;
     float* __restrict__ gm = f.m1 + tq * H;
     float* __restrict__ gv = f.v1 + tq * H;
-    const int head2 = (((uintptr_t)gp) & 15) ? 2 : 0;
-    int e = head2 + 4 * tid;
-    f32x4_t P[AV], M[AV], V[AV], G[EXTRA ? AV : 1];
     const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)tile0 * H : nullptr;
-    int E[AV], NV[AV];
+    // theta / m / v of the tile through buffer descriptors (base and size in scalar registers, one 32-bit per-lane offset, the
+    // vector index as the scalar offset): vector u of thread t = floats 4 t + 1024 u of the block; floats >= n_el (the table's last,
+    // partial tile; vectors 9.375.. of a full one) are range-checked away by the hardware, loads AND stores -- no per-vector branch.
+    // ALL loads of the tile are in flight at once (m, v requested before the dE staging and the sparse terms, theta right behind
+    // the staging, when the accumulators have left their registers): the phase waits out ONE memory latency instead of one per
+    // round (stamps: 4-5 us each under load).
+    const unsigned nbytes = (unsigned)n_el * 4u;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)gp, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)gm, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)gv, 0, nbytes, 0x00020000);
+    const int vo = 16 * tid;
+    f32x4_t P[NVEC], M[NVEC], V[NVEC];
+#define LOAD_MV()                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NVEC; ++u) {                                                     \
+        M[u] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rm, vo, 4096 * u, 0));     \
+        V[u] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 4096 * u, 0));     \
+    }
+#define LOAD_P()                                                                                           \
+    _Pragma("unroll") for (int u = 0; u < NVEC; ++u)                                                       \
+        P[u] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp, vo, 4096 * u, 0));
     // A bucket that holds a hot item (Zipf ids: hundreds of entries) takes the HEAVY path below: its (id, row) lists are fetched
     // cooperatively, 256 entries per round trip, and the gradient rows HVB at a time -- with the optimiser loads requested AFTER
     // the sparse terms, so that the registers are free for the deeper batches (a workgroup-uniform choice; rare tiles).
     const bool heavy = (meta_l[1] - meta_l[0] > HEAVY_N) || (meta_l[TM_LIST + 1] - meta_l[TM_LIST] > HEAVY_N);
-    if (!heavy) { ROUND_LOAD(); }   // first round of theta/m/v: requested BEFORE the dE staging and the sparse terms
+    STAMP(4)
+    if (!heavy) { LOAD_MV(); }
     lds_only_barrier();             // every wave is done with the last rep chunk
 #pragma unroll
     for (int cb = 0; cb < 10; ++cb) {
@@ -331,6 +348,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
         }
     }
     lds_only_barrier();
+    STAMP(8)
     {
         // sparse terms of the tile: item ids [tile0+1, tile0+65).  Thread c owns column c of every row.
         const int id_lo = tile0 + 1, id_hi = min(tile0 + TI, N) + 1;
@@ -427,42 +445,48 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             }
         }
     }
-    if (heavy) { ROUND_LOAD(); }
+    __builtin_amdgcn_sched_barrier(0);     // (theta after the sparse terms: their batches need the registers)
+    if (heavy) { LOAD_MV(); }
+    LOAD_P();
     lds_only_barrier();
+    STAMP(9)
+    // TF ApplyAdam (ADER.py:96): m += (g-m)(1-b1); v += (g*g-v)(1-b2); theta -= lr_t*m/(sqrt(v)+eps).  The square root and the
+    // division use the hardware's v_sqrt_f32 / v_rcp_f32 (<= 1 ulp each; the update differs from the correctly rounded one by
+    // < 4e-7 of ITSELF): the IEEE sequences cost ~27 vector instructions per element -- 1,300 of the 3,900 a wave issues per
+    // tile, and it is vector ISSUE (matrix + vector instructions of three waves on one SIMD) that bounds this kernel (stamps and
+    // counters: DESIGN.md section 6).  ADER_EXACT_DIV restores the correctly rounded forms.
+#ifdef ADER_EXACT_DIV
 #define ADAM1(p_, m_, v_, g_)                                                                              \
     { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2; p_ -= (m_ * f.lr_t) / (sqrtf(v_) + f.eps); }
-    if (head2 && tid == 0 && n_el > 0) {                  // elements 0,1 (row 0, columns 0,1)
-        f32x2_t p = *(const f32x2_t*)gp, m = *(const f32x2_t*)gm, v = *(const f32x2_t*)gv;
-        float2 g2 = *(const float2*)F_l;
-        if (EXTRA) { g2.x += gx[0]; g2.y += gx[1]; }
-        ADAM1(p[0], m[0], v[0], g2.x); ADAM1(p[1], m[1], v[1], g2.y);
-        *(f32x2_t*)gp = p; *(f32x2_t*)gm = m; *(f32x2_t*)gv = v;
-    }
-#pragma unroll 1
-    for (int k0 = 0; k0 < NVEC; k0 += AV) {               // 10 * 1024 floats >= 64 * 150; round 0 is already in flight
-        if (k0) { ROUND_LOAD(); }
+#else
+#define ADAM1(p_, m_, v_, g_)                                                                              \
+    { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2;                                       \
+      p_ -= (m_ * f.lr_t) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v_) + f.eps); }
+#endif
 #pragma unroll
-        for (int u = 0; u < AV; ++u) {
-            if (NV[u] == 0) continue;
-            float2 ga = *(const float2*)(F_l + E[u]);
-            float2 gb = (NV[u] == 2) ? *(const float2*)(F_l + E[u] + 2) : make_float2(0.f, 0.f);
-            if (EXTRA) { ga.x += G[u][0]; ga.y += G[u][1]; gb.x += G[u][2]; gb.y += G[u][3]; }
-            f32x4_t p = P[u], m = M[u], v = V[u];
-            ADAM1(p[0], m[0], v[0], ga.x); ADAM1(p[1], m[1], v[1], ga.y);
-            ADAM1(p[2], m[2], v[2], gb.x); ADAM1(p[3], m[3], v[3], gb.y);
-            if (NV[u] == 2) {
-                // theta/m/v of this tile are not touched again this step: keep them out of the caches
-                __builtin_nontemporal_store(p, (f32x4_t*)(gp + E[u]));
-                __builtin_nontemporal_store(m, (f32x4_t*)(gm + E[u]));
-                __builtin_nontemporal_store(v, (f32x4_t*)(gv + E[u]));
-            } else {
-                *(f32x2_t*)(gp + E[u]) = (f32x2_t){p[0], p[1]};
-                *(f32x2_t*)(gm + E[u]) = (f32x2_t){m[0], m[1]};
-                *(f32x2_t*)(gv + E[u]) = (f32x2_t){v[0], v[1]};
+    for (int u = 0; u < NVEC; ++u) {
+        const int e = 4 * tid + 1024 * u;
+        if (e < TI * H) {                                  // (the staging tile ends there; vector 9 exists for 96 threads)
+            f32x4_t g4 = *(const f32x4_t*)(F_l + e);
+            if (EXTRA) {
+                const f32x4_t x4 = (e + 3 < n_el) ? ((const F16B*)(gx + e))->v : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                g4 += x4;
             }
+            f32x4_t p = P[u], m = M[u], v = V[u];
+            ADAM1(p[0], m[0], v[0], g4[0]); ADAM1(p[1], m[1], v[1], g4[1]);
+            ADAM1(p[2], m[2], v[2], g4[2]); ADAM1(p[3], m[3], v[3], g4[3]);
+            // theta/m/v of this tile are not touched again this step: keep them out of the caches (aux 2 = nt)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, p), rp, vo, 4096 * u, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rm, vo, 4096 * u, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rv, vo, 4096 * u, 2);
         }
     }
 #undef ADAM1
+#ifdef T3_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(10)
+    if (tid == 0 && blockIdx.x % 16 == 5 && blockIdx.x / 16 < 1024) for (int k_ = 0; k_ < 12; ++k_) t3_dbg[(blockIdx.x / 16) * 12 + k_] = seg[k_];
+#endif
 }
 
 // ============================================================================================= launch (C ABI: table_update.hip)
