@@ -65,6 +65,8 @@ _SIGS = {
     "ader_scatter_owned": [P, P, I, I, I, I, I, P, P, P],
     "ader_lbf_fwd_shard": [P, P, I, I, I, I, I, I, P, P, P, P, P],
     "ader_lx3_prep": [P, P, P, I, I, I, P],
+    "ader_lx3_fwd_shard": [P, P, P, I, I, I, I, I, I, P, P, P, P, P],
+    "ader_lx3_merge_parts": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "ader_lx3_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_tab_grad": [P, P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_tab_grad_kd": [P, P, P, I, I, I, I, I, I, P, P, P, P, L, P, P, P, P],

@@ -464,8 +464,10 @@ __global__ __launch_bounds__(640) void k_lbf_combine_partial(LbfArgs a, float* _
 // Cross-rank merge for one batch row of THIS rank: parts [W][Bp][PART_LD] (slice i = the partials rank i computed over its
 // items) -> lse (natural log), backward offset, loss row, dRep row.  e_lab: fp32 table row of the label (fetched from its
 // owner); it enters as bf16(e_lab), i.e. exactly the shadow row the MFMA path multiplies.  One wave per row.
+template <bool X3>      // X3: rep_f = fp32 representations [B,H] and the label row enters in fp32 (float32-grade target logit)
 __global__ __launch_bounds__(256) void k_lbf_merge_parts(const float* __restrict__ parts, int W, int Bp, int B, int H,
                                                          const float* __restrict__ e_lab, const bf16* __restrict__ rep_bf,
+                                                         const float* __restrict__ rep_f,
                                                          const float* __restrict__ wrow, float* __restrict__ lse,
                                                          float* __restrict__ off, float* __restrict__ rowloss,
                                                          float* __restrict__ drep) {
@@ -494,8 +496,8 @@ __global__ __launch_bounds__(256) void k_lbf_merge_parts(const float* __restrict
     for (int k = 0; k < 3; ++k) {
         const int c = lane + 64 * k;
         if (c < H) {
-            const float et = (float)(bf16)e_lab[(size_t)b * H + c];
-            dot += (float)rep_bf[(size_t)b * LDR + c] * et;
+            const float et = X3 ? e_lab[(size_t)b * H + c] : (float)(bf16)e_lab[(size_t)b * H + c];
+            dot += (X3 ? rep_f[(size_t)b * H + c] : (float)rep_bf[(size_t)b * LDR + c]) * et;
             drep[(size_t)b * H + c] = w * (o[k] / L - et);
         }
     }
@@ -958,8 +960,8 @@ int ader_lbf_merge_parts(const float* parts, int world, int Bp, int B, int H, co
     if (Bp <= 0) return 0;
     if (B > Bp || H > 192 || world < 1) return -2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_lbf_merge_parts, dim3((Bp + 3) / 4), dim3(256), 0, st, parts, world, Bp, B, H, e_lab, (const bf16*)rep_bf,
-                       wrow, lse, off, rowloss, drep);
+    hipLaunchKernelGGL(k_lbf_merge_parts<false>, dim3((Bp + 3) / 4), dim3(256), 0, st, parts, world, Bp, B, H, e_lab,
+                       (const bf16*)rep_bf, (const float*)nullptr, wrow, lse, off, rowloss, drep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -1053,6 +1055,54 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        emb + H, rep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- catalog-sharded data parallelism at float32 grade (x3): the counterparts of ader_lbf_fwd_shard / ader_lbf_merge_parts.
+// Softmax partials of ALL Bp batch rows (operand planes rep_hi / rep_lo [Bp,168] of the all-gathered representations,
+// ader_lx3_prep) over the item shard [item_begin+1, item_begin+item_count] (clipped to N), streaming the fp32 table rows of the
+// shard.  part [Bp][152] = {M (log2 domain), L, O[0..H)}; scratch pm/pl/pO sized with ader_lbf_ranges(item_count, Bp).
+int ader_lx3_fwd_shard(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int Bp, int H, int N, int item_begin,
+                       int item_count, float* pm, float* pl, float* pO, float* part, void* stream) {
+    if (Bp <= 0) return 0;
+    if (Bp % 128 != 0 || H > HP || (H & 1) || H < 2 || N > item_num || item_begin < 0 || ((uintptr_t)emb & 7)) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    int n_loc = N - item_begin;
+    if (n_loc > item_count) n_loc = item_count;
+    if (n_loc < 0) n_loc = 0;
+    Lx3Args x;
+    x.emb1 = emb + (size_t)H * (1 + item_begin); x.vrows = item_num - item_begin;
+    x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
+    x.Bp = Bp; x.H = H; x.N = n_loc; x.ranges = n_loc > 0 ? ader_lbf_ranges(n_loc, Bp) : 0; x.pm = pm; x.pl = pl; x.pO = pO;
+    x.kd_row0 = Bp; x.Np = 0; x.teacher = nullptr; x.ldt = 0; x.trow = nullptr; x.tlse2 = nullptr; x.pO2 = nullptr; x.ranges2 = 0;
+    LbfArgs a;
+    a.sh1 = nullptr; a.vrows = x.vrows; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = Bp; a.Bp = Bp; a.H = H; a.N = n_loc;
+    a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
+    if (x.ranges > 0) {
+        int rc = 0;
+        if (lx3_kind(H, Bp) == 2) rc = lx3g_launch(x, stream);
+        else {
+            rc = lx3_attr();
+            if (!rc) hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), (size_t)2 * 2 * FB * LDR * sizeof(bf16), st, x);
+        }
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_lbf_combine_partial, dim3(Bp), dim3(640), 0, st, a, part);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Merge of the W ranks' partials as ader_lbf_merge_parts, with the target logit in fp32: rep [B,H] fp32 representations of THIS
+// rank's rows, e_lab [B,H] fp32 table rows of their labels.
+int ader_lx3_merge_parts(const float* parts, int world, int Bp, int B, int H, const float* e_lab, const float* rep,
+                         const float* wrow, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+    if (Bp <= 0) return 0;
+    if (B > Bp || H > 192 || world < 1) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_lbf_merge_parts<true>, dim3((Bp + 3) / 4), dim3(256), 0, st, parts, world, Bp, B, H, e_lab,
+                       (const bf16*)nullptr, rep, wrow, lse, off, rowloss, drep);
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;
 }

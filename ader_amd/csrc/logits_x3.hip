@@ -224,6 +224,11 @@ __global__ __launch_bounds__(256, 3) void k_lx3f(Lx3Args a) {
 // operand fragment feeds twice the flops of the 16x16x32 form, whose 16-row waves keep the LDS pipe as busy as the matrix pipe
 // (reads 1,920 + block stores 940 of the 2,880 clocks the MFMAs of a block take on a SIMD; measured 1.16-1.20 ms against
 // 1.05-1.08 ms for k_lx3_fwd).  Register plan (<= 256): rep fragments 80, O 80, S / P 16, one block in flight 24, operand sets 16 / 32.
+#undef F3_LOAD
+#undef F3_STORE
+#undef F3_KC
+#undef F3_PART
+#undef F3_VALID
 #define G3_ROWS 128
 #ifdef G3_STAMP     // diagnostic build only (tools/build_variant.sh ... -DG3_STAMP): per-segment clocks of wave 0 of every workgroup
 __device__ unsigned long long g3_dbg[8 * 1024];

@@ -1348,7 +1348,7 @@ class Engine:
         self._lists_async(ids_back if pack else ids_g[:, :n_pos], lab_all, N)
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
-        rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
+        rep_bf = None if self.lx3 else self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
         w_row = 1.0 / float(n_train_global if n_train_global is not None else B)
         meta = self.buf("cs_meta", (3, Bp), torch.int32)                       # rows: off (f32 bits), wrow (f32 bits), label
         off, wrow, lab = meta[0].view(torch.float32), meta[1].view(torch.float32), meta[2]
@@ -1359,17 +1359,32 @@ class Engine:
         drep = self.buf("drep", (B, H))
         lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
         with self._sec("logits_fwd"):
-            call("ader_lbf_prep", ptr(rep), ptr(rep_bf), B, Bp, H, st)
-            rep_g = self._ag(rep_bf)                                           # [W, Bp*168]
             R = call("ader_lbf_ranges", S, W * Bp)
             pm, pl = self.buf("lbf_pm", (R * W * Bp,)), self.buf("lbf_pl", (R * W * Bp,))
             pO = self.buf("lbf_pO", (R * W * Bp * 160,))
             part = self.buf("lbf_part", (W * Bp * 152,))
-            call("ader_lbf_fwd_shard", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, H, N, r * S, S, ptr(pm), ptr(pl),
-                 ptr(pO), ptr(part), st)
-            pr = self._a2a(part.view(W, Bp, 152))                              # partials of MY rows from every rank
-            call("ader_lbf_merge_parts", ptr(pr), W, Bp, B, H, ptr(e_lab), ptr(rep_bf), ptr(wrow), ptr(lse), ptr(off), ptr(rowloss),
-                 ptr(self.loss), ptr(drep), st)
+            if self.lx3:
+                # float32 grade: the fp32 representations travel (W * Bp * H floats), every rank cuts the hi / lo operand planes of
+                # the GLOBAL batch itself and streams the fp32 rows of ITS shard
+                rep_pad = self.buf("cs_rep_pad", (Bp, H))
+                rep_pad[:B].copy_(rep)
+                rep_f = self._ag(rep_pad)                                      # [W, Bp, H]
+                rep_g = self.buf("cs_rep_hi", (W * Bp * 168,), torch.bfloat16)
+                rep_lo_g = self.buf("cs_rep_lo", (W * Bp * 168,), torch.bfloat16)
+                call("ader_lx3_prep", ptr(rep_f), ptr(rep_g), ptr(rep_lo_g), W * Bp, W * Bp, H, st)
+                call("ader_lx3_fwd_shard", ptr(rep_g), ptr(rep_lo_g), self._pp["emb"], self.item_num, W * Bp, H, N, r * S, S,
+                     ptr(pm), ptr(pl), ptr(pO), ptr(part), st)
+                pr = self._a2a(part.view(W, Bp, 152))                          # partials of MY rows from every rank
+                call("ader_lx3_merge_parts", ptr(pr), W, Bp, B, H, ptr(e_lab), ptr(rep), ptr(wrow), ptr(lse), ptr(off),
+                     ptr(rowloss), ptr(self.loss), ptr(drep), st)
+            else:
+                call("ader_lbf_prep", ptr(rep), ptr(rep_bf), B, Bp, H, st)
+                rep_g = self._ag(rep_bf)                                       # [W, Bp*168]
+                call("ader_lbf_fwd_shard", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, H, N, r * S, S, ptr(pm), ptr(pl),
+                     ptr(pO), ptr(part), st)
+                pr = self._a2a(part.view(W, Bp, 152))                          # partials of MY rows from every rank
+                call("ader_lbf_merge_parts", ptr(pr), W, Bp, B, H, ptr(e_lab), ptr(rep_bf), ptr(wrow), ptr(lse), ptr(off),
+                     ptr(rowloss), ptr(self.loss), ptr(drep), st)
         self._late_force = True            # weight-gradient products and small reductions are queued ...
         try:
             dx = self._blocks_backward(seq, drep, True, None)
@@ -1399,10 +1414,18 @@ class Engine:
         ids, order, sp_start, tids, torder, tg_start, tmeta = self._lists_wait()
         tiles = S // 128
         with self._sec("logits_bwd_adam"):
-            call("ader_tab_update_sh", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
-                 ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
-                 ptr(torder), ptr(tg_start), tids.numel(), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
-                 self.beta1, self.beta2, self.eps, r * tiles, tiles, None, st)
+            if self.lx3:
+                img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", W * Bp),), torch.uint8, zero=True)
+                call("ader_x3_rep_image", ptr(rep_g), ptr(rep_lo_g), W * Bp, ptr(img), st)
+                call("ader_tab_update_x3", ptr(rep_g), ptr(rep_lo_g), ptr(img), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+                     ptr(ids), ptr(order), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids), ptr(torder),
+                     tids.numel(), ptr(tmeta), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
+                     self.beta2, self.eps, r * tiles, tiles, None, st)
+            else:
+                call("ader_tab_update_sh", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+                     ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
+                     ptr(torder), ptr(tg_start), tids.numel(), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t,
+                     self.beta1, self.beta2, self.eps, r * tiles, tiles, None, st)
         with self._sec("adam"):
             call("ader_adam_step", self.theta.data_ptr() + 4 * span, self.adam_m.data_ptr() + 4 * span,
                  self.adam_v.data_ptr() + 4 * span, self.grad.data_ptr() + 4 * span, self.P - span, lr_t, self.beta1, self.beta2,
@@ -1446,7 +1469,7 @@ class Engine:
             self._in_step = False
 
     def _train_step(self, seq, pos, max_item, lr, **kw):
-        if (self.dp_world > 1 and self.dp_mode == "catalog" and self.shadow is not None and self.seq_fused
+        if (self.dp_world > 1 and self.dp_mode == "catalog" and (self.shadow is not None or self.lx3) and self.seq_fused
                 and kw.get("teacher") is None and kw.get("ex_pos") is None):
             return self._train_step_catalog(seq, pos, max_item, lr, **kw)
         self.sync_table()

@@ -246,6 +246,12 @@ int ader_scatter_owned(const float* recv, const int* ids, int n, int n_tab, int 
                        float* extra, void* stream);
 int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int Bp, int H, int N, int item_begin,
                        int item_count, float* pm, float* pl, float* pO, float* part, void* stream);
+/* ... and at float32 grade (x3): the same two steps streaming the fp32 table rows of the shard (operand planes rep_hi / rep_lo of
+ * the all-gathered representations from ader_lx3_prep; the merge takes the fp32 representations and label rows). */
+int ader_lx3_fwd_shard(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int Bp, int H, int N,
+                       int item_begin, int item_count, float* pm, float* pl, float* pO, float* part, void* stream);
+int ader_lx3_merge_parts(const float* parts, int world, int Bp, int B, int H, const float* e_lab, const float* rep,
+                         const float* wrow, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream);
 /* float32-grade variant of ader_lbf_fwd ("x3": every product as three bf16 MFMAs on hi/lo operand splits, fp32 accumulate;
  * ADER.py:91-93 is fp32 arithmetic).  Streams the fp32 table itself -- no bf16 shadow exists in this mode.  rep_hi/rep_lo:
  * Bp*168 bf16 each (written here: bf16(rep), bf16(rep - hi)); the other scratch and the outputs as in ader_lbf_fwd. */

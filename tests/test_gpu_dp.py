@@ -63,7 +63,9 @@ def _worker(rank, world, port, out, logits, sharded, B=B):
 
 
 @pytest.mark.parametrize("logits,sharded,B", [("f32", False, B), ("bf16", False, B), ("bf16", True, B), ("bf16", "catalog", B),
-                                              ("bf16", "catalog_packed", B), ("bf16", True, 1400), ("bf16", "catalog", 1400)])
+                                              ("bf16", "catalog_packed", B), ("bf16", True, 1400), ("bf16", "catalog", 1400),
+                                              ("x3", False, B), ("x3", "catalog", B), ("x3", "catalog_packed", B),
+                                              ("x3", "catalog", 1400)])
 def test_two_ranks_match_single_process(logits, sharded, B):
     # (B = 1400: a GLOBAL batch beyond 1024 rows -- the row-sharded update and the catalog-sharded forward run on all 1408 padded
     #  rows of both ranks, as the 8-GPU configuration does with 4096)
@@ -101,7 +103,10 @@ def test_two_ranks_match_single_process(logits, sharded, B):
                      logits_bf16=(logits == "bf16"))
     oemb = params["emb"].numpy().reshape(-1)[:(ITEMS + 1) * H]
     do = np.abs(got - oemb)
-    assert do.max() < 3e-4 + 2.5e-3 * (logits == "bf16") and np.mean(do < 2e-5) > 0.99, (do.max(), np.mean(do < 2e-5))
+    # (x3 at 1,400 rows: individual elements whose gradient is ~eps move by up to +-lr per step under Adam -- 2 lr = 1e-3 after the
+    #  two steps -- when the ~1e-5 relative difference of the bf16x3 products flips their sign; 99.7 % stay within 2e-5)
+    bound = 3e-4 + 2.5e-3 * (logits == "bf16") + 1.0e-3 * (logits == "x3" and B > 1024)
+    assert do.max() < bound and np.mean(do < 2e-5) > 0.99, (do.max(), np.mean(do < 2e-5))
 
 
 # ---------------------------------------------------------------------------------------------- distilled steps under DP
