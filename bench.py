@@ -2,7 +2,8 @@
 """Benchmark of the ADER / SASRec training hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: bench.py starts its own N ranks -- a child `python -m torch.distributed.run` -- before it touches
+     the GPU, relays rank 0's JSON line and exits with the children's code; under torchrun it is one of the ranks.)
 
 A step = one pass of the hot path over one batch of synthetic input already resident in HBM: embedding gather ->
 causal self-attention blocks -> full-catalog logits + softmax CE -> backward -> [RCCL gradient all-reduce] -> dense
@@ -10,9 +11,13 @@ Adam (the `sess.run(train_op)` of reference main.py:233-256).  Workload = BASELI
 catalog, seq_len 50, batch 512 per GPU (weak scaling), dense regime (every position a real item, ids ~ U[1,N]),
 dropout 0.3, lr 5e-4, hidden 150, 2 blocks, 1 head (reference defaults main.py:98-107).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on
-the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores).
+The headline is the float32-grade step (`--logits x3`: every GEMM as three bf16 MFMAs on hi/lo operand splits, ~2^-16 relative
+per product, fp32 accumulate -- the reference's arithmetic is float32, ADER.py:91-93); the bf16-operand step is reported beside it
+as `value_bf16`.  The timed region is repeated `--reps` times (K steps each) and `value` is the MEDIAN repetition (min / max in
+`reps_ms`).  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the launch stream inside the
+timed region; `logit_gemm`, `gather`, `herding` sub-blocks) and `cpu_baseline` (the CPU oracle timed on this host's cores).
 """
+import subprocess
 import argparse
 import gc
 import json
@@ -109,28 +114,50 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--logits", choices=["bf16", "x3", "f32"], default="bf16",
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region (K steps each); value = median")
+    ap.add_argument("--logits", choices=["bf16", "x3", "f32"], default="x3",
                     help="operand type of the logit GEMMs (fp32 master table, fp32 accumulate/softmax either way)")
     ap.add_argument("--regime", choices=["dense", "realistic"], default="dense",
                     help="synthetic id/length law (SURVEY 8d); the headline number is the dense regime")
     ap.add_argument("--exemplars", type=int, default=0,
                     help="ADER-mode variant: append this many exemplar rows distilled against N(0,1) teacher logits over 0.9 N items")
-    ap.add_argument("--dp-mode", choices=["replicated", "catalog"], default="replicated",
-                    help="N > 1: 'replicated' (headline; the north-star scheme: every rank holds the table, the table update is "
-                         "row-sharded reduce-scatter / all-gather style and the updated rows are all-gathered over RCCL) or 'catalog' "
-                         "(named variant: each rank OWNS 1/N of the table rows, only touched rows travel)")
+    ap.add_argument("--dp-mode", choices=["replicated", "catalog"], default="catalog",
+                    help="N > 1: 'catalog' (default: each rank OWNS 1/N of the table rows -- parameters and Adam state --, only the rows "
+                         "the inputs touch, the representations and per-row softmax partials travel; DESIGN.md section 5 has the "
+                         "byte model) or 'replicated' (every rank holds the table: dense all-reduce of the table gradient overlapped "
+                         "with backward at float32 grade, row-sharded update + all-gather with bf16 logits)")
     ap.add_argument("--workload", choices=["cfgS", "cfgD", "cfgY", "cfgF"], default="cfgS",
                     help="cfgS: BASELINE configs[4] (the metric's configuration).  Step-shape variants of the real-data configs "
                          "(SURVEY 8a): cfgD = DIGINETICA ADER last period (N 43,105, 256 train + 143 distilled rows), cfgY = YOOCHOOSE "
                          "ADER last period (N 25,750, 512 + 102 rows), cfgF = DIGINETICA finetune baseline (BASELINE configs[0]: N 43,105, "
                          "batch 128, no exemplars, dropout 0); synthetic ids of those shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f32grade", action="store_true", help="skip the float32-grade (x3 logits) companion run")
+    ap.add_argument("--no-f32grade", "--no-companion", dest="no_companion", action="store_true",
+                    help="skip the companion run of the other logits type (bf16 beside the x3 headline)")
+    ap.add_argument("--no-herding", action="store_true", help="skip the exemplar-selection measurement (YOOCHOOSE period 1)")
     ap.add_argument("--pmc-json", default=None,
                     help="rocprofv3 PMC summary of THIS command (tools/summarize_profiles.py) to quote roofline.traffic from; "
                          "without it traffic is null (bench.py never pairs live timings with counters of another run)")
     ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start the ranks as children BEFORE anything touches the GPU (never re-exec a GPU process)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if r.returncode != 0 or not lines:
+            sys.stderr.write(r.stdout[-4000:] + r.stderr[-4000:])
+            sys.exit(r.returncode or 1)
+        print(lines[-1])
+        sys.exit(0)
 
     from ader_amd import dist as adist
     from ader_amd.engine import Engine, SectionTimer
@@ -139,7 +166,8 @@ def main():
     # ADER_DIST_BACKEND=gloo lets several ranks share one GPU (functional check of the N > 1 path without an 8-GPU node)
     rank, world, local = adist.init(os.environ.get("ADER_DIST_BACKEND", "nccl"))
     local = local % max(torch.cuda.device_count(), 1)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise RuntimeError("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -150,14 +178,8 @@ def main():
     elif args.workload == "cfgF":
         args.items, args.batch, args.exemplars = 43105, 128, 0
     N, B, T, H, L, heads, rate, lr = args.items, args.batch, 50, 150, 2, 1, (0.0 if args.workload == "cfgF" else 0.3), 5e-4
-    eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=args.logits,
-                 dp_rank=rank, dp_world=world)
-    dp = adist.DataParallel(eng, rank, world)
-    if world > 1 and args.logits == "bf16" and not args.exemplars:
-        eng.dp_mode = args.dp_mode
-    dp.set_rows(rank * B, N)
-    nbatch = 4
     E = args.exemplars
+    nbatch = 4
     batches = [synth_batch(B + E, T, N, 1000 * s + rank, dev, args.regime) for s in range(nbatch)]   # resident in HBM before timing
     kw = dict(rate=rate, n_train_global=B * world)
     if E:
@@ -171,58 +193,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Per-section HIP events (on the launch stream) cost stream time: the full breakdown is taken on the last warmup steps,
-    # and the timed region records only the dominant section (every 8th step), whose duration feeds the roofline line.
-    sections_all = {}
-    for i in range(5):        # engine initialisation (workspace allocation, kernel attributes, side streams): never timed
-        seq, pos = batches[i % nbatch]
-        eng.train_step(seq, pos, N, lr, **kw)
-    for i in range(args.warmup):
-        if not args.no_sections and i == max(0, args.warmup - 3):
-            eng.timer = SectionTimer()
-        seq, pos = batches[i % nbatch]
-        eng.train_step(seq, pos, N, lr, **kw)
-    eng.check_status()
-    if not args.no_sections:
-        if eng.timer is not None:
-            sections_all = eng.timer.collect()
-        skip = ("grad_exchange", "param_allgather")
-        dom_names = [k for k in sections_all if k not in skip]
-        # (a timing event pair around the kernel breaks its overlap with the side stream and costs ~60 us of the step: the
-        #  dominant kernel is therefore timed on every 8th step of the timed region)
-        eng.timer = SectionTimer(only={max(dom_names, key=lambda k: sections_all[k])} if dom_names else None, every=8)
-    # The interpreter's cyclic collector walks every object torch has imported (~40 ms per full pass): a pass that lands in the
-    # timed region is host noise of the same size as the region.  Collect now and freeze what exists (the steps themselves create
-    # no cycles); a training loop does the same once at start-up (ader_amd/main.py).
-    gc.collect()
-    gc.freeze()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        seq, pos = batches[i % nbatch]
-        eng.train_step(seq, pos, N, lr, **kw)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = float(eng.loss.item())
-    sections = eng.timer.collect() if eng.timer is not None else {}
-    eng.timer = None
-    sections = {**sections_all, **sections}          # dominant section: timed-region average; the rest: warmup steps
+    def make_engine(logits):
+        eng_ = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=logits,
+                      dp_rank=rank, dp_world=world)
+        dp_ = adist.DataParallel(eng_, rank, world)
+        if world > 1 and logits in ("bf16", "x3") and not E:
+            eng_.dp_mode = args.dp_mode
+        dp_.set_rows(rank * B, N)
+        return eng_
+
+    def timed(eng_, reps, sections=True):
+        """5 untimed initialisation steps, W warm-up steps (per-kernel HIP events on the last three), then `reps` repetitions of
+        EXACTLY K steps, each bracketed by a barrier + synchronize on both sides; per repetition the MAX over ranks."""
+        sec_all = {}
+        for i in range(5):        # engine initialisation (workspace allocation, kernel attributes, side streams): never timed
+            eng_.train_step(*batches[i % nbatch], N, lr, **kw)
+        for i in range(args.warmup):
+            if sections and i == max(0, args.warmup - 3):
+                eng_.timer = SectionTimer()
+            eng_.train_step(*batches[i % nbatch], N, lr, **kw)
+        eng_.check_status()
+        if sections:
+            if eng_.timer is not None:
+                sec_all = eng_.timer.collect()
+            # (a timing event pair around a kernel breaks its overlap with the side stream and costs ~60 us of the step: in the timed
+            #  region only the two logit kernels are timed, on every 8th step)
+            eng_.timer = SectionTimer(only={"logits_bwd_adam", "logits_fwd"}, every=8)
+        # The interpreter's cyclic collector walks every object torch has imported (~40 ms per full pass): a pass that lands in the
+        # timed region is host noise of the same size as the region.  Collect now and freeze what exists (the steps themselves
+        # create no cycles); a training loop does the same once at start-up (ader_amd/main.py).
+        gc.collect()
+        gc.freeze()
+        dts = []
+        for _ in range(max(1, reps)):
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                eng_.train_step(*batches[i % nbatch], N, lr, **kw)
+            sync()
+            dt_ = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ = float(t.item())
+            dts.append(dt_)
+        sec = eng_.timer.collect() if eng_.timer is not None else {}
+        eng_.timer = None
+        return dts, {**sec_all, **sec}, float(eng_.loss.item())
+
+    eng = make_engine(args.logits)
+    dts, sections, loss = timed(eng, args.reps, not args.no_sections)
+    dt = float(np.median(dts))
 
     # ---- standalone embedding gather (north_star: "rocprof HBM GB/s on the gather"): in the step it is fused into the one-launch
     # forward, so it is timed here as its own kernel on the same batch (ader_embed_fwd: ids -> x0 = drop(E[ids]*sqrt(H) + P) * mask)
     gather = None
     if rank == 0 and not args.no_sections:
-        from ader_amd._lib import call, ptr
+        import ctypes
+        from ader_amd._lib import AderDrop, call, ptr
         seq0 = batches[0][0][:B].contiguous()
         x0 = torch.empty(B * T, H, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        import ctypes
-        from ader_amd._lib import AderDrop
         dd = AderDrop(0x1234, int(0.3 * 2 ** 24), 1.0 / 0.7, 0, 0xFFFFFFFF, 0)
         for it in range(25):
             if it == 5:
@@ -237,37 +269,34 @@ def main():
                   "GBps": round(gbytes / (us * 1e-6), 1), "frac_hbm": round(gbytes / (us * 1e-6) / HBM_PEAK_GBS, 4),
                   "note": "25,600 random 600-B rows of a 600 MB table + 15.4 MB written: latency / launch bound at this size"}
 
-    # ---- float32-grade companion (the reference's arithmetic is fp32, ADER.py:91-93): the same step with logits_dtype="x3"
-    f32g = None
-    if world == 1 and args.logits == "bf16" and not args.no_f32grade and not E:
+    P, span = eng.P, eng.layout["pos"][0]
+    dp_mode, dp_pack = eng.dp_mode, eng.dp_pack
+    exchange = ("none" if world == 1 else
+                ("catalog-sharded table: input rows all-to-all + representations all-gather + softmax partials all-to-all + gradient "
+                 "rows all-gather" if (dp_mode == "catalog" and args.logits in ("bf16", "x3") and not E) else
+                 ("row-sharded table update + all-gather of the updated rows" if (eng.dp_sharded and eng.shadow is not None)
+                  else "dense gradient all-reduce (table part started right after the logits backward, under the blocks backward)")))
+
+    # ---- companion run of the other logits type (bf16 operands beside the float32-grade headline, or the reverse)
+    comp, comp_name = None, {"x3": "bf16", "bf16": "x3"}.get(args.logits)
+    if world == 1 and comp_name and not args.no_companion and not E:
         del eng
         torch.cuda.empty_cache()
-        eng3 = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype="x3")
-        for i in range(5 + args.warmup):
-            seq, pos = batches[i % nbatch]
-            eng3.train_step(seq, pos, N, lr, **kw)
-        eng3.timer = SectionTimer(only={"logits_bwd_adam", "logits_fwd"}, every=8)
-        gc.collect()
-        gc.freeze()
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            seq, pos = batches[i % nbatch]
-            eng3.train_step(seq, pos, N, lr, **kw)
-        sync()
-        dt3 = time.perf_counter() - t0
-        sec3 = eng3.timer.collect()
-        eng3.timer = None
-        f32g = {"ms_per_step": dt3 / args.steps * 1e3, "value": B * args.steps / dt3, "final_loss": float(eng3.loss.item()),
-                "sections_ms": {k: round(v, 4) for k, v in sorted(sec3.items())}}
-        eng = eng3
+        engc = make_engine(comp_name)
+        dtc, secc, lossc = timed(engc, 1, not args.no_sections)
+        comp = {"logits": comp_name, "ms_per_step": dtc[0] / args.steps * 1e3, "value": B * args.steps / dtc[0], "final_loss": lossc,
+                "sections_ms": {k: round(v, 4) for k, v in sorted(secc.items())}}
+        del engc
+        torch.cuda.empty_cache()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        P = eng.P
+        x3 = args.logits == "x3"
         lpeak = BF16_MFMA_PEAK_TFLOPS if args.logits in ("bf16", "x3") else F32_MFMA_PEAK_TFLOPS
-        # algorithmic work per launch (DESIGN.md "roofline accounting").  In bf16 mode the forward launch also
-        # produces dRep (flash-style readout), so it is credited both GEMMs; recomputation is never credited.
+        cat = world if (world > 1 and dp_mode == "catalog" and args.logits in ("bf16", "x3") and not E) else 1
+        # algorithmic work per launch (DESIGN.md "roofline accounting").  In the flash modes the forward launch also
+        # produces dRep (softmax-weighted readout), so it is credited both GEMMs; recomputation and the 3x of the hi/lo split are
+        # never credited.  Catalog-sharded N > 1: a rank streams N / world items for world * B rows -- the same products.
         fwd_flops = 2.0 * B * N * H * (2 if args.logits in ("bf16", "x3") else 1)
         work = {
             "logits_fwd": ("mfma", fwd_flops, lpeak),
@@ -275,88 +304,141 @@ def main():
             "logits_bwd_demb": ("mfma", 2.0 * B * N * H, lpeak),
             "blocks_fwd": ("mfma", L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
             "blocks_bwd": ("mfma", 2 * L * 2.0 * B * T * (5 * H * H + 2 * T * H), F32_MFMA_PEAK_TFLOPS),
-            "adam": ("hbm", 7.0 * P * 4, HBM_PEAK_GBS),
+            "adam": ("hbm", 7.0 * (P - span if "logits_bwd_adam" in sections else P) * 4, HBM_PEAK_GBS),
             # fused table update: theta/m/v of rows 1..N in and out (+ bf16 shadow row in and out in bf16 mode; x3 mode has no shadow
             # and counts ONE theta read although the kernel reads theta twice); dE never hits memory
-            # (catalog-sharded N > 1: a rank updates only its N / world rows)
-            "logits_bwd_adam": ("hbm", (6.0 * N * H * 4 + (2.0 * N * 336 if args.logits == "bf16" else 0.0)) / (world if eng.dp_mode == "catalog" else 1), HBM_PEAK_GBS),
+            "logits_bwd_adam": ("hbm", (6.0 * N * H * 4 + (2.0 * N * 336 if args.logits == "bf16" else 0.0)) / cat, HBM_PEAK_GBS),
             # distilled exemplar rows on the exact-f32 kernels: logits + dRep + dE over the 0.9 N teacher columns
             "kd_rows": ("mfma", 3 * 2.0 * E * int(0.9 * N) * H, F32_MFMA_PEAK_TFLOPS),
-            "grad_exchange": ("hbm", 0.0, HBM_PEAK_GBS),
-            "param_allgather": ("hbm", 0.0, HBM_PEAK_GBS),
         }
-        # HBM traffic of the dominant kernel: only from a PMC summary of THIS command passed with --pmc-json (rocprofv3 separate
-        # --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, gfx950 x2 read correction applied: tools/profile_round.sh); otherwise null
-        pmc_kernel = {"logits_bwd_adam": "k_tab16<" if args.logits == "bf16" else "k_tab_upd<true, true",
-                      "logits_fwd": "k_lbf_fwd" if args.logits == "bf16" else "k_lx3_fwd", "adam": "k_adam"}
-        pmc, pmc_src, prof_us = {}, None, None
-        pmc_path = args.pmc_json
-        if pmc_path is None and N == 1_000_000 and B == 512 and not E and world == 1 and args.regime == "dense":
-            # default: the committed end-of-round profile of THIS command (profiles/CURRENT.json names it and the commit it was
-            # taken at); quoted with its provenance, never silently
-            try:
+        comm_names = ("grad_exchange", "param_allgather")
+        # ---- counters of the dominant kernels: from a PMC summary of THIS command (--pmc-json), or the committed end-of-round
+        # profile IF it was taken from the kernel sources that are running now (profiles/CURRENT.json: sha of ader_amd/csrc);
+        # a profile of other kernels is named but never quoted
+        pmc_kernel = {"logits_bwd_adam": {"bf16": "k_tab16<", "x3": "k_tab16x3<"}.get(args.logits, "k_tab_upd"),
+                      "logits_fwd": {"bf16": "k_lbf_fwd", "x3": "k_lx3g<"}.get(args.logits, "k_logits"), "adam": "k_adam"}
+        pmc, sq, pmc_src = {}, {}, None
+        std = N == 1_000_000 and B == 512 and not E and world == 1 and args.regime == "dense"
+        try:
+            if args.pmc_json:
+                pmc = json.load(open(args.pmc_json))["kernels"]
+                pmc_src = {"file": os.path.relpath(os.path.abspath(args.pmc_json), ROOT), "stale": False}
+            elif std:
                 cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
-                tag = cur["x3" if args.logits == "x3" else "bf16"]
-                pmc_path = os.path.join(ROOT, "profiles", tag + "_pmc_hbm.json")
+                tag = cur[args.logits]
+                stale = cur.get("src_sha16") != csrc_sha16()
                 pmc_src = {"file": "profiles/%s_pmc_hbm.json" % tag, "kernel_stats": "profiles/%s_kernel_stats.csv" % tag,
-                           "profiled_at_commit": cur.get("git_head"),
-                           "note": "rocprofv3 passes of this same command, run separately (tools/profile_round.sh)"}
-            except Exception:
-                pmc_path, pmc_src = None, None
-        elif pmc_path:
-            pmc_src = {"file": os.path.relpath(os.path.abspath(pmc_path), ROOT)}
-        if pmc_path:
+                           "sq": "profiles/%s_pmc_sq.json" % tag, "profiled_at_commit": cur.get("git_head"), "stale": stale,
+                           "note": "rocprofv3 passes of this same command, run separately (tools/profile_round.sh)"
+                                   + ("; taken from OTHER kernel sources than the ones running: not quoted" if stale else "")}
+                if not stale:
+                    pmc = json.load(open(os.path.join(ROOT, pmc_src["file"])))["kernels"]
+                    sq = json.load(open(os.path.join(ROOT, pmc_src["sq"])))["kernels"]
+        except Exception:
+            pmc, sq, pmc_src = {}, {}, None
+
+        def pick(table, prefix):
+            return next((v for k_, v in table.items() if prefix and k_.replace("void ", "").startswith(prefix)), None)
+
+        def rocprof_ms(prefix):
+            if not (pmc_src and pmc_src.get("kernel_stats") and not pmc_src.get("stale")):
+                return None
             try:
-                pmc = json.load(open(pmc_path))["kernels"]
+                import csv
+                for r_ in csv.DictReader(open(os.path.join(ROOT, pmc_src["kernel_stats"]))):
+                    if r_["Name"].replace("void ", "").startswith(prefix):
+                        return float(r_["AverageNs"]) / 1e6
             except Exception:
-                pmc, pmc_src = {}, None
+                pass
+            return None
+
         roof = None
         if sections:
-            if "logits_bwd_adam" in sections:     # the small-parameter Adam launch is not the 7*P*4-byte kernel any more
-                work["adam"] = ("hbm", 7.0 * (P - eng.layout["pos"][0]) * 4, HBM_PEAK_GBS)
-            dom = max((k for k in sections if k not in ("grad_exchange", "param_allgather")), key=lambda k: sections[k])
+            dom = max((k for k in sections if k not in comm_names and k in work), key=lambda k: sections[k])
             bound, amount, peak = work[dom]
             sec = sections[dom] * 1e-3
-            if bound == "mfma":
-                ach, unit = amount / sec / 1e12, "TFLOP/s"
-            else:
-                ach, unit = amount / sec / 1e9, "GB/s"
-            roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                    "traffic": (next((v.get("hbm_bytes") for k_, v in pmc.items()
-                                      if pmc_kernel.get(dom) and k_.startswith(pmc_kernel[dom])), None)
-                                if unit == "GB/s" else None),
-                    "traffic_source": pmc_src,
-                    "frac_rocprof": None,
-                    "ms": sections[dom],
+            ach, unit = (amount / sec / 1e12, "TFLOP/s") if bound == "mfma" else (amount / sec / 1e9, "GB/s")
+            hb = pick(pmc, pmc_kernel.get(dom))
+            rms = rocprof_ms(pmc_kernel.get(dom, "?"))
+            roof = {"kernel": dom + " (" + pmc_kernel.get(dom, "").rstrip("<") + ")", "bound": bound, "achieved": ach, "peak": peak,
+                    "unit": unit, "frac": ach / peak,
+                    "traffic": (hb.get("hbm_bytes") if (hb and unit == "GB/s") else None),
+                    "traffic_source": pmc_src, "ms": sections[dom], "ms_rocprof": rms,
+                    "frac_rocprof": (amount / (rms * 1e-3) / (1e9 if unit == "GB/s" else 1e12) / peak) if rms else None,
+                    "algorithmic": amount,
                     # whole step against SURVEY 8(d)'s compulsory traffic (6.64 GB at cfg-S, unfused accounting) and the HBM peak
                     "step_bytes": 6.64e9 * (N / 1e6) if (B == 512 and not E) else None,
                     "step_frac": (6.64e9 * (N / 1e6) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (B == 512 and not E and world == 1) else None,
-                    "gather": gather,
                     "sections_ms": {k: round(v, 4) for k, v in sorted(sections.items())}}
-        if roof and pmc_src and pmc_src.get("kernel_stats") and roof["unit"] == "GB/s":
-            try:
-                import csv
-                want = pmc_kernel.get(roof["kernel"])
-                for r_ in csv.DictReader(open(os.path.join(ROOT, pmc_src["kernel_stats"]))):
-                    nm = r_["Name"].replace("void ", "")
-                    if want and nm.startswith(want):
-                        us = float(r_["AverageNs"]) / 1e3
-                        roof["ms_rocprof"] = us / 1e3
-                        roof["frac_rocprof"] = work[roof["kernel"]][1] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-                        break
-            except Exception:
-                pass
+            # the logit GEMM (north_star: "MFMA utilisation on the logit GEMM against gfx950 peak"): the flash forward launch
+            if "logits_fwd" in sections and args.logits in ("bf16", "x3"):
+                fms = sections["logits_fwd"]
+                q = pick(sq, pmc_kernel["logits_fwd"])
+                # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1,024 SIMDs; busy fraction = cycles / SIMDs / (kernel time x the clock the
+                # profiled pass held: SQ_WAVE_CYCLES counts 4-clock units per resident wave)
+                busy = None
+                frm = rocprof_ms(pmc_kernel["logits_fwd"])
+                if q and frm and q.get("SQ_VALU_MFMA_BUSY_CYCLES") and q.get("SQ_WAVE_CYCLES"):
+                    waves = 8 * 256 if x3 else 8 * 256
+                    clocks = 4.0 * q["SQ_WAVE_CYCLES"] / waves                  # clocks the launch lasted (resident-wave average)
+                    busy = q["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / clocks
+                roof["logit_gemm"] = {"kernel": pmc_kernel["logits_fwd"].rstrip("<") + " (logits + softmax + readout)", "ms": fms,
+                                      "flops_credited": fwd_flops, "flops_executed": fwd_flops * (3 if x3 else 1),
+                                      "TFLOPs_credited": fwd_flops / (fms * 1e-3) / 1e12,
+                                      "frac_of_bf16_peak_credited": fwd_flops / (fms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                      "frac_of_bf16_peak_executed": fwd_flops * (3 if x3 else 1) / (fms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                      "mfma_busy_profiled": busy}
+            roof["gather"] = gather
+        comm = None
+        if world > 1:
+            # bytes RECEIVED per rank and step (model; W = ranks): see DESIGN.md section 5
+            W, n_all, Bp = world, B * T + B, (B + 127) // 128 * 128
+            small = 2.0 * (W - 1) / W * (P - span) * 4
+            if cat > 1:
+                rows = (W - 1) * n_all * H * 4 if not dp_pack else (W - 1) / W * n_all * H * 4
+                rb = ((W - 1) * n_all * 4 + rows + (W - 1) * Bp * (H * 4 if x3 else 336) + (W - 1) * Bp * 152 * 4
+                      + (W - 1) * 3 * Bp * 4 + ((W - 1) * B * T * H * 4 if not dp_pack else (W - 1) / W * B * T * H * 4) + small)
+            elif eng_sharded(args.logits):
+                rb = (W - 1) * (Bp * 336 + 3 * Bp * 4 + B * T * 4 + B * T * H * 4) + (W - 1) / W * N * H * 4 + small
+            else:
+                rb = 2.0 * (W - 1) / W * (N + 1) * H * 4 + (W - 1) * (B * T * 4 + B * T * H * 4) + small
+            comm = {"dp_mode": dp_mode if cat > 1 or eng_sharded(args.logits) else "dense all-reduce", "packed_rows": bool(dp_pack),
+                    "comm_ms": round(sum(sections.get(k, 0.0) for k in comm_names), 4),
+                    "comm_ms_note": "host-side sections around the collectives in the warm-up steps (they include the kernels that pack / "
+                                    "unpack the exchanged rows); the dense all-reduce overlaps the blocks backward",
+                    "exchange_bytes_per_step": int(rb)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 leg only
             try:
                 cpu = cpu_baseline(N, B, T, H, L, heads, rate, lr, E, int(0.9 * N) if E else 0)
             except Exception as e:  # report, never fake
                 cpu = {"value": None, "unit": "sessions/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        herd = None
+        if world == 1 and not args.no_herding and args.workload == "cfgS" and not E:
+            try:        # exemplar selection of YOOCHOOSE period 1 (groups up to 1,710 rows, SURVEY 8d "Herding measurement")
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import contextlib
+                import bench_herding
+                torch.cuda.empty_cache()
+                with contextlib.redirect_stdout(sys.stderr):        # (the data loader prints the reference's log lines)
+                    herd = bench_herding.measure("YOOCHOOSE", 1, cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                herd = {"failed": repr(e)}
+        if roof is not None:
+            roof["herding"] = herd
+        prec = {"bf16": "logit GEMMs: bf16 operands, fp32 accumulate + softmax; block GEMMs and attention: bf16x3 (three bf16 MFMAs "
+                        "per product on hi/lo splits, ~2^-16 relative, fp32 accumulate); LayerNorm, softmax, optimizer, master "
+                        "weights: fp32",
+                "x3": "float32 grade: every GEMM bf16x3 (three bf16 MFMAs per product on hi/lo operand splits, ~2^-16 relative per "
+                      "product, fp32 accumulate); LayerNorm, softmax, optimizer, master weights: fp32",
+                "f32": "fp32 throughout (f32 MFMA)"}
         out = {
             "metric": "train sessions/sec at batch=512 seq=50", "value": B * world * args.steps / dt, "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "x3": "bf16x3", "f32": "f32"}[args.logits], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "x3": "bf16x3 (fp32-grade)", "f32": "f32"}[args.logits], "data": "synthetic",
+            "reps": len(dts), "reps_ms": {"median": ms, "min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
+                                          "all": [round(x / args.steps * 1e3, 4) for x in dts]},
             "config": {"workload": ("synthetic %s-item catalog, seq_len=50, batch=%d/GPU, %s regime%s (BASELINE.json configs[4]%s)"
                                     % ("1M" if N == 1_000_000 else "%d" % N, B, args.regime,
                                        ", +%d distilled exemplar rows" % E if E else "",
@@ -366,30 +448,37 @@ def main():
                                         "cfgF": "DIGINETICA finetune baseline (configs[0], main.py --finetune=True)"}
                                        [args.workload], N, B, E, args.regime)),
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
-                       "dropout": rate, "optimizer": "dense TF-Adam",
-                       "exchange": ("none" if world == 1 else
-                                    ("catalog-sharded table: input rows all-to-all + softmax partials + gradient rows all-gather"
-                                     if eng.dp_mode == "catalog" else
-                                     ("row-sharded table update + all-gather" if (eng.dp_sharded and eng.shadow is not None)
-                                      else "dense gradient all-reduce"))),
-                       "precision": {"bf16": "logit GEMMs: bf16 operands, fp32 accumulate + softmax; block GEMMs and attention: bf16x3 "
-                                             "(three bf16 MFMAs per product on hi/lo splits, ~2^-16 relative, fp32 accumulate); "
-                                             "LayerNorm, softmax, optimizer, master weights: fp32",
-                                     "x3": "every GEMM bf16x3 (three bf16 MFMAs per product on hi/lo splits, ~2^-16 relative, fp32 "
-                                           "accumulate): float32-grade; LayerNorm, softmax, optimizer, master weights: fp32",
-                                     "f32": "fp32 throughout (f32 MFMA)"}[args.logits],
+                       "dropout": rate, "optimizer": "dense TF-Adam", "exchange": exchange, "precision": prec[args.logits],
                        "parallelism": "dp%d" % world, "final_loss": loss,
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1)},
-            # float32-grade companion of the same step (logits_dtype = x3; reference arithmetic is fp32, ADER.py:91-93)
-            "value_f32grade": f32g["value"] if f32g else None,
-            "ms_per_step_f32grade": f32g["ms_per_step"] if f32g else None,
-            "f32grade": f32g,
+            "comm": comm,
+            # companion of the same step with the other logits type (bf16 operands: narrower than the reference's float32)
+            ("value_" + (comp_name or "companion")): comp["value"] if comp else None,
+            ("ms_per_step_" + (comp_name or "companion")): comp["ms_per_step"] if comp else None,
+            "companion": comp,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def eng_sharded(logits):
+    """replicated mode: the row-sharded table update exists for bf16 logits (it rebuilds the shadow rows it all-gathers)"""
+    return logits == "bf16"
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources: ties a committed profile to the kernels it was taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ader_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":

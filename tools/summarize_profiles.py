@@ -62,5 +62,8 @@ if len(sys.argv) > 2 and sys.argv[2] in ("bf16", "x3"):
         cur["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"]).decode().strip()
     except Exception:
         pass
+    sys.path.insert(0, ROOT)
+    import bench
+    cur["src_sha16"] = bench.csrc_sha16()        # bench.py quotes these counters only while the kernel sources are unchanged
     json.dump(cur, open(cur_p, "w"), indent=1)
 print("wrote profiles/%s_*" % tag)
