@@ -18,6 +18,7 @@ _SIGS = {
     "ader_sq_accum": [P, P, Z, F, P],
     "ader_ewc_penalty": [P, P, P, P, Z, F, P, P, P],
     "ader_scatter_rows": [P, P, I, I, I, F, P, P],
+    "ader_scatter_rows_ordered": [P, P, P, I, P, I, I, F, P, P],
     "ader_ln_fwd": [P, L, P, L, P, P, P, P, P, P, I, I, P],
     "ader_ln_bwd_slabs": [I],
     "ader_ln_bwd": [P, L, P, L, P, P, P, P, L, P, L, P, P, P, I, I, P],

@@ -129,6 +129,23 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const int* __restrict__ id
     for (int c = lane; c < H; c += 64) atomicAdd(de + c, g[c] * scale);
 }
 
+// The same without atomics: entries bucketed by id (ader_sparse_lists: buckets of `gran` ids in id order, inside a bucket in POSITION
+// order).  One workgroup per bucket, thread c owns column c and adds the bucket's rows one after the other: the sum of a table row is
+// formed in position order -- bit-reproducible, and bit-IDENTICAL on every rank that holds the same gathered rows (the float
+// atomics of k_scatter_rows arrive in a run- and rank-dependent order, which let data-parallel replicas drift apart).
+__global__ __launch_bounds__(192) void k_scatter_rows_ordered(const int* __restrict__ ids, const int* __restrict__ rws,
+                                                              const int* __restrict__ start, const float* __restrict__ rows,
+                                                              float* __restrict__ demb, int H, int V, float scale) {
+    const int k0 = start[blockIdx.x], k1 = start[blockIdx.x + 1];
+    for (int c = threadIdx.x; c < H; c += 192) {
+        for (int k = k0; k < k1; ++k) {                     // list order = position order inside the bucket
+            const int id = ids[k];
+            if (id <= 0 || id >= V) continue;
+            demb[(size_t)id * H + c] += rows[(size_t)rws[k] * H + c] * scale;
+        }
+    }
+}
+
 // dpos[t][c] = sum_b g[b*T + t][c].  Each workgroup owns 32 consecutive (t,c) outputs; 8 b-slices accumulate
 // sequentially and are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ g, float* __restrict__ dpos, int B, int T, int H) {
@@ -470,6 +487,16 @@ int ader_ewc_penalty(const float* theta, const float* prev, const float* F, floa
 int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, float scale, float* demb, void* stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_scatter_rows, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, rows, demb, n, H, V, scale);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// demb[ids[k]] += rows[rws[k]] * scale in list order, bucket by bucket (lists from ader_sparse_lists over the gathered ids; nb =
+// number of buckets): deterministic counterpart of ader_scatter_rows.
+int ader_scatter_rows_ordered(const int* ids, const int* rws, const int* start, int nb, const float* rows, int H, int V, float scale,
+                              float* demb, void* stream) {
+    if (nb <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter_rows_ordered, dim3(nb), dim3(192), 0, (hipStream_t)stream, ids, rws, start, rows, demb, H, V, scale);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -181,5 +181,9 @@ class DataParallel:
             dist.all_reduce(eng.grad[table_span:], op=dist.ReduceOp.SUM, group=self.group)   # ... and every non-table parameter
         for w in works:
             w.wait()                                                                  # table buckets (started before the blocks backward)
-        call("ader_scatter_rows", ptr(ids_g), ptr(rows_g), ids_g.numel(), H, eng.V, float(np.sqrt(np.float32(H))),
-             ptr(eng.gradient("emb")), eng._stream())
+        # every rank adds the SAME gathered rows in the SAME order (bucketed by id, position order inside a table row): the reduced
+        # gradient stays bit-identical across the replicas -- float atomics here let theta / m / v drift apart between ranks
+        lab0 = eng.buf("dp_lab0", (1,), torch.int32, zero=True)
+        ids_s, order, sp_start, _, _, _, _ = eng._sparse_lists(ids_g, lab0, self.max_item)
+        call("ader_scatter_rows_ordered", ptr(ids_s), ptr(order), ptr(sp_start), sp_start.numel() - 1, ptr(rows_g), H, eng.V,
+             float(np.sqrt(np.float32(H))), ptr(eng.gradient("emb")), eng._stream())

@@ -45,6 +45,10 @@ int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, in
  * differentiated) for rows already masked / dropout-scaled by ader_embed_bwd_rows -- used by the data-parallel dense exchange to add
  * the input-embedding rows of every rank after the table gradient's all-reduce. */
 int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, float scale, float* demb, void* stream);
+/* ... without atomics: (ids, rws, start) = the bucketed lists ader_sparse_lists builds from the ids (nb buckets); every table row is
+ * summed in position order -- bit-identical on every data-parallel rank that holds the same gathered rows (modules.py:127 gradient) */
+int ader_scatter_rows_ordered(const int* ids, const int* rws, const int* start, int nb, const float* rows, int H, int V, float scale,
+                              float* demb, void* stream);
 
 /* ---- LayerNorm: modules.py:23-50 (`normalize`) ---------------------------------------------------------- */
 /* xnz/ynz (optional) = sign(|sum_c x|), sign(|sum_c y|): the key / query masks of modules.py:188,208. */
