@@ -155,6 +155,13 @@ def param_layout(item_num, T, H, L, align=64, table_rows_alloc=None):
     return layout, off
 
 
+def _check(cond, msg):
+    """Shape / dtype / range violations of the operator surface raise RuntimeError (what TF's InvalidArgumentError
+    becomes; never an AssertionError, which `python -O` would drop)."""
+    if not cond:
+        raise RuntimeError(msg)
+
+
 class Engine:
     MAX_ROWS = 1024        # padded batch rows per launch of the exact-f32 logit kernels (per-row state in LDS) and of the eval paths
     MAX_ROWS_FAST = 4096   # ... of a train step whose logits run on the flash kernels (logits_dtype bf16 / x3): 128-row chunks
@@ -164,11 +171,13 @@ class Engine:
         if not torch.cuda.is_available():
             raise _lib.AderHipError("ader_amd.Engine needs an MI355X (no CPU fallback)")
         _lib.load()
-        assert hidden_units <= 159 and maxlen <= 64 and hidden_units % num_heads == 0
+        _check(hidden_units <= 159 and maxlen <= 64 and hidden_units % num_heads == 0,
+               "ader_amd.Engine: hidden_units <= 159, maxlen <= 64, hidden_units %% num_heads == 0 (got %d, %d, %d)"
+               % (hidden_units, maxlen, num_heads))
         self.item_num, self.T, self.H, self.L, self.heads = item_num, maxlen, hidden_units, num_blocks, num_heads
         self.V = item_num + 1
         self.seed = seed
-        assert logits_dtype in ("f32", "bf16", "x3")
+        _check(logits_dtype in ("f32", "bf16", "x3"), "logits_dtype must be 'f32', 'bf16' or 'x3' (got %r)" % (logits_dtype,))
         # "bf16": logit GEMMs on v_mfma_f32_32x32x16_bf16 with bf16-rounded operands (fp32 master table, fp32 accumulate and
         # softmax); "x3": the same kernels at float32 grade -- every product as three bf16 MFMAs on hi/lo operand splits
         # (~2^-16 relative, the reference's fp32 arithmetic of ADER.py:91-93 on the bf16 matrix cores), no bf16 shadow;
@@ -192,7 +201,7 @@ class Engine:
         self.shadow = (torch.zeros(self.V_alloc * 168, dtype=torch.bfloat16, device=self.device)
                        if logits_dtype == "bf16" and hidden_units % 2 == 0 else None)
         # block GEMMs: "x3" = bf16 hi/lo split on the bf16 matrix cores (float32-grade accuracy), "f32" = exact f32 MFMA
-        assert gemm in ("x3", "f32")
+        _check(gemm in ("x3", "f32"), "gemm must be 'x3' or 'f32' (got %r)" % (gemm,))
         self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
         # whole forward stack in one launch (seq_fwd.hip); the per-op kernels remain for the shapes it does not cover
         self.seq_fused = (self.gemm_x3 and num_heads == 1 and maxlen <= 64 and num_blocks <= _lib.SEQ_MAXL)
@@ -373,6 +382,9 @@ class Engine:
         per = self._ws_store.setdefault(name, collections.OrderedDict())
         t = per.get(key)
         if t is None:
+            if zero and self._main is not None and self._st_ptr is not None and self._st_ptr != self._main.cuda_stream:
+                raise RuntimeError("Engine.buf(%r, zero=True) first requested inside a side-stream section: its fill would run on "
+                                   "the main stream, unordered with the side-stream kernels" % name)
             t = (torch.zeros if zero else torch.empty)(key[0], dtype=dtype, device=self.device)
             per[key] = t
             while len(per) > 4:
@@ -695,20 +707,23 @@ class Engine:
         pos = self._dev_i32(pos)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
         cap = self.MAX_ROWS_FAST if self.lfast else self.MAX_ROWS
-        assert B <= cap, "at most %d rows per step with logits_dtype=%s" % (cap, self.logits_dtype)
+        _check(seq.dim() == 2 and seq.shape[1] == T, "input_seq must be [rows, maxlen = %d] (got %s)" % (T, tuple(seq.shape)))
+        _check(B <= cap, "at most %d rows per step with logits_dtype=%s (got %d)" % (cap, self.logits_dtype, B))
         n_train = pos.shape[0]
         n_ex = B - n_train
         N = int(max_item)
-        assert 1 <= N <= self.item_num
+        _check(1 <= N <= self.item_num, "max_item must be in [1, item_num = %d] (got %d)" % (self.item_num, N))
+        _check(0 <= n_train <= B, "pos has %d rows but input_seq only %d" % (n_train, B))
         Np = 0
         if n_ex > 0:
             if teacher is not None:
                 ex_trow = self._dev_i32(ex_trow if ex_trow is not None else np.arange(n_ex))
                 Np = teacher.shape[1]
-                assert teacher.dtype == torch.float32 and teacher.stride(1) == 1 and Np <= N
+                _check(teacher.dtype == torch.float32 and teacher.stride(1) == 1 and Np <= N,
+                       "exemplar_logits must be float32 [*, Np <= max_item], unit stride along the items")
             else:
                 ex_pos = self._dev_i32(ex_pos)
-                assert ex_pos.shape[0] == n_ex
+                _check(ex_pos.shape[0] == n_ex, "exemplar_pos has %d rows, the batch %d exemplar rows" % (ex_pos.shape[0], n_ex))
         w_train = 1.0 / float(n_train_global if n_train_global is not None else max(n_train, 1))
         w_ex = (lambda_ / float(n_ex_global if n_ex_global is not None else n_ex)) if n_ex > 0 else 0.0
         step = self.global_step
@@ -1278,7 +1293,8 @@ class Engine:
         B, T, H, S = seq.shape[0], self.T, self.H, self.shard_items
         N = int(max_item)
         Bp = (B + 127) // 128 * 128
-        assert pos.shape[0] == B and B <= self.MAX_ROWS and 1 <= N <= self.item_num
+        _check(pos.shape[0] == B and B <= self.MAX_ROWS and 1 <= N <= self.item_num,
+               "catalog-sharded step: pos rows == input rows <= %d and 1 <= max_item <= item_num" % self.MAX_ROWS)
         st = self._stream()
         step = self.global_step
         n_pos, n_all = B * T, B * T + B
@@ -1576,7 +1592,11 @@ class Engine:
     def compute_fisher(self, seq, pos, max_item):
         """Diagonal Fisher information of EWC.py:126-164: the mean over the n given sub-sequences of the SQUARED per-sample
         gradient of the eval-mode cross entropy (batch of one, dropout off) w.r.t. every parameter -> self.ewc["F"] (flat, the
-        parameter layout).  One forward / backward per sample like the reference (n <= --ewc_sample_num = 1000)."""
+        parameter layout).  One forward / backward per sample like the reference (n <= --ewc_sample_num = 1000).
+        Deviation, on purpose: the reference densifies the position table's IndexedSlices gradient with `dense[idx] = value`
+        (EWC.py:153-157), an ASSIGNMENT -- for a row that occurs more than once in a sample only the last slice survives -- whereas
+        the SUMMED gradient is squared here (the mathematical Fisher diagonal).  Only rows repeated inside one sample differ
+        (tests/test_gpu_extras.py pins the summed semantics against the oracle)."""
         self._refresh_stream()
         self.sync_table()
         if self.ewc is None:

@@ -112,6 +112,10 @@ class Ewc(Ader):
         from .data import Sampler
         smp = Sampler(data, self.args.maxlen, batch_size, is_subseq=True)
         if dry_run:
+            # the reference draws batch_num() batches (EWC.py:139-141): the last draw wraps around and reshuffles the index list
+            # (util.py:232-237), a second consumption of the `random` stream that a dry run must reproduce as well
+            for _ in range(smp.batch_num()):
+                smp._next_indices()
             return
         seqs, poss = [], []
         for _ in range(smp.batch_num()):
