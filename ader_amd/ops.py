@@ -12,6 +12,13 @@ violation (never clamps ids, never falls back to the CPU).  `import ader_amd.ops
   ader::adam_step(p, m, v, g, lr_t, beta1, beta2, eps)         -> ()     in place, ADER.py:96 (TF ApplyAdam)
   ader::rank_of_target(rep, emb, target, N)                    -> rank   ADER.py:99-103 + util.py:325
   ader::herding_select(rep, seg, quota, max_steps)             -> (sel, cnt)   util.py:401-434
+
+Trainable surface (second half of this file; every forward has an autograd formula over its `_bwd` operator):
+  ader::embed_fwd / embed_bwd                                  ADER.py:25-60, modules.py:118-130
+  ader::layernorm / layernorm_bwd                              modules.py:23-50 (+ the key / query mask bits)
+  ader::attn_fwd / attn_bwd                                    modules.py:135-229 (Q/K/V projections included)
+  ader::ffn_fwd / ffn_bwd                                      modules.py:232-271 + ADER.py:80
+  ader::logits_ce / logits_ce_bwd                              ADER.py:88-93 (exact-f32 logits, one-hot CE)
 """
 import torch
 
@@ -159,3 +166,307 @@ def herding_select(rep: torch.Tensor, seg: torch.Tensor, quota: torch.Tensor, ma
 @herding_select.register_fake
 def _(rep, seg, quota, max_steps):
     return quota.new_empty(rep.shape[0]), quota.new_empty(quota.shape[0])
+
+
+# ================================================================================================ trainable surface
+# SURVEY 8(b) "Native ABI": embed_fwd/bwd, layernorm_fwd/bwd, attn_fwd/bwd, ffn_fwd/bwd, logits_ce_fwd/bwd over the exact-f32
+# launchers, each forward with a registered autograd formula, so that torch.ops.ader.* composes into a trainable graph
+# (tests/test_gpu_ops_autograd.py trains one SASRec step through these ops + torch.autograd and compares every gradient with
+# Engine.loss_and_grad).  Dropout is the counter-hash of the kernels: (key, thr, scale) per site, thr = 0 disables it.
+import ctypes
+
+
+def _drop(key, thr, scale):
+    return ctypes.byref(_lib.AderDrop(key & 0xFFFFFFFF, thr, scale, 0, 0xFFFFFFFF, 0))
+
+
+def _atb(A, G):
+    """dW = A^T G [H,H], db = colsum(G) [H]"""
+    M, H = A.shape
+    slab = torch.empty(call("ader_gemm_atb_slabs", M) * 160 * 160, device=A.device)
+    dW, db = torch.empty(H, H, device=A.device), torch.empty(H, device=A.device)
+    call("ader_gemm_atb", ptr(A), ptr(G), ptr(slab), ptr(dW), ptr(db), M, H, _st())
+    return dW, db
+
+
+def _gemm(A, W, bias, aux, seq, epi, trans, drop=None):
+    M, H = A.shape
+    C = torch.empty(M, H, device=A.device)
+    call("ader_gemm_rows", ptr(A), ptr(W), ptr(bias), ptr(C), ptr(aux), ptr(seq), M, H, epi, trans, 1, 0, drop, _st())
+    return C
+
+
+# ---- embedding prologue: x = drop(E0[seq] * sqrt(H) + P) * (seq != 0)   (ADER.py:25-60, modules.py:118-130)
+@torch.library.custom_op("ader::embed_bwd", mutates_args=())
+def embed_bwd(seq: torch.Tensor, dx: torch.Tensor, V: int, key: int, thr: int, scale: float) -> tuple[torch.Tensor, torch.Tensor]:
+    _chk(seq, "seq", torch.int32, 2), _chk(dx, "dx", torch.float32, 3)
+    B, T = seq.shape
+    H = dx.shape[2]
+    g = dx.clone()                                   # (the launcher scales the rows in place)
+    demb, dpos = torch.zeros(V, H, device=dx.device), torch.zeros(T, H, device=dx.device)
+    call("ader_embed_bwd", ptr(seq), ptr(g), ptr(demb), ptr(dpos), B, T, H, V, _drop(key, thr, scale), _st())
+    return demb, dpos
+
+
+@embed_bwd.register_fake
+def _(seq, dx, V, key, thr, scale):
+    return dx.new_empty(V, dx.shape[2]), dx.new_empty(seq.shape[1], dx.shape[2])
+
+
+def _embed_setup(ctx, inputs, output):
+    seq, emb, pos, key, thr, scale = inputs
+    ctx.save_for_backward(seq)
+    ctx.meta = (emb.shape[0], key, thr, scale)
+
+
+def _embed_backward(ctx, dx):
+    (seq,) = ctx.saved_tensors
+    V, key, thr, scale = ctx.meta
+    demb, dpos = torch.ops.ader.embed_bwd(seq, dx.contiguous(), V, key, thr, scale)
+    return None, demb, dpos, None, None, None
+
+
+torch.library.register_autograd("ader::embed_fwd", _embed_backward, setup_context=_embed_setup)
+
+
+# ---- LayerNorm (modules.py:23-50) with the key / query masks of modules.py:188-193, 208-211 as by-products
+@torch.library.custom_op("ader::layernorm", mutates_args=())
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (y, mean, std, xnz, ynz): xnz[r] = (sum_c x[r,c] != 0) (key mask), ynz[r] = (sum_c y[r,c] != 0) (query mask)"""
+    _chk(x, "x", torch.float32, 2), _chk(gamma, "gamma", torch.float32, 1), _chk(beta, "beta", torch.float32, 1)
+    rows, H = x.shape
+    if gamma.shape[0] != H or beta.shape[0] != H:
+        raise RuntimeError("ader::layernorm: gamma / beta must be [H]")
+    y = torch.empty_like(x)
+    mean, std, xnz, ynz = (torch.empty(rows, device=x.device) for _ in range(4))
+    call("ader_ln_fwd", ptr(x), H, ptr(y), H, ptr(gamma), ptr(beta), ptr(mean), ptr(std), ptr(xnz), ptr(ynz), rows, H, _st())
+    return y, mean, std, xnz, ynz
+
+
+@layernorm.register_fake
+def _(x, gamma, beta):
+    r = x.shape[0]
+    return torch.empty_like(x), x.new_empty(r), x.new_empty(r), x.new_empty(r), x.new_empty(r)
+
+
+@torch.library.custom_op("ader::layernorm_bwd", mutates_args=())
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
+                  std: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    _chk(dy, "dy", torch.float32, 2), _chk(x, "x", torch.float32, 2)
+    rows, H = x.shape
+    dx = torch.empty_like(x)
+    slab = torch.empty(call("ader_ln_bwd_slabs", rows) * 2 * H, device=x.device)
+    dg, db = torch.empty(H, device=x.device), torch.empty(H, device=x.device)
+    call("ader_ln_bwd", ptr(dy), H, ptr(x), H, ptr(gamma), ptr(mean), ptr(std), None, 0, ptr(dx), H, ptr(slab), ptr(dg), ptr(db),
+         rows, H, _st())
+    return dx, dg, db
+
+
+@layernorm_bwd.register_fake
+def _(dy, x, gamma, mean, std):
+    return torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+def _ln_setup(ctx, inputs, output):
+    x, gamma, beta = inputs
+    ctx.save_for_backward(x, gamma, output[1], output[2])
+
+
+def _ln_backward(ctx, dy, dmean, dstd, dxnz, dynz):
+    x, gamma, mean, std = ctx.saved_tensors
+    dx, dg, db = torch.ops.ader.layernorm_bwd(dy.contiguous(), x, gamma, mean, std)
+    return dx, dg, db
+
+
+torch.library.register_autograd("ader::layernorm", _ln_backward, setup_context=_ln_setup)
+
+
+# ---- multi-head attention of modules.py:135-229: Q = q_in Wq + bq, K = x Wk + bk, V = x Wv + bv, causal + key masks, softmax,
+# query mask, dropout on the probabilities, . V, + q_in (the NORMALISED queries as residual)
+@torch.library.custom_op("ader::attn_fwd", mutates_args=())
+def attn_fwd(x: torch.Tensor, q_in: torch.Tensor, wq: torch.Tensor, bq: torch.Tensor, wk: torch.Tensor, bk: torch.Tensor,
+             wv: torch.Tensor, bv: torch.Tensor, kmask: torch.Tensor, qmask: torch.Tensor, B: int, T: int, heads: int, key: int,
+             thr: int, scale: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x, q_in [B*T,H] -> (out [B*T,H], Q, K, V, P [B*heads*T*T])"""
+    _chk(x, "x", torch.float32, 2), _chk(q_in, "q_in", torch.float32, 2)
+    rows, H = x.shape
+    if rows != B * T or q_in.shape != x.shape or H % heads:
+        raise RuntimeError("ader::attn_fwd: x, q_in must be [B*T, H] with H % heads == 0")
+    Q = _gemm(q_in, wq, bq, None, None, 0, 0)
+    K = _gemm(x, wk, bk, None, None, 0, 0)
+    Vv = _gemm(x, wv, bv, None, None, 0, 0)
+    out = torch.empty_like(x)
+    P = torch.empty(B * heads * T * T, device=x.device)
+    call("ader_attn_fwd", ptr(Q), ptr(K), ptr(Vv), ptr(q_in), ptr(kmask), ptr(qmask), ptr(out), ptr(P), B, T, H, heads,
+         _drop(key, thr, scale), _st())
+    return out, Q, K, Vv, P
+
+
+@attn_fwd.register_fake
+def _(x, q_in, wq, bq, wk, bk, wv, bv, kmask, qmask, B, T, heads, key, thr, scale):
+    return torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), x.new_empty(B * heads * T * T)
+
+
+@torch.library.custom_op("ader::attn_bwd", mutates_args=())
+def attn_bwd(dO: torch.Tensor, x: torch.Tensor, q_in: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor,
+             Q: torch.Tensor, K: torch.Tensor, Vv: torch.Tensor, P: torch.Tensor, kmask: torch.Tensor, qmask: torch.Tensor, B: int,
+             T: int, heads: int, key: int, thr: int,
+             scale: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (dx, dq_in, dwq, dbq, dwk, dbk, dwv, dbv)"""
+    rows, H = x.shape
+    dQ, dK, dV = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    call("ader_attn_bwd", ptr(dO), ptr(Q), ptr(K), ptr(Vv), ptr(P), ptr(kmask), ptr(qmask), ptr(dQ), ptr(dK), ptr(dV), B, T, H, heads,
+         _drop(key, thr, scale), _st())
+    dq_in = _gemm(dQ, wq, None, dO, None, 4, 1)                       # dQ Wq^T + dO (the residual adds the normalised queries)
+    dx = _gemm(dK, wk, None, None, None, 0, 1)
+    dx = _gemm(dV, wv, None, dx, None, 4, 1)
+    dwq, dbq = _atb(q_in, dQ)
+    dwk, dbk = _atb(x, dK)
+    dwv, dbv = _atb(x, dV)
+    return dx, dq_in, dwq, dbq, dwk, dbk, dwv, dbv
+
+
+@attn_bwd.register_fake
+def _(dO, x, q_in, wq, wk, wv, Q, K, Vv, P, kmask, qmask, B, T, heads, key, thr, scale):
+    e = torch.empty_like
+    return e(x), e(x), e(wq), wq.new_empty(wq.shape[0]), e(wk), wk.new_empty(wk.shape[0]), e(wv), wv.new_empty(wv.shape[0])
+
+
+def _attn_setup(ctx, inputs, output):
+    x, q_in, wq, bq, wk, bk, wv, bv, kmask, qmask, B, T, heads, key, thr, scale = inputs
+    ctx.save_for_backward(x, q_in, wq, wk, wv, output[1], output[2], output[3], output[4], kmask, qmask)
+    ctx.meta = (B, T, heads, key, thr, scale)
+
+
+def _attn_backward(ctx, dO, dQ_, dK_, dV_, dP_):
+    x, q_in, wq, wk, wv, Q, K, Vv, P, kmask, qmask = ctx.saved_tensors
+    dx, dq_in, dwq, dbq, dwk, dbk, dwv, dbv = torch.ops.ader.attn_bwd(dO.contiguous(), x, q_in, wq, wk, wv, Q, K, Vv, P, kmask, qmask,
+                                                                      *ctx.meta)
+    return dx, dq_in, dwq, dbq, dwk, dbk, dwv, dbv, None, None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ader::attn_fwd", _attn_backward, setup_context=_attn_setup)
+
+
+# ---- position-wise feed-forward of modules.py:232-271 + ADER.py:80: (drop(drop(relu(y W1 + b1)) W2 + b2) + y) * (seq != 0)
+@torch.library.custom_op("ader::ffn_fwd", mutates_args=())
+def ffn_fwd(y: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, seq: torch.Tensor, key1: int,
+            thr1: int, scale1: float, key2: int, thr2: int, scale2: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """y [B*T,H] (the LayerNorm'd block input), seq int32 [B,T] -> (x2, h1d = drop(relu(y W1 + b1)))"""
+    _chk(y, "y", torch.float32, 2), _chk(seq, "seq", torch.int32, 2)
+    if y.shape[0] != seq.numel():
+        raise RuntimeError("ader::ffn_fwd: y must have one row per position of seq")
+    h1d = _gemm(y, w1, b1, None, None, 1, 0, _drop(key1, thr1, scale1))
+    x2 = _gemm(h1d, w2, b2, y, seq, 2, 0, _drop(key2, thr2, scale2))
+    return x2, h1d
+
+
+@ffn_fwd.register_fake
+def _(y, w1, b1, w2, b2, seq, key1, thr1, scale1, key2, thr2, scale2):
+    return torch.empty_like(y), torch.empty_like(y)
+
+
+@torch.library.custom_op("ader::ffn_bwd", mutates_args=())
+def ffn_bwd(dx2: torch.Tensor, y: torch.Tensor, h1d: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, seq: torch.Tensor, key1: int,
+            thr1: int, scale1: float, key2: int, thr2: int,
+            scale2: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (dy, dw1, db1, dw2, db2)"""
+    M, H = y.shape
+    g, dh2 = torch.empty_like(y), torch.empty_like(y)
+    call("ader_mask_dropgrad", ptr(dx2), ptr(seq), ptr(g), ptr(dh2), M, H, 1, 0, _drop(key2, thr2, scale2), _st())
+    da = _gemm(dh2, w2, None, h1d, None, 3, 1, _drop(key1, thr1, scale1))          # through W2^T, the first dropout and the ReLU
+    dy = _gemm(da, w1, None, g, None, 4, 1)                                        # through W1^T, + the residual's gradient
+    dw2, db2 = _atb(h1d, dh2)
+    dw1, db1 = _atb(y, da)
+    return dy, dw1, db1, dw2, db2
+
+
+@ffn_bwd.register_fake
+def _(dx2, y, h1d, w1, w2, seq, key1, thr1, scale1, key2, thr2, scale2):
+    e = torch.empty_like
+    return e(y), e(w1), w1.new_empty(w1.shape[0]), e(w2), w2.new_empty(w2.shape[0])
+
+
+def _ffn_setup(ctx, inputs, output):
+    y, w1, b1, w2, b2, seq, *d = inputs
+    ctx.save_for_backward(y, output[1], w1, w2, seq)
+    ctx.meta = tuple(d)
+
+
+def _ffn_backward(ctx, dx2, dh1d):
+    y, h1d, w1, w2, seq = ctx.saved_tensors
+    dy, dw1, db1, dw2, db2 = torch.ops.ader.ffn_bwd(dx2.contiguous(), y, h1d, w1, w2, seq, *ctx.meta)
+    return dy, dw1, db1, dw2, db2, None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ader::ffn_fwd", _ffn_backward, setup_context=_ffn_setup)
+
+
+# ---- full-catalog logits + one-hot softmax cross entropy (ADER.py:88-93), exact-f32 kernels: loss = sum_b w_b (lse_b - s_b[label_b])
+def _rowinfo(labels, weights, N, dev):
+    B = labels.shape[0]
+    Bp = (B + 63) // 64 * 64
+    lab, ncol = torch.zeros(Bp, dtype=torch.int32, device=dev), torch.zeros(Bp, dtype=torch.int32, device=dev)
+    w, trow, tlse = torch.zeros(Bp, device=dev), torch.full((Bp,), -1, dtype=torch.int32, device=dev), torch.zeros(Bp, device=dev)
+    lab[:B], ncol[:B], w[:B] = labels, N, weights
+    return Bp, lab, ncol, w, trow, tlse
+
+
+@torch.library.custom_op("ader::logits_ce", mutates_args=())
+def logits_ce(rep: torch.Tensor, emb: torch.Tensor, labels: torch.Tensor, weights: torch.Tensor, N: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """rep [B,H], emb [V,H] (row 0 = padding item), labels int32 [B] 1-based, weights [B] -> (loss [1], lse [B])"""
+    _chk(rep, "rep", torch.float32, 2), _chk(emb, "emb", torch.float32, 2), _chk(labels, "labels", torch.int32, 1)
+    _chk(weights, "weights", torch.float32, 1)
+    B, H = rep.shape
+    if emb.shape[1] != H or not (1 <= N <= emb.shape[0] - 1) or labels.shape[0] != B or weights.shape[0] != B or B > 1024:
+        raise RuntimeError("ader::logits_ce: bad shapes")
+    dev = rep.device
+    Bp, lab, ncol, w, trow, tlse = _rowinfo(labels, weights, N, dev)
+    part = torch.empty(call("ader_logits_parts", N) * Bp * 3, device=dev)
+    lse, rowloss, loss = torch.empty(Bp, device=dev), torch.empty(Bp, device=dev), torch.zeros(1, device=dev)
+    call("ader_logits_loss_fwd", ptr(rep), ptr(emb), B, Bp, H, N, ptr(lab), ptr(ncol), ptr(w), ptr(trow), ptr(tlse), None, 0,
+         ptr(part), ptr(lse), ptr(rowloss), ptr(loss), _st())
+    return loss, lse[:B].clone()
+
+
+@logits_ce.register_fake
+def _(rep, emb, labels, weights, N):
+    return rep.new_empty(1), rep.new_empty(rep.shape[0])
+
+
+@torch.library.custom_op("ader::logits_ce_bwd", mutates_args=())
+def logits_ce_bwd(rep: torch.Tensor, emb: torch.Tensor, labels: torch.Tensor, weights: torch.Tensor, lse: torch.Tensor,
+                  N: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (drep [B,H], demb [V,H]) for d loss = 1"""
+    B, H = rep.shape
+    dev = rep.device
+    Bp, lab, ncol, w, trow, tlse = _rowinfo(labels, weights, N, dev)
+    lse_p = torch.zeros(Bp, device=dev)
+    lse_p[:B] = lse
+    slab = torch.empty(call("ader_logits_ranges", N, Bp) * Bp * 160, device=dev)
+    drep, demb = torch.empty(B, H, device=dev), torch.zeros_like(emb)
+    call("ader_logits_bwd_drep", ptr(rep), ptr(emb), B, Bp, H, N, ptr(lab), ptr(ncol), ptr(w), ptr(trow), ptr(tlse), None, 0,
+         ptr(lse_p), ptr(slab), ptr(drep), _st())
+    call("ader_logits_bwd_demb", ptr(rep), ptr(emb), B, Bp, H, N, ptr(lab), ptr(ncol), ptr(w), ptr(trow), ptr(tlse), None, 0,
+         ptr(lse_p), ptr(demb), _st())
+    return drep, demb
+
+
+@logits_ce_bwd.register_fake
+def _(rep, emb, labels, weights, lse, N):
+    return torch.empty_like(rep), torch.empty_like(emb)
+
+
+def _lce_setup(ctx, inputs, output):
+    rep, emb, labels, weights, N = inputs
+    ctx.save_for_backward(rep, emb, labels, weights, output[1])
+    ctx.N = N
+
+
+def _lce_backward(ctx, dloss, dlse):
+    rep, emb, labels, weights, lse = ctx.saved_tensors
+    drep, demb = torch.ops.ader.logits_ce_bwd(rep, emb, labels, weights, lse, ctx.N)
+    return drep * dloss, demb * dloss, None, None, None
+
+
+torch.library.register_autograd("ader::logits_ce", _lce_backward, setup_context=_lce_setup)
