@@ -158,6 +158,9 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             x0[ks] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rt, vt, 128 * ks, 0));
             x1[ks] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rt, vt, 128 * ks + 16, 0));
         }
+        // (Measured and dropped: touching the theta rows of tile + 768 here -- one dword per 64 bytes, results unused, so that the next
+        //  workgroup of the slot finds them on the chip -- made the kernel 3 % slower; so did prefetching theta / m / v of that tile by
+        //  LDS-DMA from a fourth "prefetch" wave during the GEMM phase (+12 %): L2-hit rep pieces queue behind the HBM misses.)
         for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
         if (KD) {
             for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
@@ -491,7 +494,9 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
 
 // ============================================================================================= launch (C ABI: table_update.hip)
 static size_t tab16x3_lds(int Bp, int Bk) {
-    return (size_t)2 * X3_IMG_B + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int) + (size_t)Bk * 8;
+    static int pad = -1;                  // ADER_X3_LDSPAD: extra bytes (timing experiments: fewer workgroups per CU)
+    if (pad < 0) { const char* e = getenv("ADER_X3_LDSPAD"); pad = e ? atoi(e) : 0; }
+    return (size_t)2 * X3_IMG_B + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int) + (size_t)Bk * 8 + pad;
 }
 
 template <bool EXTRA, bool KD>
