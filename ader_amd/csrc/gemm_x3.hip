@@ -11,28 +11,17 @@
 //   ader_gemm_atb_x3 : dW = A^T . G, db = colsum(G)   (operands read k-major from row-major LDS tiles with
 //                      ds_read_b64_tr_b16; per-workgroup slabs, deterministic reduce)
 // H <= 159 (ones-column bias trick), H even.  gfx950 only.
-#include "common.h"
+#include "lbf_common.h"
+#include "x3_image.h"
+#include <string.h>
+#include <stdlib.h>
 #include "../../include/ader_hip.h"
 
-typedef __bf16 bf16;
-typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-#define HP 160
-#define LDR 168
 #define TM 64
 #define WSZ (HP * LDR)            // elements of one prepared weight plane
 
 enum { EPI_BIAS = 0, EPI_BIAS_RELU_DROP = 1, EPI_BIAS_DROP_RES_MASK = 2, EPI_RELUDROPGRAD = 3, EPI_ADD = 4 };
 
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
-__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
-}
 __device__ __forceinline__ void split2(float x, float y, bf16x2& hi, bf16x2& lo) {
     hi[0] = (bf16)x; hi[1] = (bf16)y;
     lo[0] = (bf16)(x - (float)hi[0]); lo[1] = (bf16)(y - (float)hi[1]);
@@ -303,6 +292,130 @@ __global__ __launch_bounds__(256) void k_atb_reduce_batch(AtbBatch b, const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small-footprint form of the batched weight-gradient products: the one that runs INSIDE the fused table update.
+// k_gemm_atb_x3_batch (86 KB of LDS, 256 registers x 5 waves) can not share a CU with update workgroups (k_tab16x3: three per CU,
+// 168 registers, ~47 KB each), so it used to start when the update drained: a ~0.1 ms tail on every step.  This form is cut to the
+// hole ONE retiring update workgroup leaves: 256 threads, <= 168 registers, 43.5 KB of LDS, so the high-priority side stream gets
+// its workgroups placed as update workgroups retire.  32-row tiles (the K of one v_mfma_f32_16x16x32_bf16), operands stored as the
+// conflict-free hi / lo images of x3_image.h (both operands are read k-major: ds_read_b64_tr_b16), wave w owns output-channel
+// row blocks {2w, 2w+1} x 10 column blocks + half of row block 8 + (w >> 1): 25 blocks of 16x16 = 100 accumulator registers.
+// No register prefetch across the MFMA phase (the accumulators leave no room): its latency is covered by the update workgroups
+// on the same CU -- this is filler work, not a kernel that has the chip to itself.  Slabs and reduce: as the large form.
+#define SM_TM 32
+struct __attribute__((packed, aligned(8))) AtbVec { f32x4v v; };      // 16-byte vector at an 8-byte aligned address
+#define SM_LDS (4 * X3_PLANE_B)
+template <int HT>       // HT: hidden size known at compile time (150: the reference default, main.py:104) or 0 = runtime
+__global__ __launch_bounds__(256, 3) void k_gemm_atb_x3_sm(AtbBatch b, float* __restrict__ slab, int Hrt) {
+    const int H = HT ? HT : Hrt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int y = 0;
+#pragma unroll 1
+    while (y + 1 < b.n && (int)blockIdx.x >= b.wg0[y + 1]) ++y;
+    const float* __restrict__ A = b.A[y];
+    const float* __restrict__ G = b.G[y];
+    const int M = b.M[y];
+    const int wg = blockIdx.x - b.wg0[y], nwg = b.wg0[y + 1] - b.wg0[y];
+    float* __restrict__ out = slab + (size_t)blockIdx.x * HP * HP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
+    unsigned char* Ah = smem_raw;                      // planes: A hi, A lo, G hi, G lo
+    for (int i = tid; i < SM_LDS / 16; i += 256) ((uint4*)smem_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+    f32x4v acc[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const int nkc = (H + 8) >> 3;                      // k-chunks that hold channels 0..H (channel H of A: the ones column -> db)
+    const int nslot = SM_TM * nkc;
+    const int n_tiles = (M + SM_TM - 1) / SM_TM;
+    // transposed read of (rows 4g + q4 and 16 + 4g + q4, 16-channel block cb): see x3_image.h
+    const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
+    const int rb2 = 8 + (wave >> 1), cb2 = 5 * (wave & 1);
+    __syncthreads();
+    for (int tile = wg; tile < n_tiles; tile += nwg) {
+        const int m0 = tile * SM_TM;
+        // ---- stage: slot s = (row m = s / nkc, k-chunk kc = s % nkc): consecutive lanes read consecutive 32-byte pieces of a row
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {               // one operand at a time: 40 staging registers beside the 100 accumulators
+            const float* __restrict__ src = op ? G : A;
+            float2 v[5][4];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int s = tid + 256 * r;
+                const int m = s / nkc, kc = s - m * nkc;
+                const bool rowok = s < nslot && m0 + m < M;
+                const float* ps = src + (size_t)(m0 + m) * H + 8 * kc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[r][j] = make_float2(0.f, 0.f);
+                if (rowok && 8 * kc + 8 <= H) {            // full k-chunk: two 16-byte loads (rows are 8-byte aligned: H even)
+                    const AtbVec q0 = *(const AtbVec*)ps, q1 = *(const AtbVec*)(ps + 4);
+                    v[r][0] = make_float2(q0.v[0], q0.v[1]); v[r][1] = make_float2(q0.v[2], q0.v[3]);
+                    v[r][2] = make_float2(q1.v[0], q1.v[1]); v[r][3] = make_float2(q1.v[2], q1.v[3]);
+                } else if (rowok) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (8 * kc + 2 * j < H) v[r][j] = *(const float2*)(ps + 2 * j);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int s = tid + 256 * r;
+                const int m = s / nkc, kc = s - m * nkc;
+                if (s < nslot) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[2 * j] = v[r][j].x; x[2 * j + 1] = v[r][j].y; }
+                    if (op == 0 && kc == (H >> 3) && m0 + m < M) x[H & 7] = 1.0f;          // ones column
+                    bf16x8 h_, l_;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { h_[j] = (bf16)x[j]; l_[j] = (bf16)(x[j] - (float)h_[j]); }
+                    const int so = x3_kc_off(kc) + 16 * m + 2 * op * X3_PLANE_B;
+                    *(bf16x8*)(Ah + so) = h_;
+                    *(bf16x8*)(Ah + X3_PLANE_B + so) = l_;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- products
+#define SM_FRAG(dst_, plane_, blk_)                                                                      \
+        { const bf16* tp_ = (const bf16*)(Ah + (plane_) * X3_PLANE_B + t_off + X3_QUAD * ((blk_) >> 1) + 512 * ((blk_) & 1)); \
+          const bf16x4 x0_ = tr_read(tp_), x1_ = tr_read(tp_ + 128);                                     \
+          _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) { dst_[j_] = x0_[j_]; dst_[4 + j_] = x1_[j_]; } }
+#pragma unroll
+        for (int rbi = 0; rbi < 3; ++rbi) {
+            const int rb = rbi < 2 ? 2 * wave + rbi : rb2;
+            bf16x8 ah, al;
+            SM_FRAG(ah, 0, rb);
+            SM_FRAG(al, 1, rb);
+#pragma unroll
+            for (int cbi = 0; cbi < (rbi < 2 ? 10 : 5); ++cbi) {
+                const int cb = rbi < 2 ? cbi : cb2 + cbi;
+                bf16x8 gh, gl;
+                SM_FRAG(gh, 2, cb);
+                SM_FRAG(gl, 3, cb);
+                f32x4v& c = acc[rbi < 2 ? 10 * rbi + cbi : 20 + cbi];
+                c = mfma16_bf16(al, gh, c);
+                c = mfma16_bf16(ah, gl, c);
+                c = mfma16_bf16(ah, gh, c);
+                __builtin_amdgcn_sched_barrier(0);         // keep hipcc from hoisting all fragment reads of a row block (registers)
+            }
+        }
+        __syncthreads();                                   // the tile's reads are done before the next one is stored
+    }
+    // ---- slab: out[input channel][output channel]; C layout: column = lane & 15 (G's block), rows 4 (lane >> 4) + i (A's block)
+#pragma unroll
+    for (int rbi = 0; rbi < 3; ++rbi) {
+        const int rb = rbi < 2 ? 2 * wave + rbi : rb2;
+#pragma unroll
+        for (int cbi = 0; cbi < (rbi < 2 ? 10 : 5); ++cbi) {
+            const int cb = rbi < 2 ? cbi : cb2 + cbi;
+            const f32x4v c = acc[rbi < 2 ? 10 * rbi + cbi : 20 + cbi];
+            const int col = x3_channel(cb, c16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[(size_t)x3_channel(rb, 4 * g + i) * HP + col] = c[i];
+        }
+    }
+}
+
 // ============================================================================================= C ABI
 static const size_t kGemmX3Lds = (size_t)2 * 2 * TM * LDR * sizeof(bf16);
 static const size_t kAtbX3Lds = (size_t)4 * TM * LDR * sizeof(bf16);
@@ -377,12 +490,18 @@ int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, flo
 // Batched form: n <= 16 products dW[i] = A[i]^T . G[i] (M[i] rows each), db[i] = colsum(G[i]) (db[i] may be NULL), one
 // product launch + one reduce launch.  Host arrays of device pointers.  slab: ader_gemm_atb_batch_slabs(M, n)*160*160
 // floats.  Workgroups are shared out in proportion to the rows of each product (about one per CU in total).
+static bool atb_small() {                 // ADER_ATB=big: the 86 KB form (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ADER_ATB"); v = (e && !strcmp(e, "big")) ? 0 : 1; }
+    return v == 1;
+}
 static void atb_batch_plan(const int* M, int n, int* wg0) {
+    const int tm = atb_small() ? SM_TM : TM;
     long tiles_total = 0;
-    for (int i = 0; i < n; ++i) tiles_total += (M[i] + TM - 1) / TM;
+    for (int i = 0; i < n; ++i) tiles_total += (M[i] + tm - 1) / tm;
     wg0[0] = 0;
     for (int i = 0; i < n; ++i) {
-        const long t = (M[i] + TM - 1) / TM;
+        const long t = (M[i] + tm - 1) / tm;
         long s = tiles_total > 256 ? (t * 256 + tiles_total / 2) / tiles_total : t;
         if (s < 1) s = 1;
         if (s > t && t > 0) s = t;
@@ -416,7 +535,9 @@ int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* 
     }
     b.n = n;
     atb_batch_plan(M, n, b.wg0);
-    hipLaunchKernelGGL(k_gemm_atb_x3_batch, dim3(b.wg0[n]), dim3(320), kAtbX3Lds, (hipStream_t)stream, b, slab, H);
+    if (atb_small() && H == 150) hipLaunchKernelGGL(k_gemm_atb_x3_sm<150>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
+    else if (atb_small()) hipLaunchKernelGGL(k_gemm_atb_x3_sm<0>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
+    else hipLaunchKernelGGL(k_gemm_atb_x3_batch, dim3(b.wg0[n]), dim3(320), kAtbX3Lds, (hipStream_t)stream, b, slab, H);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_atb_reduce_batch, dim3(((H + 1) * H + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, b, slab, H);
     HIP_LAUNCH_CHECK();
