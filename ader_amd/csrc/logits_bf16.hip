@@ -796,15 +796,22 @@ int lx3f_ranges(int N, int Bp);
 bool lx3f_supports(int H);
 int lx3f_launch(const Lx3Args& x, void* stream);
 int lx3g_launch(const Lx3Args& x, void* stream);
-// ADER_X3_FWD = old | f | g: the round-2 kernel (k_lx3_fwd), the 16x16x32 form (k_lx3f) or the 32x32x16 form (k_lx3g; default)
-static int lx3_kind(int H, int Bp) {
+int lx3h_launch(const Lx3Args& x, void* stream);
+// ADER_X3_FWD = old | f | g | h: the round-2 kernel (k_lx3_fwd), the 16-row 16x16x32 form (k_lx3f), the 32x32x16 form (k_lx3g) or
+// the 32-row 16x16x32 form (k_lx3h)
+static int lx3_env() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 2 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : 2)); }
+    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 2 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'h' ? 3 : 2))); }
+    return v;
+}
+static int lx3_kind(int H, int Bp) {
+    const int v = lx3_env();
     if (!lx3f_supports(H)) return 0;
     if (v == 1 && Bp % 64 == 0) return 1;
-    if (v == 2 && Bp % 128 == 0) return 2;
+    if (v >= 2 && Bp % 128 == 0) return 2;
     return 0;
 }
+static int lx3gh_launch(const Lx3Args& x, void* stream) { return lx3_env() == 3 ? lx3h_launch(x, stream) : lx3g_launch(x, stream); }
 
 // ============================================================================================= C ABI
 static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);
@@ -1011,7 +1018,7 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
     a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
     a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H);
-    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3g_launch(x, stream); if (rc) return rc; }
+    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
@@ -1049,7 +1056,7 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     a.pO2 = pO2; a.ranges2 = x.ranges2;
     hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, n_train, n_ex,
                        kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
-    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3g_launch(x, stream); if (rc) return rc; }
+    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
@@ -1081,7 +1088,7 @@ int ader_lx3_fwd_shard(const void* rep_hi, const void* rep_lo, const float* emb,
     a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     if (x.ranges > 0) {
         int rc = 0;
-        if (lx3_kind(H, Bp) == 2) rc = lx3g_launch(x, stream);
+        if (lx3_kind(H, Bp) == 2) rc = lx3gh_launch(x, stream);
         else {
             rc = lx3_attr();
             if (!rc) hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), (size_t)2 * 2 * FB * LDR * sizeof(bf16), st, x);
