@@ -68,6 +68,7 @@ struct TabArgs {
     int ko;                 // timing-only knock-outs (ADER_X3_KO; 0 in every real run): 1 no theta/m/v traffic, 2 no GEMM, 4 no DMA, 8 no barrier
     const float* off;       // [Bp] log2(w_b) - lse2_b; -inf for rows without a loss term
     int Bp, H, N, tile_off;
+    int tile_end;           // k_tab32x3: first 64-row tile beyond the launch (its workgroups own PAIRS of tiles)
     float* demb1;           // !ADAM: gradient row of item 1
     // KD rows (ADER.py:132-137): batch rows [kd_row0, Bp) are distilled exemplar rows: dlogit = w (softmax(s[:Np]) - softmax(t)),
     // zero for items >= Np.  kd_row0 % 128 == 0; = Bp: none.  trow / tlse2: [Bp] as written by ader_lx3_fwd_kd.

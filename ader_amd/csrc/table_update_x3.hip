@@ -492,11 +492,351 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_tab32x3: the same update with 128 table rows per workgroup -- each wave owns 16 rows of BOTH 64-row tiles of a pair -- and two
+// workgroups per CU (<= 256 registers).  Why: every workgroup streams the WHOLE batch (512 rows x 160 channels, hi + lo = 352 KB)
+// through its LDS once per tile; at 64 rows per workgroup that is 5.5 GB of L2 -> LDS traffic per 10^6 rows and ~1,000 clocks of
+// LDS-DMA issue per 32-row chunk and wave (stamps: 11-18 % of a tile, wherever in the chunk the issue is placed).  With a pair of
+// tiles per pass the DMA bytes, the DMA issue, the chunk barriers and the LDS operand reads (the rep fragments of a chunk feed the
+// MFMAs of both tiles) are halved per table row.  The optimiser phase is k_tab16x3's, run once per tile of the pair.
+template <bool EXTRA, bool KD>
+__global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* R_l = (bf16*)smem_raw;                                // [2 buffers][chunk image]; later the dE tile of one half
+    float* off_l = (float*)(smem_raw + 2 * X3_IMG_B);           // [Bp]
+    int* meta_l = (int*)(off_l + a.Bp);                         // the pair's list records [2 tiles][2][TM_LIST]
+    float* toff_l = (float*)(meta_l + 4 * TM_LIST);             // KD: [Bp - kd_row0]
+    int* trow_l = (int*)(toff_l + (a.Bp - a.kd_row0));          // KD: [Bp - kd_row0]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int H = a.H, N = a.N;
+    const int tileA = 2 * blockIdx.x + a.tile_off;              // tiles tileA, tileA + 1 (the second may lie beyond the launch)
+    const char* img = (const char*)a.rep_img;
+    const int nch = a.Bp / X3_CH;
+    x3_dma_chunk(img, 0, R_l, wave, lane);
+    bf16x8 e_hi[2][5], e_lo[2][5];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int tile0 = (tileA + h) * TI;
+        const int rows_avail = (tileA + h < a.tile_end) ? min(TI, a.vrows - tile0) : 0;
+        const int n_av = rows_avail > 0 ? rows_avail * H : 0;
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.emb1 + (size_t)tile0 * H), 0, (unsigned)n_av * 4u, 0x00020000);
+        const int vt = 4 * ((wave * 16 + c16) * H + 8 * g);
+        f32x4_t x0[5], x1[5];
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            x0[ks] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rt, vt, 128 * ks, 0));
+            x1[ks] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rt, vt, 128 * ks + 16, 0));
+        }
+        if (h == 0) {
+            for (int i = tid; i < a.Bp; i += 256) off_l[i] = a.off[i];
+            if (KD) {
+                for (int i = tid; i < a.Bp - a.kd_row0; i += 256) {
+                    const int b = a.kd_row0 + i, tr = a.trow[b];
+                    const float w = f.wrow[b];
+                    toff_l[i] = (tr >= 0 && w > 0.0f) ? log2f(w) - a.tlse2[b] : -INFINITY;
+                    trow_l[i] = tr < 0 ? 0 : tr;
+                }
+            }
+            if (tid < 4 * TM_LIST) {
+                const int t_ = tileA + tid / (2 * TM_LIST);
+                meta_l[tid] = (t_ < a.tile_end) ? f.tile_meta[(size_t)tileA * (2 * TM_LIST) + tid] : 0;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in0 = 32 * ks + 8 * g + j < H, in1 = 32 * ks + 8 * g + 4 + j < H;
+                const float v0 = in0 ? x0[ks][j] : 0.0f, v1 = in1 ? x1[ks][j] : 0.0f;
+                const bf16 h0 = (bf16)v0, h1 = (bf16)v1;
+                e_hi[h][ks][j] = h0; e_hi[h][ks][4 + j] = h1;
+                e_lo[h][ks][j] = (bf16)(v0 - (float)h0); e_lo[h][ks][4 + j] = (bf16)(v1 - (float)h1);
+            }
+        }
+    }
+    __syncthreads();                                            // off_l / meta_l are in LDS
+    float spv[2][SPV];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int* ms = meta_l + h * 2 * TM_LIST;
+#pragma unroll
+        for (int i = 0; i < SPV; ++i) {
+            const bool on = tid < H && ms[0] + i < ms[1];
+            spv[h][i] = f.sp_src[on ? (size_t)ms[3 + 2 * i] * H + tid : 0] * (on ? f.sp_scale : 0.0f);
+        }
+    }
+    f32x4v dE[2][10];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int cb = 0; cb < 10; ++cb) dE[h][cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const int q4 = c16 >> 2, p4 = c16 & 3;
+    const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
+    const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
+    const int itA = tileA * TI + wave * 16;                     // this wave's first item of half 0 (half 1: + TI)
+    for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char* Bh = (const char*)(R_l + (c & 1) * X3_BUF);
+        const int b0 = c * X3_CH;
+        float tv[KD ? 16 : 1];
+        const bool kdc = KD && b0 >= a.kd_row0;
+        if (kdc) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int it = itA + h * TI + c16;
+                const bool okt = it < a.Np;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    tv[KD ? 8 * h + j : 0] = a.teacher[(size_t)trow_l[b0 - a.kd_row0 + 16 * (j >> 2) + 4 * g + (j & 3)] * a.ldt + (okt ? it : 0)];
+            }
+        }
+#define X3_LOADA(set_, ks_)                                                                               \
+        { const char* ap_ = Bh + a_off + X3_QUAD * (ks_);                                                 \
+          set_[0] = *(const bf16x8*)ap_; set_[1] = *(const bf16x8*)(ap_ + X3_PLANE_B);                    \
+          set_[2] = *(const bf16x8*)(ap_ + 256); set_[3] = *(const bf16x8*)(ap_ + X3_PLANE_B + 256); }
+#define X3_LOADT(set_, cb_)                                                                               \
+        { const bf16* tp_ = (const bf16*)(Bh + t_off + X3_QUAD * ((cb_) >> 1) + 512 * ((cb_) & 1));         \
+          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 128);                                           \
+          set_[2] = tr_read(tp_ + X3_PLANE_B / 2); set_[3] = tr_read(tp_ + X3_PLANE_B / 2 + 128); }
+        f32x4v S[2][2];         // [half][row block]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { S[h][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; S[h][1] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+        bf16x8 fa[2][4];
+        X3_LOADA(fa[0], 0);
+        X3_LOADA(fa[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nch) x3_dma_chunk(img, c + 1, R_l + ((c + 1) & 1) * X3_BUF, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            bf16x8* A_ = fa[ks & 1];                             // {ah0, al0, ah1, al1}
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                S[h][0] = mfma16_bf16(A_[1], e_hi[h][ks], S[h][0]);
+                S[h][1] = mfma16_bf16(A_[3], e_hi[h][ks], S[h][1]);
+                S[h][0] = mfma16_bf16(A_[0], e_lo[h][ks], S[h][0]);
+                S[h][1] = mfma16_bf16(A_[2], e_lo[h][ks], S[h][1]);
+                S[h][0] = mfma16_bf16(A_[0], e_hi[h][ks], S[h][0]);
+                S[h][1] = mfma16_bf16(A_[2], e_hi[h][ks], S[h][1]);
+            }
+            if (ks + 2 < 5) X3_LOADA(fa[ks & 1], ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bf16x4 ft[3][4];
+        X3_LOADT(ft[0], 0);
+        X3_LOADT(ft[1], 1);
+        X3_LOADT(ft[2], 2);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ph_[2], pl_[2];  // k order of a fragment: rows 4g..4g+3 of row block 0, then of row block 1
+        {
+            const float4 o0 = *(const float4*)(off_l + b0 + 4 * g);
+            const float4 o1 = *(const float4*)(off_l + b0 + 16 + 4 * g);
+            const float o0a[4] = {o0.x, o0.y, o0.z, o0.w}, o1a[4] = {o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    S[h][0][j] = __builtin_amdgcn_exp2f(fmaf(S[h][0][j], LOG2E, o0a[j]));
+                    S[h][1][j] = __builtin_amdgcn_exp2f(fmaf(S[h][1][j], LOG2E, o1a[j]));
+                }
+                if (kdc) {
+                    if (itA + h * TI + c16 < a.Np) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            S[h][0][j] -= __builtin_amdgcn_exp2f(fmaf(tv[KD ? 8 * h + j : 0], LOG2E, toff_l[b0 - a.kd_row0 + 4 * g + j]));
+                            S[h][1][j] -= __builtin_amdgcn_exp2f(fmaf(tv[KD ? 8 * h + 4 + j : 0], LOG2E, toff_l[b0 - a.kd_row0 + 16 + 4 * g + j]));
+                        }
+                    } else {
+                        S[h][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; S[h][1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16 h0 = (bf16)S[h][0][j], h1 = (bf16)S[h][1][j];
+                    ph_[h][j] = h0; ph_[h][4 + j] = h1;
+                    pl_[h][j] = (bf16)(S[h][0][j] - (float)h0); pl_[h][4 + j] = (bf16)(S[h][1][j] - (float)h1);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cb = 0; cb < 10; ++cb) {
+            bf16x4* T_ = ft[cb % 3];
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bh[j] = T_[0][j]; bh[4 + j] = T_[1][j]; bl[j] = T_[2][j]; bl[4 + j] = T_[3][j]; }
+            dE[0][cb] = mfma16_bf16(pl_[0], bh, dE[0][cb]);
+            dE[1][cb] = mfma16_bf16(pl_[1], bh, dE[1][cb]);
+            dE[0][cb] = mfma16_bf16(ph_[0], bl, dE[0][cb]);
+            dE[1][cb] = mfma16_bf16(ph_[1], bl, dE[1][cb]);
+            dE[0][cb] = mfma16_bf16(ph_[0], bh, dE[0][cb]);
+            dE[1][cb] = mfma16_bf16(ph_[1], bh, dE[1][cb]);
+            if (cb + 3 < 10) X3_LOADT(ft[cb % 3], cb + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef X3_LOADA
+#undef X3_LOADT
+    // ---- optimiser phase, once per tile of the pair (k_tab16x3's: comments there)
+    float* F_l = (float*)smem_raw;
+    const int vo = 16 * tid;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int tile = tileA + h;
+        const int tile0 = tile * TI;
+        const int* ms = meta_l + h * 2 * TM_LIST;
+        const int* mg = ms + TM_LIST;
+        const int rows_valid = (tile < a.tile_end) ? min(TI, N - tile0) : 0;
+        const int n_el = rows_valid > 0 ? rows_valid * H : 0;
+        float* __restrict__ gp = f.emb1 + (size_t)tile0 * H;
+        float* __restrict__ gm = f.m1 + (size_t)tile0 * H;
+        float* __restrict__ gv = f.v1 + (size_t)tile0 * H;
+        const float* __restrict__ gx = EXTRA ? f.extra1 + (size_t)tile0 * H : nullptr;
+        const unsigned nbytes = (unsigned)n_el * 4u;
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)gp, 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)gm, 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)gv, 0, nbytes, 0x00020000);
+        f32x4_t P[NVEC], M[NVEC], V[NVEC];
+        const bool heavy = (ms[1] - ms[0] > HEAVY_N) || (mg[1] - mg[0] > HEAVY_N);
+        if (!heavy) { LOAD_MV(); }
+        lds_only_barrier();             // every wave is done with the last rep chunk / with the other half's staging tile
+#pragma unroll
+        for (int cb = 0; cb < 10; ++cb) {
+            const int hc = 32 * (cb >> 1) + 8 * (cb & 1) + 16 * (c16 >> 3) + (c16 & 7);
+            if (hc < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) F_l[(wave * 16 + 4 * g + j) * H + hc] = dE[h][cb][j];
+            }
+        }
+        lds_only_barrier();
+        {
+            const int id_lo = tile0 + 1, id_hi = (tile < a.tile_end ? min(tile0 + TI, N) : tile0) + 1;
+            if (heavy) {
+                int* hv_l = (int*)(smem_raw + TI * HP * sizeof(float));
+#define HEAVY_LIST(K0_, K1_, IDS_, ROWS_, VAL_, OP_)                                                       \
+                for (int base_ = (K0_); base_ < (K1_); base_ += 256) {                                     \
+                    const int n_ = min(256, (K1_) - base_);                                                \
+                    if (tid < n_) { hv_l[tid] = (IDS_)[base_ + tid]; hv_l[256 + tid] = (ROWS_)[base_ + tid]; } \
+                    __syncthreads();                                                                       \
+                    if (tid < H && id_lo < id_hi) {                                                        \
+                        for (int e0_ = 0; e0_ < n_; e0_ += HVB) {                                          \
+                            int idv[HVB];                                                                  \
+                            float val[HVB];                                                                \
+                            _Pragma("unroll") for (int u = 0; u < HVB; ++u) {                              \
+                                const bool in_ = e0_ + u < n_;                                             \
+                                idv[u] = in_ ? hv_l[e0_ + u] : 0x7fffffff;                                 \
+                                const int rw = in_ ? hv_l[256 + e0_ + u] : 0;                              \
+                                val[u] = (VAL_) * ((idv[u] < id_hi) ? 1.0f : 0.0f);                        \
+                            }                                                                              \
+                            _Pragma("unroll") for (int u = 0; u < HVB; ++u)                                \
+                                if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] OP_ val[u];            \
+                        }                                                                                  \
+                    }                                                                                      \
+                    __syncthreads();                                                                       \
+                }
+                HEAVY_LIST(ms[0], ms[1], f.sp_ids, f.sp_rows, f.sp_src[(size_t)rw * H + tid] * f.sp_scale, +=)
+                HEAVY_LIST(mg[0], mg[1], f.tg_ids, f.tg_rows,
+                           f.wrow[rw] * ((float)a.rep_hi[(size_t)rw * LDR + tid] + (float)a.rep_lo[(size_t)rw * LDR + tid]), -=)
+#undef HEAVY_LIST
+            } else if (tid < H && id_lo < id_hi) {
+                const int k0s = ms[0], k1s = ms[1];
+#pragma unroll
+                for (int i = 0; i < SPV; ++i) {
+                    if (k0s + i < k1s) {
+                        const int id = ms[2 + 2 * i];
+                        if (id < id_hi) F_l[(id - id_lo) * H + tid] += spv[h][i];
+                    }
+                }
+                for (int k = k0s + SPV, i = SPV; k < k1s; k += SPB, i += SPB) {
+                    int idv[SPB], rw[SPB];
+                    float val[SPB];
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u) {
+                        const int ic = (i + u) < 8 ? (i + u) : 7;
+                        const int id_c = ms[2 + 2 * ic], row_c = ms[3 + 2 * ic];
+                        const bool in = k + u < k1s;
+                        int id_g = 0, row_g = 0;
+                        if (i + SPB > 8) {
+                            const int ke = in ? k + u : k0s;
+                            id_g = f.sp_ids[ke]; row_g = f.sp_rows[ke];
+                        }
+                        idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : id_g);
+                        rw[u] = !in ? 0 : ((i + u < 8) ? row_c : row_g);
+                    }
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u)
+                        val[u] = f.sp_src[(size_t)rw[u] * H + tid] * ((idv[u] < id_hi) ? f.sp_scale : 0.0f);
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u)
+                        if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] += val[u];
+                }
+                for (int k = mg[0], k1 = mg[1], i = 0; k < k1; k += SPB, i += SPB) {
+                    int idv[SPB], bw[SPB];
+                    float val[SPB];
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u) {
+                        const int ic = (i + u) < 8 ? (i + u) : 7;
+                        const int id_c = mg[2 + 2 * ic], b_c = mg[3 + 2 * ic];
+                        const bool in = k + u < k1;
+                        int id_g = 0, b_g = 0;
+                        if (i + SPB > 8) {
+                            const int ke = in ? k + u : mg[0];
+                            id_g = f.tg_ids[ke]; b_g = f.tg_rows[ke];
+                        }
+                        idv[u] = !in ? 0x7fffffff : ((i + u < 8) ? id_c : id_g);
+                        bw[u] = !in ? 0 : ((i + u < 8) ? b_c : b_g);
+                    }
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u) {
+                        const float rv_ = (float)a.rep_hi[(size_t)bw[u] * LDR + tid] + (float)a.rep_lo[(size_t)bw[u] * LDR + tid];
+                        val[u] = rv_ * f.wrow[bw[u]] * ((idv[u] < id_hi) ? 1.0f : 0.0f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u)
+                        if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] -= val[u];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (heavy) { LOAD_MV(); }
+        LOAD_P();
+        lds_only_barrier();
+#define ADAM1(p_, m_, v_, g_)                                                                              \
+        { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2;                                   \
+          p_ -= (m_ * f.lr_t) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v_) + f.eps); }
+#pragma unroll
+        for (int u = 0; u < NVEC; ++u) {
+            const int e = 4 * tid + 1024 * u;
+            if (e < TI * H) {
+                f32x4_t g4 = *(const f32x4_t*)(F_l + e);
+                if (EXTRA) {
+                    const f32x4_t x4 = (e + 3 < n_el) ? ((const F16B*)(gx + e))->v : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    g4 += x4;
+                }
+                f32x4_t p = P[u], m = M[u], v = V[u];
+                ADAM1(p[0], m[0], v[0], g4[0]); ADAM1(p[1], m[1], v[1], g4[1]);
+                ADAM1(p[2], m[2], v[2], g4[2]); ADAM1(p[3], m[3], v[3], g4[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, p), rp, vo, 4096 * u, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rm, vo, 4096 * u, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rv, vo, 4096 * u, 2);
+            }
+        }
+#undef ADAM1
+    }
+}
+
 // ============================================================================================= launch (C ABI: table_update.hip)
 static size_t tab16x3_lds(int Bp, int Bk) {
     static int pad = -1;                  // ADER_X3_LDSPAD: extra bytes (timing experiments: fewer workgroups per CU)
     if (pad < 0) { const char* e = getenv("ADER_X3_LDSPAD"); pad = e ? atoi(e) : 0; }
-    return (size_t)2 * X3_IMG_B + (size_t)Bp * sizeof(float) + 2 * TM_LIST * sizeof(int) + (size_t)Bk * 8 + pad;
+    return (size_t)2 * X3_IMG_B + (size_t)Bp * sizeof(float) + 4 * TM_LIST * sizeof(int) + (size_t)Bk * 8 + pad;
+}
+static bool tab_pairs() {                 // ADER_X3_TILE=64: k_tab16x3 (one 64-row tile per workgroup, three per CU) instead of k_tab32x3
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ADER_X3_TILE"); v = (e && atoi(e) == 64) ? 0 : 1; }
+    return v == 1;
 }
 
 template <bool EXTRA, bool KD>
@@ -510,12 +850,29 @@ static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, siz
     hipLaunchKernelGGL((k_tab16x3<EXTRA, KD>), dim3(tiles), dim3(256), lds, st, a, fa);
     return 0;
 }
+template <bool EXTRA, bool KD>
+static int tab32x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
+    static int lds_set = 0;
+    if ((int)lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_tab32x3<EXTRA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = (int)lds;
+    }
+    hipLaunchKernelGGL((k_tab32x3<EXTRA, KD>), dim3((tiles + 1) / 2), dim3(256), lds, st, a, fa);
+    return 0;
+}
 
 static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, bool kd, void* stream) {
     { static int ko = -1; if (ko < 0) { const char* e = getenv("ADER_X3_KO"); ko = e ? atoi(e) : 0; const char* s_ = getenv("ADER_X3_STAGGER"); ko |= (s_ ? atoi(s_) : 0) << 16; } a.ko = ko; }
     if (a.Bp % X3_CH != 0 || (kd && a.kd_row0 % X3_CH != 0) || !a.rep_img || ((uintptr_t)a.rep_img & 15)) return -2;
     const size_t lds = tab16x3_lds(a.Bp, kd ? a.Bp - a.kd_row0 : 0);
     hipStream_t st = (hipStream_t)stream;
+    a.tile_end = a.tile_off + tiles;
+    if (tab_pairs() && (a.tile_off & 1) == 0 && !a.ko) {
+        if (kd) return tab32x3_launch_t<false, true>(a, fa, tiles, lds, st);
+        if (extra) return tab32x3_launch_t<true, false>(a, fa, tiles, lds, st);
+        return tab32x3_launch_t<false, false>(a, fa, tiles, lds, st);
+    }
     if (kd) return tab16x3_launch_t<false, true>(a, fa, tiles, lds, st);
     if (extra) return tab16x3_launch_t<true, false>(a, fa, tiles, lds, st);
     return tab16x3_launch_t<false, false>(a, fa, tiles, lds, st);
