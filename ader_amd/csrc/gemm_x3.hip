@@ -27,7 +27,12 @@ __device__ __forceinline__ void split2(float x, float y, bf16x2& hi, bf16x2& lo)
     lo[0] = (bf16)(x - (float)hi[0]); lo[1] = (bf16)(y - (float)hi[1]);
 }
 
-// planes per weight: [0] W^T hi, [1] W^T lo, [2] W hi, [3] W lo ; plane[n][k], row stride LDR, zero padded
+// planes per weight: [0] W^T hi, [1] W^T lo, [2] W hi, [3] W lo; a plane holds B[n][k] (zero padded to 160 x 160) in FRAGMENT order:
+// element (n = 32 nb + r, k = 16 ks + 8 hh + j) at ((nb * 10 + ks) * 64 + 32 hh + r) * 8 + j, i.e. the 64 lanes' 16-byte operands of one
+// v_mfma_f32_32x32x16_bf16 B fragment are 1 KiB contiguous: a wave's fragment load touches 8 fully used cache lines (the row-major
+// [n][168] planes of rounds 1-2 made every such load touch 32 lines at 25 % use; the ten waves' 20 KB streams overflowed the 32 KB
+// L1 and every line was fetched from L2 several times: 1 GB per k_seq_fwd launch).
+__device__ __host__ __forceinline__ constexpr int wfrag_off(int nb, int ks, int lane) { return ((nb * 10 + ks) * 64 + lane) * 8; }
 __global__ __launch_bounds__(256) void k_wprep(const float* __restrict__ theta, const long* __restrict__ offs, int nw, int H,
                                                bf16* __restrict__ out) {
     const int w = blockIdx.y;
@@ -35,9 +40,13 @@ __global__ __launch_bounds__(256) void k_wprep(const float* __restrict__ theta, 
     const float* W = theta + offs[w];
     bf16* o = out + (size_t)w * 4 * WSZ;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < WSZ; i += gridDim.x * blockDim.x) {
-        const int n = i / LDR, k = i - n * LDR;
-        const float vt = (n < H && k < H) ? W[(size_t)k * H + n] : 0.0f;     // W^T[n][k]
-        const float vn = (n < H && k < H) ? W[(size_t)n * H + k] : 0.0f;     // W[n][k]
+        float vt = 0.0f, vn = 0.0f;
+        if (i < 5 * 10 * 64 * 8) {
+            const int j = i & 7, lane = (i >> 3) & 63, f = i >> 9;
+            const int ks = f % 10, nb = f / 10;
+            const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+            if (n < H && k < H) { vt = W[(size_t)k * H + n]; vn = W[(size_t)n * H + k]; }     // W^T[n][k], W[n][k]
+        }
         const bf16 th = (bf16)vt, nh = (bf16)vn;
         o[i] = th; o[WSZ + i] = (bf16)(vt - (float)th);
         o[2 * WSZ + i] = nh; o[3 * WSZ + i] = (bf16)(vn - (float)nh);
@@ -65,8 +74,8 @@ __global__ __launch_bounds__(640) void k_gemm_x3(GemmX3Args g) {
     bf16x8 bh[10], bl[10];
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) {
-        bh[ks] = *(const bf16x8*)(g.Bhi + (size_t)(32 * nb + r) * LDR + 16 * ks + 8 * hh);
-        bl[ks] = *(const bf16x8*)(g.Blo + (size_t)(32 * nb + r) * LDR + 16 * ks + 8 * hh);
+        bh[ks] = *(const bf16x8*)(g.Bhi + wfrag_off(nb, ks, lane));
+        bl[ks] = *(const bf16x8*)(g.Blo + wfrag_off(nb, ks, lane));
     }
     for (int i = tid; i < 2 * 2 * TM * LDR / 2; i += 640) ((uint32_t*)A_l)[i] = 0u;     // K padding columns stay zero
     const int it_first = tid / HH, c2_first = tid - it_first * HH;

@@ -77,13 +77,14 @@ __device__ __forceinline__ void put_split(bf16* Th, bf16* Tl, int off, float v) 
     Tl[off] = (bf16)(v - (float)h);
 }
 
-// B fragments of this wave's 32 output columns: planes [n][k] (W^T hi at W, lo at W + WSZ), zero padded
+// B fragments of this wave's 32 output columns: planes in fragment order (k_wprep: the 64 lanes' operands of a fragment are 1 KiB
+// contiguous; W^T hi at W, lo at W + WSZ), zero padded
 __device__ __forceinline__ void load_bfrags(const bf16* __restrict__ W, int nb, int r, int hh, bf16x8 (&bh)[10], bf16x8 (&bl)[10]) {
-    const bf16* p = W + (size_t)(32 * nb + r) * LDR + 8 * hh;
+    const bf16* p = W + ((size_t)nb * 10 * 64 + 32 * hh + r) * 8;
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) {
-        bh[ks] = *(const bf16x8*)(p + 16 * ks);
-        bl[ks] = *(const bf16x8*)(p + WSZ + 16 * ks);
+        bh[ks] = *(const bf16x8*)(p + 512 * ks);
+        bl[ks] = *(const bf16x8*)(p + WSZ + 512 * ks);
     }
 }
 // acc = tile rows 32mh.. (hi/lo in LDS) . W columns 32nb..
