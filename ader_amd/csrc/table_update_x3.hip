@@ -514,6 +514,10 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
     const int tileA = 2 * blockIdx.x + a.tile_off;              // tiles tileA, tileA + 1 (the second may lie beyond the launch)
     const char* img = (const char*)a.rep_img;
     const int nch = a.Bp / X3_CH;
+#ifdef T3_STAMP
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#endif
     x3_dma_chunk(img, 0, R_l, wave, lane);
     bf16x8 e_hi[2][5], e_lo[2][5];
 #pragma unroll
@@ -556,7 +560,9 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
             }
         }
     }
+    STAMP(0)
     __syncthreads();                                            // off_l / meta_l are in LDS
+    STAMP(1)
     float spv[2][SPV];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -576,8 +582,11 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
     const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
     const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
     const int itA = tileA * TI + wave * 16;                     // this wave's first item of half 0 (half 1: + TI)
+    STAMP(2)
     for (int c = 0; c < nch; ++c) {
+        STAMP(4)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        STAMP(5)
         const char* Bh = (const char*)(R_l + (c & 1) * X3_BUF);
         const int b0 = c * X3_CH;
         float tv[KD ? 16 : 1];
@@ -624,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
             if (ks + 2 < 5) X3_LOADA(fa[ks & 1], ks + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(6)
         bf16x4 ft[3][4];
         X3_LOADT(ft[0], 0);
         X3_LOADT(ft[1], 1);
@@ -661,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(7)
 #pragma unroll
         for (int cb = 0; cb < 10; ++cb) {
             bf16x4* T_ = ft[cb % 3];
@@ -682,6 +693,7 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
     // ---- optimiser phase, once per tile of the pair (k_tab16x3's: comments there)
     float* F_l = (float*)smem_raw;
     const int vo = 16 * tid;
+    STAMP(4)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int tile = tileA + h;
@@ -700,6 +712,8 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)gv, 0, nbytes, 0x00020000);
         f32x4_t P[NVEC], M[NVEC], V[NVEC];
         const bool heavy = (ms[1] - ms[0] > HEAVY_N) || (mg[1] - mg[0] > HEAVY_N);
+        // (measured and dropped: theta requested here too, with m and v -- the registers are there at two workgroups per CU -- made the
+        //  step 0.04 ms SLOWER: 30 loads issued ahead of the staging stores delay them, and the Adam section did not get shorter)
         if (!heavy) { LOAD_MV(); }
         lds_only_barrier();             // every wave is done with the last rep chunk / with the other half's staging tile
 #pragma unroll
@@ -711,6 +725,7 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
             }
         }
         lds_only_barrier();
+        STAMP(8)
         {
             const int id_lo = tile0 + 1, id_hi = (tile < a.tile_end ? min(tile0 + TI, N) : tile0) + 1;
             if (heavy) {
@@ -803,6 +818,7 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
         if (heavy) { LOAD_MV(); }
         LOAD_P();
         lds_only_barrier();
+        STAMP(9)
 #define ADAM1(p_, m_, v_, g_)                                                                              \
         { m_ += ((g_) - m_) * f.omb1; v_ += ((g_) * (g_) - v_) * f.omb2;                                   \
           p_ -= (m_ * f.lr_t) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v_) + f.eps); }
@@ -824,7 +840,14 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
             }
         }
 #undef ADAM1
+#ifdef T3_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(10)
+#endif
     }
+#ifdef T3_STAMP
+    if (tid == 0 && blockIdx.x % 8 == 5 && blockIdx.x / 8 < 1024) for (int k_ = 0; k_ < 12; ++k_) t3_dbg[(blockIdx.x / 8) * 12 + k_] = seg[k_];
+#endif
 }
 
 // ============================================================================================= launch (C ABI: table_update.hip)
