@@ -23,6 +23,7 @@ _SIGS = {
     "ader_ln_bwd_slabs": [I],
     "ader_ln_bwd": [P, L, P, L, P, P, P, P, L, P, L, P, P, P, I, I, P],
     "ader_gemm_rows": [P, P, P, P, P, P, I, I, I, I, I, I] + _DROP + [P],
+    "ader_lbf_sum": [P, I, P, P],
     "ader_gemm_atb_slabs": [I],
     "ader_gemm_atb": [P, P, P, P, P, I, I, P],
     "ader_wprep_elems": [I],

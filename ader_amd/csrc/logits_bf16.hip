@@ -1021,7 +1021,15 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
     if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
-    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
+    if (loss) hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);     // NULL: ader_lbf_sum later (off the critical path)
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss = sum of the per-row losses a flash forward left in rowloss[0..n) (fixed order), for callers that passed loss = NULL
+int ader_lbf_sum(const float* rowloss, int n, float* loss, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, rowloss, n, loss);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -533,9 +533,11 @@ int ader_ln_bwd(const float* dy, long dy_rs, const float* x, long x_rs, const fl
     const int G = ader_ln_bwd_slabs(rows);
     hipLaunchKernelGGL(k_ln_bwd, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, dy_rs, x, x_rs, gamma, mean_i, std_i, add, add_rs,
                        dx, dx_rs, slab, rows, H);
-    // slab layout [G][2][H]: row 0 = dgamma partial, row 1 = dbeta partial
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + RS_O - 1) / RS_O), dim3(RS_G * RS_O), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
-                       dgamma, dbeta);
+    // slab layout [G][2][H]: row 0 = dgamma partial, row 1 = dbeta partial.  dgamma == NULL: the caller reduces the slabs later
+    // (ader_reduce_slabs(slab, 2 H, ader_ln_bwd_slabs(rows), H, 1, H, dgamma, dbeta) -- off the critical path of the backward pass)
+    if (dgamma)
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((2 * H + RS_O - 1) / RS_O), dim3(RS_G * RS_O), 0, (hipStream_t)stream, slab, (long)2 * H, G, H, 1, H,
+                           dgamma, dbeta);
     HIP_LAUNCH_CHECK();
     return 0;
 }

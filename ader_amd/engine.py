@@ -494,11 +494,13 @@ class Engine:
         late, self._late = self._late, []
         red = [a for n, a in late if n == "ader_reduce_slabs"]
         if len(red) > 1:
-            n = len(red)
-            VP, LA, IA = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
-            call("ader_reduce_slabs_batch", VP(*[a[0] for a in red]), LA(*[a[1] for a in red]), IA(*[a[2] for a in red]),
-                 IA(*[a[3] for a in red]), IA(*[a[4] for a in red]), IA(*[a[5] for a in red]), VP(*[a[6] for a in red]),
-                 VP(*[a[7] for a in red]), n, self._stream())
+            for i0 in range(0, len(red), 8):        # (a launch takes up to 8 jobs: 2 per block + the final LayerNorm)
+                rr = red[i0:i0 + 8]
+                n = len(rr)
+                VP, LA, IA = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+                call("ader_reduce_slabs_batch", VP(*[a[0] for a in rr]), LA(*[a[1] for a in rr]), IA(*[a[2] for a in rr]),
+                     IA(*[a[3] for a in rr]), IA(*[a[4] for a in rr]), IA(*[a[5] for a in rr]), VP(*[a[6] for a in rr]),
+                     VP(*[a[7] for a in rr]), n, self._stream())
             late = [(nm, a) for nm, a in late if nm != "ader_reduce_slabs"]
         for name, args in late:
             call(name, *args, self._stream())
@@ -780,8 +782,12 @@ class Engine:
             lse, off, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lbf_off", (Bp,)), self.buf("lg_rowloss", (Bp,))
             with self._sec("logits_fwd"):
                 if self.lx3:
+                    # the loss scalar feeds nothing in the backward pass: with the fused update deferred, its (single-workgroup) sum
+                    # leaves the critical path and runs beside the table update
+                    late_loss = bool(defer and self.dp_world == 1 and not split_kd and self.late_side_stream and self.seq_fused)
                     call("ader_lx3_fwd", ptr(rep), emb, self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(rep_lo),
-                         ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
+                         ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), st)
+                    self._pending_loss = (rowloss, Bb) if late_loss else None
                 else:
                     call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
                          ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), ptr(self.loss), ptr(drep), st)
@@ -899,17 +905,24 @@ class Engine:
         xL = A["xL"]
         dx = self.buf("dx_a", (rows, H), zero=True)
         dxn = self.buf("dx_b", (rows, H), zero=True)
+        self._late_on = bool(defer and (self.dp_world == 1 or self._late_force) and self.seq_fused and self.late_side_stream)
         if self.prune_last:
             dxl = self.buf("dx_L", (B, H))        # gradient of the final block's output row T-1 (compact)
-            call("ader_ln_bwd", ptr(drep), H, ptr(xL), H, pp["lnf_g"], ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dxl), H,
-                 ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
+            if self._late_on:       # gamma / beta partials reduced later, beside the table update (their own slab buffer)
+                G = call("ader_ln_bwd_slabs", B)
+                fslab = self.buf("lnf_slab", (G * 2 * H,))
+                call("ader_ln_bwd", ptr(drep), H, ptr(xL), H, pp["lnf_g"], ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dxl), H,
+                     ptr(fslab), None, None, B, H, st)
+                self._late_call("ader_reduce_slabs", ptr(fslab), 2 * H, G, H, 1, H, gp["lnf_g"], gp["lnf_b"])
+            else:
+                call("ader_ln_bwd", ptr(drep), H, ptr(xL), H, pp["lnf_g"], ptr(A["meanf"]), ptr(A["stdf"]), None, 0, ptr(dxl), H,
+                     ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
         else:
             dx.zero_()
             call("ader_ln_bwd", ptr(drep), H, ptr(xL.view(B, T, H)[:, T - 1, :]), T * H, pp["lnf_g"], ptr(A["meanf"]),
                  ptr(A["stdf"]), None, 0, ptr(dx.view(B, T, H)[:, T - 1, :]), T * H, ptr(wslab), gp["lnf_g"], gp["lnf_b"], B, H, st)
         last_map = (T, T - 1)
         fused_emb = False
-        self._late_on = bool(defer and (self.dp_world == 1 or self._late_force) and self.seq_fused and self.late_side_stream)
         for l in reversed(range(L)):
             p = "b%d." % l
             S = A[l]
@@ -1108,6 +1121,10 @@ class Engine:
         span = self.layout["pos"][0]
 
         def small_update():     # everything that feeds / is the update of the non-table parameters
+            pl_ = getattr(self, "_pending_loss", None)
+            if pl_ is not None:
+                call("ader_lbf_sum", ptr(pl_[0]), pl_[1], ptr(self.loss), self._stream())
+                self._pending_loss = None
             self._flush_late()
             self._atb_flush()
             with self._sec("adam"):
