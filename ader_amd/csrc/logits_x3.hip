@@ -281,6 +281,40 @@ __global__ __launch_bounds__(256, 2) void k_lx3g(Lx3Args a) {
     const int voffp = voff + 4 * (rem - 4);                // second vector of the partial k-chunk: ends with the row
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.emb1, 0, a.vrows * H * 4, 0x00020000);
     const int dst0 = X3B_KC * kc0 + 16 * it_;               // byte offset inside a plane (round r: + 8 k-chunks)
+    // ---- H = 150: the block as 16-byte pieces read in memory order.  Lane l -> item 8 wave + (l >> 3), piece (l & 7) + 8 r of the
+    // row's 37.5 (round r = 0..4): a wave-instruction reads 8 x 128 contiguous bytes -- ~12 cache lines, every byte used -- where the
+    // k-chunk mapping above reads 8 x 8 half-used 32-byte pieces (~20 lines, each touched by two instructions); 5 loads instead of
+    // 6.  A piece = 4 channels = half a k-chunk slot: one ds_write_b64 per plane (two-way bank conflicts, hidden under the
+    // VGPR-to-LDS transfer of the store).
+    constexpr bool MAPB = (HT == 150);
+    const int itb = 8 * wave + (lane >> 3), qb = lane & 7;
+    const int voffb = itb * (4 * 150) + 16 * qb;           // round r: + 128 r
+    const int dstb = X3B_KC * (qb >> 1) + 16 * itb + 8 * (qb & 1);      // round r: + 4 k-chunks
+    f32x4_t sc[5];
+#define G3B_LOAD(blk_)                                                                                    \
+    {                                                                                                     \
+        const int so_ = (blk_) * (F3_FB * 4) * 150;                                                       \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r)                                                     \
+            sc[r] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(trs, voffb + 128 * r, so_, 0)); \
+    }
+#define G3B_STORE(buf_)                                                                                   \
+    {                                                                                                     \
+        unsigned char* dst_ = smem_raw + (buf_) * X3B_IMG_B;                                              \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                   \
+            const int p_ = qb + 8 * r;                          /* piece 37 = channels 148, 149 and two floats of the next row */ \
+            float x_[4];                                                                                  \
+            x_[0] = sc[r][0]; x_[1] = sc[r][1];                                                           \
+            x_[2] = (r == 4 && p_ == 37) ? 0.f : sc[r][2]; x_[3] = (r == 4 && p_ == 37) ? 0.f : sc[r][3]; \
+            bf16x4 h_, l_;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
+            if (r < 4 || p_ < 38) {                                                                       \
+                *(bf16x4*)(dst_ + dstb + 4 * X3B_KC * r) = h_;                                            \
+                *(bf16x4*)(dst_ + X3B_PLANE_B + dstb + 4 * X3B_KC * r) = l_;                              \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define G3_LOADBLK(blk_) { if constexpr (MAPB) G3B_LOAD(blk_) else F3_LOAD(blk_) }
+#define G3_STOREBLK(buf_) { if constexpr (MAPB) G3B_STORE(buf_) else F3_STORE(buf_) }
 #define F3_KC(r_) (8 * (r_) + kc0)
 #define F3_PART(r_) (rem && F3_KC(r_) == nfull)
 #define F3_VALID(r_) (F3_KC(r_) < nfull || F3_PART(r_))
@@ -325,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void k_lx3g(Lx3Args a) {
     // three LDS buffers: block i is read from buffer i % 3 while block i + 1 (stored during iteration i - 1) waits in the next one and
     // block i + 2 -- requested at the head of iteration i, converted and stored between its two MFMA phases -- goes into the third:
     // the 24 staging registers are live only under the S^T phase, where the operand sets are small
-    if (nb_blocks > 0) F3_LOAD(blk_begin);
+    if (nb_blocks > 0) G3_LOADBLK(blk_begin);
     __syncthreads();                                       // zero fill done
-    if (nb_blocks > 0) F3_STORE(0);
-    if (nb_blocks > 1) { F3_LOAD(blk_begin + 1); F3_STORE(1); }
+    if (nb_blocks > 0) G3_STOREBLK(0);
+    if (nb_blocks > 1) { G3_LOADBLK(blk_begin + 1); G3_STOREBLK(1); }
     int bcur = 0;                                          // i % 3
 #ifdef G3_STAMP
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_lx3g(Lx3Args a) {
         __syncthreads();                                   // blocks i and i + 1 are in LDS; every wave is done with block i - 1
         STAMP(1)
         const bool more = i + 2 < nb_blocks;
-        if (more) F3_LOAD(blk_begin + i + 2);
+        if (more) G3_LOADBLK(blk_begin + i + 2);
         STAMP(2)
         const char* Bh = (const char*)(smem_raw + bcur * X3B_IMG_B);
         const int bnew = bcur == 0 ? 2 : bcur - 1;         // (i + 2) % 3
@@ -369,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_lx3g(Lx3Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         STAMP(3)
-        if (more) F3_STORE(bnew);
+        if (more) G3_STOREBLK(bnew);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(4)
         // the first transposed reads of the readout do not depend on S: in flight under the softmax section
