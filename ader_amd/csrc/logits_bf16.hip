@@ -797,11 +797,12 @@ bool lx3f_supports(int H);
 int lx3f_launch(const Lx3Args& x, void* stream);
 int lx3g_launch(const Lx3Args& x, void* stream);
 int lx3h_launch(const Lx3Args& x, void* stream);
-// ADER_X3_FWD = old | f | g | h: the round-2 kernel (k_lx3_fwd), the 16-row 16x16x32 form (k_lx3f), the 32x32x16 form (k_lx3g) or
-// the 32-row 16x16x32 form (k_lx3h)
+int lx3p_launch(const Lx3Args& x, void* stream);
+// ADER_X3_FWD = old | f | g | h | p: the round-2 kernel (k_lx3_fwd), the 16-row 16x16x32 form (k_lx3f), the 32x32x16 form (k_lx3g), the
+// 32-row 16x16x32 form (k_lx3h) or k_lx3g with the softmax / staging vector work inside the MFMA phases (k_lx3p; default, H = 150)
 static int lx3_env() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 2 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'h' ? 3 : 2))); }
+    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 4 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'h' ? 3 : (e[0] == 'g' ? 2 : 4)))); }
     return v;
 }
 static int lx3_kind(int H, int Bp) {
@@ -811,7 +812,9 @@ static int lx3_kind(int H, int Bp) {
     if (v >= 2 && Bp % 128 == 0) return 2;
     return 0;
 }
-static int lx3gh_launch(const Lx3Args& x, void* stream) { return lx3_env() == 3 ? lx3h_launch(x, stream) : lx3g_launch(x, stream); }
+static int lx3gh_launch(const Lx3Args& x, void* stream) {
+    return lx3_env() == 3 ? lx3h_launch(x, stream) : (lx3_env() == 4 ? lx3p_launch(x, stream) : lx3g_launch(x, stream));
+}
 
 // ============================================================================================= C ABI
 static const size_t kFwdLds = (size_t)2 * FB * LDR * sizeof(bf16);

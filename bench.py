@@ -316,7 +316,7 @@ def main():
         # profile IF it was taken from the kernel sources that are running now (profiles/CURRENT.json: sha of ader_amd/csrc);
         # a profile of other kernels is named but never quoted
         pmc_kernel = {"logits_bwd_adam": {"bf16": "k_tab16<", "x3": "k_tab32x3<"}.get(args.logits, "k_tab_upd"),
-                      "logits_fwd": {"bf16": "k_lbf_fwd", "x3": "k_lx3g<"}.get(args.logits, "k_logits"), "adam": "k_adam"}
+                      "logits_fwd": {"bf16": "k_lbf_fwd", "x3": "k_lx3p<"}.get(args.logits, "k_logits"), "adam": "k_adam"}
         pmc, sq, pmc_src = {}, {}, None
         std = N == 1_000_000 and B == 512 and not E and world == 1 and args.regime == "dense"
         try:
