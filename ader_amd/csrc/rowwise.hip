@@ -11,26 +11,80 @@
 //   reference: modules.py:118-130 (row 0 of the table reads as zeros, items scaled by sqrt(H)),
 //   ADER.py:41-60 (positional table, dropout, mask).  One wave per (b,t) row; the table row is read
 //   in place (no zero-pad concat copy of the whole table as the TF graph does).
+struct __attribute__((packed, aligned(8))) EmbVec { f32x4 v; };      // 16-byte vector at an 8-byte aligned address (rows: 4 H bytes, H even)
+// Four rows per wave, all of their pieces in flight before the first use (16 waves per CU x 4 random rows: the shape that reads
+// whole rows of a table far larger than the caches at 5.5+ TB/s, MI355X_MICROARCH.md "Indexed rows"); lane l owns the 16-byte piece
+// l of a row (H = 150: 37.5 pieces; the half piece and odd H / 4 tails go through the per-element path below).
 __global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ seq, const float* __restrict__ emb,
                                                    const float* __restrict__ pos, float* __restrict__ x,
                                                    int rows, int T, int H, int V, float sqrtH, DropArgs d,
                                                    int* __restrict__ status) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    int id = seq[row];
-    if (id < 0 || id >= V) {
-        if (lane == 0) atomicOr(status, ADER_ST_BAD_ID);
-        id = 0;
-    }
-    const int t = row % T;
-    const float* e = emb + (size_t)id * H;
-    const float* p = pos + (size_t)t * H;
-    float* o = x + (size_t)row * H;
-    for (int c = lane; c < H; c += 64) {
-        float v = (id != 0 ? e[c] * sqrtH : 0.0f) + p[c];
-        v = drop_apply(d, (uint32_t)row * (uint32_t)H + (uint32_t)c, v);
-        o[c] = (id != 0) ? v : 0.0f;
+    const int gstride = gridDim.x * 16;                         // rows per sweep of the grid (a wave: 4 rows per step)
+    int row0 = (blockIdx.x * 4 + wave) * 4;
+    if (row0 >= rows) return;
+    const bool wide = (H & 1) == 0 && H <= 256;
+    const int c = 4 * lane;                                     // first channel of this lane's 16-byte piece
+    const bool full = c + 4 <= H, part = !full && c < H;        // H even: a partial piece holds exactly 2 channels
+    int idn[4];                                                 // ids of the NEXT step: requested a step ahead (persistent waves)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idn[u] = seq[min(row0 + u, rows - 1)];
+    for (; row0 < rows; row0 += gstride) {
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int v = row0 + u < rows ? idn[u] : 0;
+            if (v < 0 || v >= V) {
+                if (lane == 0) atomicOr(status, ADER_ST_BAD_ID);
+                v = 0;
+            }
+            id[u] = v;
+        }
+        if (row0 + gstride < rows) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) idn[u] = seq[min(row0 + gstride + u, rows - 1)];
+        }
+        if (wide) {
+            f32x4 e[4], q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {       // (row 0 of the table is read for padding ids and ignored: no load under a branch)
+                const int row = min(row0 + u, rows - 1);
+                const float* ep = emb + (size_t)id[u] * H + c;
+                const float* pp = pos + (size_t)(row % T) * H + c;
+                e[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; q[u] = e[u];
+                if (full) { e[u] = ((const EmbVec*)ep)->v; q[u] = ((const EmbVec*)pp)->v; }
+                else if (part) { e[u][0] = ep[0]; e[u][1] = ep[1]; q[u][0] = pp[0]; q[u][1] = pp[1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = row0 + u;
+                if (row >= rows || c >= H) continue;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = (id[u] != 0 ? e[u][j] * sqrtH : 0.0f) + q[u][j];
+                    v = drop_apply(d, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j), v);
+                    o[j] = (id[u] != 0) ? v : 0.0f;
+                }
+                float* op = x + (size_t)row * H + c;
+                if (full) ((EmbVec*)op)->v = o;
+                else { op[0] = o[0]; op[1] = o[1]; }
+            }
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {       // any H: element by element
+                const int row = row0 + u;
+                if (row >= rows) break;
+                const float* e = emb + (size_t)id[u] * H;
+                const float* p = pos + (size_t)(row % T) * H;
+                float* o = x + (size_t)row * H;
+                for (int cc = lane; cc < H; cc += 64) {
+                    float v = (id[u] != 0 ? e[cc] * sqrtH : 0.0f) + p[cc];
+                    v = drop_apply(d, (uint32_t)row * (uint32_t)H + (uint32_t)cc, v);
+                    o[cc] = (id[u] != 0) ? v : 0.0f;
+                }
+            }
+        }
     }
 }
 
@@ -446,7 +500,9 @@ extern "C" {
 int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x, int rows, int T, int H, int V,
                    const AderDrop* drop, int* status, void* stream) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_embed_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, H, V,
+    // 16 rows per workgroup.  (Persistent waves -- 8 workgroups per CU sweeping the rows with the next step's ids requested a step
+    // ahead -- measured SLOWER: 175 vs 150-158 us for 409,600 rows; short-lived waves keep more rows in flight.)
+    hipLaunchKernelGGL(k_embed_fwd, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, H, V,
                        sqrtf((float)H), drop_from(drop), status);
     HIP_LAUNCH_CHECK();
     return 0;

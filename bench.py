@@ -268,6 +268,32 @@ def main():
         gather = {"kernel": "k_embed_fwd (standalone)", "us": round(us, 2), "bytes": B * T * (4 + 2 * H * 4),
                   "GBps": round(gbytes / (us * 1e-6), 1), "frac_hbm": round(gbytes / (us * 1e-6) / HBM_PEAK_GBS, 4),
                   "note": "25,600 random 600-B rows of a 600 MB table + 15.4 MB written: latency / launch bound at this size"}
+        if N >= 100_000:
+            # the same kernel on 16 batches' worth of ids (409,600 random rows, 493 MB): what the gather reaches when it is not launch-bound
+            Bl = 16 * B
+            seql = torch.randint(1, N + 1, (Bl, T), generator=torch.Generator().manual_seed(7), dtype=torch.int32).to(dev)
+            xl = torch.empty(Bl * T, H, device=dev)
+            for it in range(12):
+                if it == 2:
+                    a.record()
+                call("ader_embed_fwd", ptr(seql), eng._pp["emb"], eng._pp["pos"], ptr(xl), Bl * T, T, H, eng.V, ctypes.byref(dd),
+                     ptr(eng.status), st)
+            b.record()
+            torch.cuda.synchronize()
+            usl = a.elapsed_time(b) / 10 * 1e3
+            gl = Bl * T * (4 + 2 * H * 4) / 1e9
+            for it in range(12):            # ... and without the dropout hash (evaluation / herding forwards): the bare gather
+                if it == 2:
+                    a.record()
+                call("ader_embed_fwd", ptr(seql), eng._pp["emb"], eng._pp["pos"], ptr(xl), Bl * T, T, H, eng.V, None, ptr(eng.status), st)
+            b.record()
+            torch.cuda.synchronize()
+            use = a.elapsed_time(b) / 10 * 1e3
+            gather["large"] = {"rows": Bl * T, "us": round(usl, 2), "bytes": Bl * T * (4 + 2 * H * 4), "GBps": round(gl / (usl * 1e-6), 1),
+                               "frac_hbm": round(gl / (usl * 1e-6) / HBM_PEAK_GBS, 4), "us_no_dropout": round(use, 2),
+                               "GBps_no_dropout": round(gl / (use * 1e-6), 1), "frac_hbm_no_dropout": round(gl / (use * 1e-6) / HBM_PEAK_GBS, 4),
+                               "note": "training prologue = gather + counter-hash dropout (two integer multiplies per element: vector-bound)"}
+            del seql, xl
 
     P, span = eng.P, eng.layout["pos"][0]
     dp_mode, dp_pack = eng.dp_mode, eng.dp_pack
