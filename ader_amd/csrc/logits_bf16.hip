@@ -29,6 +29,7 @@
 // (20 r mod 64 covers 16 distinct 4-bank slots).  gfx950 only.
 #include <stdlib.h>
 #include "lbf_common.h"
+#include "x3_image.h"
 #include "../../include/ader_hip.h"
 
 // rep fp32 [B,H] -> rep_bf [Bp, LDR] bf16, zero padded (rows >= B, cols >= H)
@@ -526,15 +527,21 @@ __global__ __launch_bounds__(256) void k_lbf_sum(const float* __restrict__ x, in
 // bf16(x) + bf16(x - bf16(x)): ~2^-16 relative per product, fp32 accumulate) -- the reference's float32 logits
 // (ADER.py:91-93) on the bf16 matrix cores.  There is no bf16 shadow in this mode: the fp32 table rows are streamed
 // directly (600 B per item instead of 2 x 336 B) and split on the way into LDS.
+// img != NULL: also the LDS images of the 32-row chunks that the fused update streams (ader_x3_rep_image's output, x3_image.h)
 __global__ __launch_bounds__(256) void k_lx3_prep(const float* __restrict__ rep, bf16* __restrict__ rep_hi, bf16* __restrict__ rep_lo,
-                                                  int B, int Bp, int H) {
+                                                  int B, int Bp, int H, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp * LDR) return;
     const int b = i / LDR, c = i - b * LDR;
     const float x = (b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f;
-    const bf16 h = (bf16)x;
+    const bf16 h = (bf16)x, l = (bf16)(x - (float)h);
     rep_hi[i] = h;
-    rep_lo[i] = (bf16)(x - (float)h);
+    rep_lo[i] = l;
+    if (img && c < HP) {
+        char* p = img + (size_t)(b >> 5) * X3_IMG_B + x3_kc_off(c >> 3) + 16 * (b & 31) + 2 * (c & 7);
+        *(bf16*)p = h;
+        *(bf16*)(p + X3_PLANE_B) = l;
+    }
 }
 
 
@@ -982,7 +989,7 @@ int ader_lx3_prep(const float* rep, void* rep_hi, void* rep_lo, int B, int Bp, i
     if (Bp <= 0) return 0;
     if (B > Bp || H > HP) return -2;
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, (hipStream_t)stream, rep, (bf16*)rep_hi, (bf16*)rep_lo,
-                       B, Bp, H);
+                       B, Bp, H, (char*)nullptr);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1003,10 +1010,22 @@ static int lx3_attr() {
     return 0;
 }
 
+int ader_lx3_fwd_img(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                     void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
+                     float* drep, void* rep_img, void* stream);
 int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
                  void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
                  float* drep, void* stream) {
+    return ader_lx3_fwd_img(rep, emb, item_num, B, Bp, H, N, lab, wrow, rep_hi, rep_lo, pm, pl, pO, lse, off, rowloss, loss, drep, nullptr,
+                            stream);
+}
+// ... rep_img != NULL: ader_x3_rep_image's output (ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned, pads zero) is written by the same
+// launch that cuts the operand planes: the fused update finds it ready (one launch and one kernel boundary fewer on the critical path)
+int ader_lx3_fwd_img(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                     void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
+                     float* drep, void* rep_img, void* stream) {
     if (B <= 0) return 0;
+    if (rep_img && ((uintptr_t)rep_img & 15)) return -2;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || ((uintptr_t)emb & 7)) return -2;
     const size_t lds = (size_t)2 * 2 * FB * LDR * sizeof(bf16);
     int rc = lx3_attr();
@@ -1020,7 +1039,7 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
     LbfArgs a;
     a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
     a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
-    hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H);
+    hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H, (char*)rep_img);
     if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);

@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
         const int tile0 = (tileA + h) * TI;
         const int rows_avail = (tileA + h < a.tile_end) ? min(TI, a.vrows - tile0) : 0;
         const int n_av = rows_avail > 0 ? rows_avail * H : 0;
-        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.emb1 + (size_t)tile0 * H), 0, (unsigned)n_av * 4u, 0x00020000);
+        const size_t tqe = (a.ko & 256) ? (size_t)((tileA + h) & 63) * TI : (size_t)tile0;   // ko 256: operand rows served by L2 (timing only)
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.emb1 + tqe * H), 0, (unsigned)n_av * 4u, 0x00020000);
         const int vt = 4 * ((wave * 16 + c16) * H + 8 * g);
         f32x4_t x0[5], x1[5];
 #pragma unroll
@@ -891,7 +892,7 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
     const size_t lds = tab16x3_lds(a.Bp, kd ? a.Bp - a.kd_row0 : 0);
     hipStream_t st = (hipStream_t)stream;
     a.tile_end = a.tile_off + tiles;
-    if (tab_pairs() && (a.tile_off & 1) == 0 && !a.ko) {
+    if (tab_pairs() && (a.tile_off & 1) == 0 && !(a.ko & 0xff)) {
         if (kd) return tab32x3_launch_t<false, true>(a, fa, tiles, lds, st);
         if (extra) return tab32x3_launch_t<true, false>(a, fa, tiles, lds, st);
         return tab32x3_launch_t<false, false>(a, fa, tiles, lds, st);

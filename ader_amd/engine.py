@@ -785,8 +785,13 @@ class Engine:
                     # the loss scalar feeds nothing in the backward pass: with the fused update deferred, its (single-workgroup) sum
                     # leaves the critical path and runs beside the table update
                     late_loss = bool(defer and self.dp_world == 1 and not split_kd and self.late_side_stream and self.seq_fused)
-                    call("ader_lx3_fwd", ptr(rep), emb, self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(rep_lo),
-                         ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), st)
+                    # (the operand images of the fused update are cut by the same launch as the operand planes)
+                    img = (self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", Bp),), torch.uint8, zero=True)
+                           if (defer and self.x3_update == "tab16" and not split_kd) else None)
+                    call("ader_lx3_fwd_img", ptr(rep), emb, self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(rep_lo),
+                         ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep),
+                         ptr(img), st)
+                    self._img_ready = img is not None
                     self._pending_loss = (rowloss, Bb) if late_loss else None
                 else:
                     call("ader_lbf_fwd", ptr(rep), ptr(self.shadow), self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf),
@@ -1146,7 +1151,9 @@ class Engine:
         with self._sec("logits_bwd_adam"):
             if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
                 img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", D["Bp"]),), torch.uint8, zero=True)
-                call("ader_x3_rep_image", ptr(D["rep_bf"]), ptr(D["rep_lo"]), D["Bp"], ptr(img), st)
+                if not (getattr(self, "_img_ready", False) and not D.get("kd")):
+                    call("ader_x3_rep_image", ptr(D["rep_bf"]), ptr(D["rep_lo"]), D["Bp"], ptr(img), st)
+                self._img_ready = False
             if self.lx3 and D.get("kd"):
                 K = D["kd"]
                 call("ader_tab_update_x3_kd" if self.x3_update == "tab16" else "ader_tab_update_kd", ptr(D["rep_bf"]), ptr(D["rep_lo"]),

@@ -266,6 +266,11 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
 /* loss = sum of rowloss[0..n) in a fixed order: the last launch of ader_lx3_fwd when that was given loss = NULL (reference
  * ADER.py:93: reduce_mean of the per-row cross entropies; the weights 1/B are already in rowloss). */
 int ader_lbf_sum(const float* rowloss, int n, float* loss, void* stream);
+/* ader_lx3_fwd that also writes the operand images of the fused update (rep_img: ader_x3_rep_image_bytes(Bp) bytes, zero-initialised
+ * once, 16-byte aligned; NULL: exactly ader_lx3_fwd) -- ader_x3_rep_image need not be launched for this batch. */
+int ader_lx3_fwd_img(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab,
+                     const float* wrow, void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off,
+                     float* rowloss, float* loss, float* drep, void* rep_img, void* stream);
 /* Gradient of the one-hot softmax CE w.r.t. the item table (ADER.py:91-93 differentiated): demb rows 1..N overwritten
  * (each row written once, then the sparse one-hot term is added with float atomics).  The GEMM operand is cut from the
  * fp32 table `emb` inside the kernel (bf16, or hi/lo when rep_lo != NULL: x3 mode). */
