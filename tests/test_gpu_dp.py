@@ -302,3 +302,73 @@ def test_odd_batch_sharded_then_checkpoint_then_dense_distilled_step():
     ref = eng.theta.cpu().numpy()[:(ITEMS + 1) * H]
     d = np.abs(got[1]["theta"].numpy() - ref)
     assert np.mean(d < 5e-6) > 0.99 and d.max() < 3e-3
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 4's shape: 8 ranks x 512 rows
+Y_ITEMS, Y_N, Y_B, Y_W = 25958, 25750, 4096, 8       # YOOCHOOSE: item_num (main.py:136), max_item of its last period, 8 x 512 rows
+
+
+def _y_data():
+    rs = np.random.RandomState(11)
+    seq = np.zeros((Y_B, T), dtype=np.int32)
+    ln = np.clip(rs.geometric(0.2, size=Y_B), 1, T)                 # session lengths of the real splits (mean ~5)
+    for b in range(Y_B):
+        seq[b, T - ln[b]:] = rs.randint(1, Y_N + 1, size=ln[b])
+    pos = rs.randint(1, Y_N + 1, size=Y_B).astype(np.int32)
+    return seq, pos
+
+
+def _y_engine(rank=0, world=1):
+    from ader_amd.engine import Engine
+    eng = Engine(Y_ITEMS, maxlen=T, hidden_units=H, num_blocks=L, num_heads=HEADS, seed=4, logits_dtype="x3", dp_rank=rank,
+                 dp_world=world)
+    g = torch.Generator().manual_seed(2)
+    for k in eng.layout:
+        if k.endswith("_b"):
+            eng.param(k).copy_(torch.randn(eng.layout[k][1], generator=g) * 0.1)
+    return eng
+
+
+def _y_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ader_amd import dist as adist
+    seq, pos = _y_data()
+    eng = _y_engine(rank, world)
+    dp = adist.DataParallel(eng, rank, world)
+    eng.dp_mode = "catalog"                      # the `bench.py --gpus N` default; 8 ranks: packed (uneven) row exchange by default
+    lo, hi = adist.shard_bounds(Y_B, world, rank)
+    assert hi - lo == 512
+    for step in range(2):
+        dp.set_rows(lo, Y_N)
+        eng.train_step(seq[lo:hi], pos[lo:hi], Y_N, 5e-4, rate=0.3, n_train_global=Y_B)
+    eng.sync_table()
+    torch.cuda.synchronize()
+    if rank == world - 1:
+        torch.save(eng.theta.cpu()[:(Y_ITEMS + 1) * H], out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_global_batch_4096_at_the_yoochoose_catalog_match_single_process():
+    """BASELINE.json configs[3] ("YOOCHOOSE ADER data-parallel global_batch=4096, 8 ranks") as far as one GPU can take it: EIGHT
+    ranks share cuda:0 (gloo carries the collectives), 512 rows each, catalog-sharded table at float32 grade with the 8-rank
+    defaults (packed row exchange), YOOCHOOSE's catalog size and session lengths; two optimiser steps with dropout on == one process
+    stepping on the 4,096 rows (main.py:223-256 with the batch split over the ranks)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "theta.pt")
+        mp.spawn(_y_worker, args=(Y_W, port, out), nprocs=Y_W, join=True)
+        got = torch.load(out).numpy()
+    seq, pos = _y_data()
+    eng = _y_engine()
+    for step in range(2):
+        eng.train_step(seq, pos, Y_N, 5e-4, rate=0.3)
+    torch.cuda.synchronize()
+    ref = eng.theta.cpu().numpy()[:(Y_ITEMS + 1) * H]
+    d = np.abs(got - ref)
+    # (bounds of test_two_ranks_match_single_process at > 1024 rows: elements whose gradient is ~eps may move by +-lr per step)
+    assert np.mean(d < 5e-6) > 0.995 and d.max() < 2.5e-3, (np.mean(d < 5e-6), d.max())
