@@ -137,8 +137,12 @@ class ExemplarGenerator:
             p += c
         return int(len(keep))
 
-    def loss_selection(self, sess, model):
+    def loss_selection(self, sess, model, first_only=False):
         """Exemplars with the SMALLEST loss per label (util.py:463-495), ranking by the per-row cross entropy.
+
+        first_only (driver flag `--selection loss_ref`): what the reference's code EXECUTES rather than what it documents -- the first
+        candidate of every label with a quota >= 1 (see below): the exemplar set of the poster's `loss` columns, if the published
+        code produced them.
 
         The reference fetches `model.loss` -- the batch MEAN, a scalar (ADER.py:93) -- so its `loss.argsort()[:m]` sees a 0-d array,
         yields [0] and always keeps just the FIRST candidate of every label.  This implementation does
@@ -153,7 +157,8 @@ class ExemplarGenerator:
             m = int(self.item_count[label - 1])
             c = 0
             if m >= 1:
-                ids = np.argsort(loss[offs[g]:offs[g + 1]], kind="stable")[:min(m, n)]
+                ids = (np.zeros(1, np.int64) if first_only else
+                       np.argsort(loss[offs[g]:offs[g + 1]], kind="stable")[:min(m, n)])
                 keep.append(ids + offs[g])
                 c = len(ids)
             counts.append(c)

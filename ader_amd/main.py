@@ -246,6 +246,8 @@ def run(args, log=print):
                     saved_num = exemplar.herding_selection(sess, model)
                 elif args.selection == 'loss':
                     saved_num = exemplar.loss_selection(sess, model)
+                elif args.selection == 'loss_ref':                           # the reference's executed behaviour (util.py:488)
+                    saved_num = exemplar.loss_selection(sess, model, first_only=True)
                 elif args.selection == 'random':
                     saved_num = exemplar.randomly_selection(sess, model)
                 else:
