@@ -15,6 +15,9 @@ PARITY STATUS: **unpinned** for the model math.  TensorFlow 2.0/2.1 (requirments
 not installed here and the reference has no tests or golden vectors for this path,
 so this file restates the published TF semantics at the reference's call sites; it is checked by
 hand-derived cases and fp64 finite differences (tests/test_oracle_model.py), not by reference output.
+What the reference itself publishes pins the path END TO END instead: the per-period test curves of its figure
+(results.svg -> tests/golden/results_svg_curves.json) and its poster's ablation table, against which the HIP path that
+matches this restatement op by op is run for all 16 periods of both datasets (tests/test_gpu_e2e_parity.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 

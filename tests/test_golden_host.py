@@ -152,3 +152,22 @@ def test_exemplar_store_round_trip(tmp_path):
     view = back.by_label()
     assert sorted(view) == [3, 9] and [e[0] for e in view[3]] == [[5, 9, 3], [1, 2, 3, 4, 3]] and view[9][0][0] == [7, 7, 2, 9]
     assert torch.equal(view[9][0][1], logits[1])
+
+
+def test_published_curves_fixture():
+    """tests/golden/results_svg_curves.json (the reference's results.svg, recovered by tests/golden/make_results_curves.py): 2 datasets
+    x 5 methods x 2 metrics x 16 periods, and the 16-period averages the reference's paper / poster quote for ADER on DIGINETICA."""
+    import json
+    cur = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "results_svg_curves.json")))["curves"]
+    assert sorted(cur) == ["DIGINETICA", "YOOCHOOSE"]
+    for ds in cur:
+        assert sorted(cur[ds]) == ["ADER", "Dropout", "EWC", "Finetune", "Joint"]
+        for m in cur[ds].values():
+            assert len(m["recall20"]) == 16 and len(m["mrr20"]) == 16
+    avg = lambda v: sum(v) / 16      # noqa: E731
+    assert abs(avg(cur["DIGINETICA"]["ADER"]["recall20"]) - 50.21) < 0.02 and abs(avg(cur["DIGINETICA"]["ADER"]["mrr20"]) - 17.32) < 0.02
+    assert abs(avg(cur["YOOCHOOSE"]["ADER"]["recall20"]) - 72.38) < 0.02 and abs(avg(cur["YOOCHOOSE"]["ADER"]["mrr20"]) - 36.71) < 0.02
+    # ADER is the best continual method on both datasets, fine-tuning the worst (the figure's message)
+    for ds in cur:
+        r = {k: avg(v["recall20"]) for k, v in cur[ds].items()}
+        assert r["ADER"] > r["Dropout"] > r["EWC"] > r["Finetune"]

@@ -43,15 +43,64 @@ def test_diginetica_ader_bf16_inside_the_poster_band():
     assert 36.7 <= 100.0 * avg["recall10"] <= 37.9 and 15.85 <= 100.0 * avg["mrr10"] <= 16.9   # poster 37.21-37.41 / 16.35-16.41
 
 
-def test_yoochoose_ader_regression_pin():
+def _curves():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "results_svg_curves.json")))["curves"]
+
+
+def _against_figure(out, dataset, method, tol_avg, tol_period):
+    """Average and per-period test metrics of a 16-period run against the curve of the reference's published figure (results.svg,
+    recovered by tests/golden/make_results_curves.py).  Per-period numbers carry the run's own noise (early stopping, RNG streams
+    that diverge from the reference's as soon as an epoch count differs: SURVEY appendix), so they are held to a mean absolute
+    deviation; the 16-period averages to tol_avg."""
+    ref = _curves()[dataset][method]
+    per = out["periods"]
+    assert len(per) == 16
+    res = {}
+    for key in ("recall20", "mrr20"):
+        mine = [100.0 * p_[key] for p_ in per]
+        avg, avg_ref = sum(mine) / 16, sum(ref[key]) / 16
+        mad = sum(abs(a - b) for a, b in zip(mine, ref[key])) / 16
+        res[key] = (avg, avg_ref, mad)
+        print("%s %s %s: average %.2f (figure %.2f, delta %+.2f), per-period mean |delta| %.2f"
+              % (dataset, method, key, avg, avg_ref, avg - avg_ref, mad))
+    for key, (avg, avg_ref, mad) in res.items():
+        assert abs(avg - avg_ref) <= tol_avg, (dataset, method, key, avg, avg_ref)
+        assert mad <= tol_period, (dataset, method, key, "per-period deviation", mad)
+    return res
+
+
+def test_yoochoose_ader_matches_the_published_curve():
+    """BASELINE configs[2]: YOOCHOOSE `--lambda_=1.0 --batch_size=512 --test_batch=64` (reference README.md:77), bf16 logit operands.
+    The reference's figure gives ADER on YOOCHOOSE 72.38 % Recall@20 / 36.71 % MRR@20 over the 16 periods: this run must be within 0.3
+    point of both (measured: 72.32 / 36.69) and follow the per-period curve."""
     out = _run(["--dataset", "YOOCHOOSE", "--lambda_", "1.0", "--batch_size", "512", "--test_batch", "64", "--logits_dtype",
                 "bf16"])
-    avg, per = out["average"], out["periods"]
-    assert len(per) == 16
+    per = out["periods"]
     assert per[0]["max_item"] == 12885 and per[-1]["max_item"] == 25750
-    r20, m20 = 100.0 * avg["recall20"], 100.0 * avg["mrr20"]
-    assert abs(r20 - 72.31) <= 0.3, ("Recall@20 moved from the committed pin 72.31", r20)
-    assert abs(m20 - 36.72) <= 0.3, ("MRR@20 moved from the committed pin 36.72", m20)
+    _against_figure(out, "YOOCHOOSE", "ADER", 0.3, 0.35)
+
+
+# ---- the baselines of the reference's figure (README.md:83-86: --finetune / --dropout / --ewc), float32 grade, both datasets.
+# Measured in round 3 (profiles/e2e_r3/baselines_scan.txt): YOOCHOOSE Finetune 71.83 / 36.50, Dropout 72.21 / 36.61, EWC 71.90 / 36.54,
+# ADER 72.34 / 36.71 against the figure's 71.86 / 36.49, 72.20 / 36.60, 71.91 / 36.53, 72.38 / 36.71 -- every average within 0.04 point;
+# DIGINETICA (a third of the data, noisier) Finetune 47.04 / 16.04, Dropout 48.72 / 16.72, EWC 47.18 / 16.08, Joint 49.93 / 17.33 against
+# 47.28 / 16.01, 49.07 / 16.86, 47.66 / 16.28, 50.03 / 17.31.  (Joint is not in the suite: 5.5 minutes.)
+BASELINES = [
+    ("YOOCHOOSE", "Finetune", ["--finetune", "True"], 0.3, 0.4),
+    ("YOOCHOOSE", "Dropout", ["--dropout", "True"], 0.3, 0.4),
+    ("YOOCHOOSE", "EWC", ["--ewc", "True", "--lambda_", "1.0"], 0.3, 0.4),
+    ("DIGINETICA", "Finetune", ["--finetune", "True"], 0.6, 0.8),
+    ("DIGINETICA", "Dropout", ["--dropout", "True"], 0.6, 0.8),
+    ("DIGINETICA", "EWC", ["--ewc", "True"], 0.7, 0.9),
+]
+
+
+@pytest.mark.parametrize("dataset,method,flags,tol_avg,tol_period", BASELINES, ids=["%s-%s" % (b[0][:4], b[1]) for b in BASELINES])
+def test_baselines_match_the_published_curves(dataset, method, flags, tol_avg, tol_period):
+    extra = ["--batch_size", "512", "--test_batch", "64"] if dataset == "YOOCHOOSE" else []
+    out = _run(["--dataset", dataset, "--logits_dtype", "x3", "--save_dir", method] + extra + flags)
+    _against_figure(out, dataset, method, tol_avg, tol_period)
 
 
 def test_diginetica_ader_float32_grade_inside_the_poster_band():
@@ -62,6 +111,7 @@ def test_diginetica_ader_float32_grade_inside_the_poster_band():
     r20, m20 = 100.0 * avg["recall20"], 100.0 * avg["mrr20"]
     assert 49.4 <= r20 <= 50.6, ("Recall@20 outside the poster band", r20)
     assert 16.9 <= m20 <= 17.7, ("MRR@20 outside the poster band", m20)
+    _against_figure(out, "DIGINETICA", "ADER", 0.5, 0.8)      # the figure: 50.21 / 17.32
 
 
 # ---- the other columns of the poster's DIGINETICA table (reference flags main.py:83-91, command lines
