@@ -92,7 +92,10 @@ BASELINES = [
     ("YOOCHOOSE", "EWC", ["--ewc", "True", "--lambda_", "1.0"], 0.3, 0.4),
     ("DIGINETICA", "Finetune", ["--finetune", "True"], 0.6, 0.8),
     ("DIGINETICA", "Dropout", ["--dropout", "True"], 0.6, 0.8),
-    ("DIGINETICA", "EWC", ["--ewc", "True"], 0.7, 0.9),
+    # (the EWC baseline runs the unfused step -- dense gradient + penalty -- whose input-embedding scatter uses float atomics: last
+    #  bits differ from run to run, the trajectories diverge through early stopping, and on the small dataset the 16-period average
+    #  moves by +-0.25: 47.18 and 46.95 in two runs.  The fused path of the other rows is bitwise reproducible.)
+    ("DIGINETICA", "EWC", ["--ewc", "True"], 1.0, 1.1),
 ]
 
 
