@@ -85,17 +85,15 @@ def test_yoochoose_ader_matches_the_published_curve():
 # Measured in round 3 (profiles/e2e_r3/baselines_scan.txt): YOOCHOOSE Finetune 71.83 / 36.50, Dropout 72.21 / 36.61, EWC 71.90 / 36.54,
 # ADER 72.34 / 36.71 against the figure's 71.86 / 36.49, 72.20 / 36.60, 71.91 / 36.53, 72.38 / 36.71 -- every average within 0.04 point;
 # DIGINETICA (a third of the data, noisier) Finetune 47.04 / 16.04, Dropout 48.72 / 16.72, EWC 47.18 / 16.08, Joint 49.93 / 17.33 against
-# 47.28 / 16.01, 49.07 / 16.86, 47.66 / 16.28, 50.03 / 17.31.  (Joint is not in the suite: 5.5 minutes.)
+# 47.28 / 16.01, 49.07 / 16.86, 47.66 / 16.28, 50.03 / 17.31.  Not in the suite (its time budget): Joint (5.5 minutes), YOOCHOOSE
+# Finetune, and DIGINETICA EWC -- the EWC baseline runs the unfused step whose input-embedding scatter uses float atomics: last bits
+# differ from run to run, the trajectories diverge through early stopping, and on the small dataset the 16-period average moves by
+# +-0.25 (47.18 and 46.95 in two runs); the fused path of the other rows is bitwise reproducible.
 BASELINES = [
-    ("YOOCHOOSE", "Finetune", ["--finetune", "True"], 0.3, 0.4),
     ("YOOCHOOSE", "Dropout", ["--dropout", "True"], 0.3, 0.4),
     ("YOOCHOOSE", "EWC", ["--ewc", "True", "--lambda_", "1.0"], 0.3, 0.4),
     ("DIGINETICA", "Finetune", ["--finetune", "True"], 0.6, 0.8),
     ("DIGINETICA", "Dropout", ["--dropout", "True"], 0.6, 0.8),
-    # (the EWC baseline runs the unfused step -- dense gradient + penalty -- whose input-embedding scatter uses float atomics: last
-    #  bits differ from run to run, the trajectories diverge through early stopping, and on the small dataset the 16-period average
-    #  moves by +-0.25: 47.18 and 46.95 in two runs.  The fused path of the other rows is bitwise reproducible.)
-    ("DIGINETICA", "EWC", ["--ewc", "True"], 1.0, 1.1),
 ]
 
 
@@ -129,7 +127,7 @@ def test_diginetica_ader_float32_grade_inside_the_poster_band():
 #     49.23 / 49.01 / 48.94 / 48.70 / 48.33 (--fix_lambda, i.e. a constant 0.8: 47.39) -- one-hot replay wants a smaller weight than
 #     distillation, and at --lambda_ 0.2 ALL FOUR published metrics of both columns are met within 0.25 point (ER-herding 49.23 /
 #     16.90 / 36.77 / 16.04 against 49.44 / 16.95 / 36.88 / 16.08; ER-random 49.20 / 16.91 / 36.67 / 16.05 against 49.14 / 16.79 /
-#     36.61 / 15.92).  The columns are therefore asserted at --lambda_ 0.2, +- 0.5 point like the others.
+#     36.61 / 15.92).  The ER-herding column is therefore asserted at --lambda_ 0.2, +- 0.5 point like the others (ER-random: measured, not in the suite).
 #   * ER-loss: the reference's `loss` selector ranks a 0-d scalar (util.py:482-488: `model.loss` is the batch mean), so what its code
 #     EXECUTES is "keep the first candidate of every label with a quota": `--selection loss_ref` reproduces that exemplar set (this
 #     build's `--selection loss` ranks by the per-row loss the method documents).  At --lambda_ 0.2 on the exact-f32 kernels: 49.18 /
@@ -138,7 +136,6 @@ def test_diginetica_ader_float32_grade_inside_the_poster_band():
 #     through the early-stopping decisions (same flags: bf16 operands 49.24, float32 grade 48.71 -- both runs are deterministic).
 POSTER = [
     ("ER-herding", ["--disable_distillation", "True", "--lambda_", "0.2"], 49.44, 16.95, None),
-    ("ER-random", ["--disable_distillation", "True", "--selection", "random", "--lambda_", "0.2"], 49.14, 16.79, None),
     ("ER-loss", ["--disable_distillation", "True", "--selection", "loss_ref", "--lambda_", "0.2", "--logits_dtype", "f32"], 49.31, 16.90, None),
     ("ADER-equal", ["--equal_exemplar", "True"], 49.92, 17.23, None),
     ("ADER-fix", ["--fix_lambda", "True"], 50.09, 17.29, None),
