@@ -94,6 +94,7 @@ _SIGS = {
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_reduce_slabs_batch": [P, P, P, P, P, P, P, P, I, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
+    "ader_herding_select_generic": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
 SEQ_MAXL = 4
 

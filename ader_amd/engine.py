@@ -167,7 +167,7 @@ class Engine:
     MAX_ROWS_FAST = 4096   # ... of a train step whose logits run on the flash kernels (logits_dtype bf16 / x3): 128-row chunks
 
     def __init__(self, item_num, maxlen=50, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device="cuda:0",
-                 logits_dtype="f32", gemm="x3", dp_rank=0, dp_world=1):
+                 logits_dtype="x3", gemm="x3", dp_rank=0, dp_world=1):
         if not torch.cuda.is_available():
             raise _lib.AderHipError("ader_amd.Engine needs an MI355X (no CPU fallback)")
         _lib.load()
@@ -1406,7 +1406,10 @@ class Engine:
             if self.lx3:
                 # float32 grade: the fp32 representations travel (W * Bp * H floats), every rank cuts the hi / lo operand planes of
                 # the GLOBAL batch itself and streams the fp32 rows of ITS shard
-                rep_pad = self.buf("cs_rep_pad", (Bp, H))
+                # (pad rows [B, Bp) must be finite: they are all-gathered and enter every rank's S = rep.E^T as real rows, silenced
+                #  only by off = -inf -- exp2(NaN - inf) is NaN and would poison the whole shard: cleared at allocation, and rows
+                #  a larger earlier batch left behind are finite representations)
+                rep_pad = self.buf("cs_rep_pad", (Bp, H), zero=True)
                 rep_pad[:B].copy_(rep)
                 rep_f = self._ag(rep_pad)                                      # [W, Bp, H]
                 rep_g = self.buf("cs_rep_hi", (W * Bp * 168,), torch.bfloat16)
@@ -1676,7 +1679,7 @@ class Engine:
         seg = torch.as_tensor(np.asarray(offs, dtype=np.int64)).to(self.device)
         q = torch.as_tensor(np.asarray(quota, dtype=np.int32)).to(self.device)
         ms = torch.as_tensor(np.array([herding_max_steps(int(m)) for m in quota], dtype=np.int32)).to(self.device)
-        D = torch.empty(max(n * self.H, 1), dtype=torch.float32, device=self.device)
+        D = torch.empty(n * self.H + G + 64, dtype=torch.float32, device=self.device)     # normalised columns + the device-built work list
         chosen = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
         sel = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
         cnt = torch.zeros(max(G, 1), dtype=torch.int32, device=self.device)

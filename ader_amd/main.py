@@ -51,7 +51,7 @@ _REFERENCE_FLAGS = (
 )
 # Flags of this build only: (flag, default, type, help / choices)
 _BUILD_FLAGS = (
-    ("logits_dtype", "f32", str, ("f32", "bf16", "x3")), ("max_periods", 0, int, None), ("data_root", None, str, None),
+    ("logits_dtype", "x3", str, ("f32", "bf16", "x3")), ("max_periods", 0, int, None), ("data_root", None, str, None),
     ("results_root", "results", str, None), ("save_ckpt", False, bool, None),
     ("dist_backend", "nccl", str, "torch.distributed backend when WORLD_SIZE > 1"),
     ("device_feed", True, bool, "keep the packed training rows on the GPU and gather batches there"),

@@ -28,7 +28,7 @@ class Ader:
     def __init__(self, item_num, args, reuse=None, device="cuda:0", logits_dtype=None, dp_rank=0, dp_world=1):
         self.args = args
         self.item_num = item_num
-        ld = logits_dtype or getattr(args, "logits_dtype", "f32")
+        ld = logits_dtype or getattr(args, "logits_dtype", "x3")
         self.engine = Engine(item_num, maxlen=args.maxlen, hidden_units=args.hidden_units, num_blocks=args.num_blocks,
                              num_heads=args.num_heads, seed=args.random_seed, device=device, logits_dtype=ld,
                              dp_rank=dp_rank, dp_world=dp_world)

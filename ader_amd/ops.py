@@ -154,7 +154,7 @@ def herding_select(rep: torch.Tensor, seg: torch.Tensor, quota: torch.Tensor, ma
     if seg.shape[0] != G + 1 or max_steps.shape[0] != G:
         raise RuntimeError("ader::herding_select: seg must be [G+1], quota / max_steps [G]")
     dev = rep.device
-    D = torch.empty(max(n * H, 1), device=dev)
+    D = torch.empty(n * H + G + 64, device=dev)
     chosen = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
     sel = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
     cnt = torch.zeros(max(G, 1), dtype=torch.int32, device=dev)

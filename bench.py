@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0    # MI355X_MICROARCH.md: what a pure streaming kernel reaches (frac_of_achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 
@@ -139,6 +140,9 @@ def main():
                     help="rocprofv3 PMC summary of THIS command (tools/summarize_profiles.py) to quote roofline.traffic from; "
                          "without it traffic is null (bench.py never pairs live timings with counters of another run)")
     ap.add_argument("--no-sections", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--sustained-steps", type=int, default=2000,
+                    help="after the median-of-reps block: ONE more timed region of this many steps of the same kernels (~4 s), so the "
+                         "line also says what a power-limited chip sustains (0 = skip)")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: start the ranks as children BEFORE anything touches the GPU (never re-exec a GPU process)
@@ -244,6 +248,27 @@ def main():
     eng = make_engine(args.logits)
     dts, sections, loss = timed(eng, args.reps, not args.no_sections)
     dt = float(np.median(dts))
+
+    # ---- sustained figure: the K-step repetitions above are ~40 ms bursts on a chip that clocks down under the logit kernels
+    # (MI355X_MICROARCH.md, DVFS): one multi-second region of the SAME steps, no per-kernel events, same barrier + synchronize
+    sustained = None
+    if args.sustained_steps > 0 and args.workload == "cfgS":
+        eng.timer = None
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.sustained_steps):
+            eng.train_step(*batches[i % nbatch], N, lr, **kw)
+        sync()
+        dts_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dts_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts_ = float(t.item())
+        eng.check_status()
+        sustained = {"steps": args.sustained_steps, "seconds": round(dts_, 3), "ms_per_step": dts_ / args.sustained_steps * 1e3,
+                     "value": B * world * args.sustained_steps / dts_,
+                     "clock_note": "one uninterrupted region after the median-of-reps block (the chip has been under load for its whole "
+                                   "length: steady-state clocks); `value` above is the median of short bursts"}
 
     # ---- standalone embedding gather (north_star: "rocprof HBM GB/s on the gather"): in the step it is fused into the one-launch
     # forward, so it is timed here as its own kernel on the same batch (ader_embed_fwd: ids -> x0 = drop(E[ids]*sqrt(H) + P) * mask)
@@ -388,6 +413,7 @@ def main():
             rms = rocprof_ms(pmc_kernel.get(dom, "?"))
             roof = {"kernel": dom + " (" + pmc_kernel.get(dom, "").rstrip("<") + ")", "bound": bound, "achieved": ach, "peak": peak,
                     "unit": unit, "frac": ach / peak,
+                    "frac_of_achievable": (ach / HBM_ACHIEVABLE_GBS) if unit == "GB/s" else None,
                     "traffic": (hb.get("hbm_bytes") if (hb and unit == "GB/s") else None),
                     "traffic_source": pmc_src, "ms": sections[dom], "ms_rocprof": rms,
                     "frac_rocprof": (amount / (rms * 1e-3) / (1e9 if unit == "GB/s" else 1e12) / peak) if rms else None,
@@ -477,6 +503,7 @@ def main():
                        "dropout": rate, "optimizer": "dense TF-Adam", "exchange": exchange, "precision": prec[args.logits],
                        "parallelism": "dp%d" % world, "final_loss": loss,
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1)},
+            "sustained": sustained,
             "comm": comm,
             # companion of the same step with the other logits type (bf16 operands: narrower than the reference's float32)
             ("value_" + (comp_name or "companion")): comp["value"] if comp else None,

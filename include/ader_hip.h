@@ -376,9 +376,19 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
 int ader_reduce_slabs_batch(const float* const* src, const long* slab_stride, const int* S, const int* ld, const int* n_rows,
                             const int* n_cols, float* const* dst, float* const* dst_extra, int n, void* stream);
 
-/* ---- herding exemplar selection: util.py:401-434 ------------------------------------------------------- */
+/* ---- herding exemplar selection: util.py:401-434 (the loop of ExemplarGenerator.herding, called per label from
+ *      herding_selection util.py:447-457) -- ALL label groups of a period in one call ------------------------------------
+ * rep [n_total,H] candidate representations in group order; seg [G+1] group offsets; quota [G]; max_steps [G] = number of
+ * integers k < 1.1*min(quota,n) (the reference's loop bound, evaluated by the host in float64).  Scratch: D n_total*H + G + 64
+ * floats, chosen n_total bytes.  Out: sel [n_total] (per group, the selected LOCAL indices in selection order at the start of
+ * its span), sel_cnt [G], steps_out [G] (optional).  H = 150 (the reference's hidden_units): register-resident kernel;
+ * any other H <= 256: the generic kernel.  Both follow the canonical float32 spec of oracle/herding_ref.py bit for bit. */
 int ader_herding_select(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
                         int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
+/* the generic kernel for any H <= 256 (one 256-thread workgroup per group, D streamed from L2 every iteration; D needs only
+ * n_total*H floats): what ader_herding_select runs for H != 150, exported for kernel-vs-kernel checks and A/B timing */
+int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
+                                int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,8 @@ def _run(args, env=None):
 
 
 def test_single_gpu_line_has_the_contract_fields():
-    d = _run(["--steps", "3", "--warmup", "3", "--reps", "3", "--items", "30000", "--no-cpu-baseline", "--no-herding"])
+    d = _run(["--steps", "3", "--warmup", "3", "--reps", "3", "--items", "30000", "--no-cpu-baseline", "--no-herding",
+              "--sustained-steps", "40"])
     assert d["n_gpus"] == 1 and d["dtype"].startswith("bf16x3") and d["unit"] == "sessions/s" and d["scaling"] == "weak"
     assert d["reps"] == 3 and d["reps_ms"]["min"] <= d["reps_ms"]["median"] <= d["reps_ms"]["max"]
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
@@ -34,11 +35,15 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["logit_gemm"]["flops_executed"] == 3 * r["logit_gemm"]["flops_credited"]
     assert d["value_bf16"] is not None and d["companion"]["logits"] == "bf16"
     assert "REDUCED SIZE" in d["config"]["workload"]
+    su = d["sustained"]
+    assert su["steps"] == 40 and abs(su["value"] - 512 / (su["ms_per_step"] * 1e-3)) < 1e-6 * su["value"]
+    assert r["frac_of_achievable"] is None or r["frac_of_achievable"] > r["frac"]
 
 
 @pytest.mark.parametrize("mode", ["catalog", "replicated"])
 def test_gpus_2_starts_its_own_ranks(mode):
-    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--reps", "1", "--items", "20000", "--no-cpu-baseline", "--dp-mode", mode],
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--reps", "1", "--items", "20000", "--no-cpu-baseline", "--dp-mode", mode,
+              "--sustained-steps", "0"],
              env={"ADER_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 1024
     assert d["comm"]["exchange_bytes_per_step"] > 0 and d["comm"]["comm_ms"] >= 0

@@ -39,12 +39,22 @@ def _engine(logits, rank=0, world=1):
     return eng
 
 
+def _poison_allocator():
+    """Leave NaN bit patterns in the caching allocator's free blocks of every size class, so that every `torch.empty` workspace
+    of the step starts out as NaN: pad rows that a kernel reads but nobody wrote then show up in the result (round-3 advisor
+    finding: the all-gathered pad rows of the catalog-sharded x3 step)."""
+    blocks = [torch.full((n,), float("nan"), device="cuda") for n in (128, 4096, 65536, 1 << 20, 1 << 22, 1 << 24) for _ in range(6)]
+    torch.cuda.synchronize()
+    del blocks
+
+
 def _worker(rank, world, port, out, logits, sharded, B=B):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ader_amd import dist as adist
     seq, pos = _data(B)
     eng = _engine(logits, rank, world)
+    _poison_allocator()        # (B / 2 = 48 or 700 rows per rank: never a multiple of 128 -> every padded buffer has pad rows)
     eng.dp_sharded = bool(sharded)
     dp = adist.DataParallel(eng, rank, world)
     if sharded in ("catalog", "catalog_packed"):

@@ -19,6 +19,7 @@ from oracle import herding_ref  # noqa: E402
 
 def _engine(item_num, T, H, L, heads, seed=0, **kw):
     from ader_amd.engine import Engine
+    kw.setdefault("logits_dtype", "f32")      # the exact-f32 kernels unless a test names another arithmetic (Engine's default is "x3")
     eng = Engine(item_num, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=seed, **kw)
     # non-trivial LN parameters / biases so masks and residual paths are exercised away from the init symmetry
     g = torch.Generator().manual_seed(seed + 11)
@@ -929,29 +930,42 @@ def test_herding_bit_exact_against_oracle(golden_dir):
         reps.append(herding_inputs(c["seed"], c["n"], c["H"], c["dup"]))
         offs.append(offs[-1] + c["n"])
         quota.append(min(c["m"], c["n"]))
+    # ... plus the size classes of the register-resident kernel (csrc/herding.hip: one wave up to 64 rows, one workgroup up to 512,
+    # then 240 LDS-resident candidates, then streamed ones) at their boundaries, duplicates included -- checked against the oracle only
+    cases = [dict(c) for c in cases]
+    for i, (nn, mm, dup) in enumerate([(64, 64, False), (65, 30, False), (129, 129, True), (511, 40, False), (512, 512, False),
+                                       (513, 77, True), (752, 90, False), (753, 753, False), (1300, 25, True), (2, 0, False)]):
+        cases.append({"seed": 900 + i, "n": nn, "H": 150, "m": mm, "dup": dup, "class": "oracle-only"})
+        reps.append(herding_inputs(900 + i, nn, 150, dup))
+        offs.append(offs[-1] + nn)
+        quota.append(min(mm, nn))
     rep = torch.from_numpy(np.concatenate(reps)).cuda()
     n, G, H = rep.shape[0], len(cases), 150
     dev = rep.device
     seg = torch.tensor(offs, dtype=torch.int64, device=dev)
     q = torch.tensor(quota, dtype=torch.int32, device=dev)
     ms = torch.tensor([herding_max_steps(m) for m in quota], dtype=torch.int32, device=dev)
-    D = torch.empty(n * H, device=dev)
-    chosen = torch.empty(n, dtype=torch.uint8, device=dev)
-    sel = torch.zeros(n, dtype=torch.int32, device=dev)
-    cnt = torch.zeros(G, dtype=torch.int32, device=dev)
-    steps = torch.zeros(G, dtype=torch.int32, device=dev)
-    _lib.call("ader_herding_select", rep.data_ptr(), seg.data_ptr(), q.data_ptr(), ms.data_ptr(), G, n, H, D.data_ptr(),
-              chosen.data_ptr(), sel.data_ptr(), cnt.data_ptr(), steps.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    sel, cnt, steps = sel.cpu().numpy(), cnt.cpu().numpy(), steps.cpu().numpy()
+    out = {}
+    for fn in ("ader_herding_select", "ader_herding_select_generic"):
+        D = torch.full((n * H + G + 64,), float("nan"), device=dev)
+        chosen = torch.empty(n, dtype=torch.uint8, device=dev)
+        sel = torch.zeros(n, dtype=torch.int32, device=dev)
+        cnt = torch.full((G,), -1, dtype=torch.int32, device=dev)
+        steps = torch.full((G,), -1, dtype=torch.int32, device=dev)
+        _lib.call(fn, rep.data_ptr(), seg.data_ptr(), q.data_ptr(), ms.data_ptr(), G, n, H, D.data_ptr(),
+                  chosen.data_ptr(), sel.data_ptr(), cnt.data_ptr(), steps.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out[fn] = (sel.cpu().numpy(), cnt.cpu().numpy(), steps.cpu().numpy())
+    sel, cnt, steps = out["ader_herding_select"]
     n_ref_exact = 0
     for g, c in enumerate(cases):
         o_sel, o_steps = herding_ref.herding_select(reps[g], c["m"])
-        got = sel[offs[g]:offs[g] + cnt[g]].tolist()
-        assert got == o_sel, (c["n"], c["m"], c["dup"])                  # HIP == canonical spec, every case
-        assert steps[g] == o_steps
+        for fn, (sel_, cnt_, steps_) in out.items():
+            got = sel_[offs[g]:offs[g] + cnt_[g]].tolist()
+            assert got == o_sel, (fn, c["n"], c["m"], c["dup"])          # HIP == canonical spec, every case, both kernels
+            assert steps_[g] == o_steps, (fn, c["n"], c["m"])
         if c["class"] == "exact":
-            assert got == c["selected"]                                   # == the reference's own herding()
+            assert sel[offs[g]:offs[g] + cnt[g]].tolist() == c["selected"]    # == the reference's own herding()
             n_ref_exact += 1
     assert n_ref_exact >= 30
 
