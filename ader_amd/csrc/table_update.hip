@@ -448,20 +448,48 @@ __global__ __launch_bounds__(256) void k_tile_meta(const int* __restrict__ sp_id
     }
 }
 
-// sparse one-hot term of dlogit for the gradient-only entry point: dE[label_b,:] -= w_b * rep_b  (one wave per batch row)
+// sparse one-hot term of dlogit for the gradient-only entry point: dE[label_b,:] -= w_b * rep_b  (one wave per batch row).
+// Several rows of a batch may share a label: the wave of the FIRST such row (lowest b) is the single writer of that table row and
+// subtracts the rows of all of them in batch order; the other waves leave.  No float atomics: the sum has one fixed order
+// (deterministic kernels on the parity path).
 __global__ __launch_bounds__(256) void k_tab_target_fix(const bf16* __restrict__ rep_hi, const bf16* __restrict__ rep_lo,
                                                         const int* __restrict__ lab, const float* __restrict__ wrow,
                                                         float* __restrict__ demb1, int B, int H) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;
-    const int t = lab[b] - 1;
+    const int lb = lab[b];
+    const int t = lb - 1;
     if (t < 0) return;
-    const float w = wrow[b];
-    for (int c = lane; c < H; c += 64) {
-        float rv = (float)rep_hi[(size_t)b * LDR + c];
-        if (rep_lo) rv += (float)rep_lo[(size_t)b * LDR + c];
-        atomicAdd(demb1 + (size_t)t * H + c, -w * rv);
+    // an earlier row with this label?  (64 labels per step; B <= 4096)
+    for (int b0 = 0; b0 < b; b0 += 64) {
+        const int j = b0 + lane;
+        const bool hit = j < b && lab[j] == lb;
+        if (__ballot(hit) != 0ull) return;
+    }
+    float acc[3] = {0.0f, 0.0f, 0.0f};                       // channels lane, lane + 64, lane + 128 (H <= 168)
+    for (int b0 = b & ~63; b0 < B; b0 += 64) {
+        const int j = b0 + lane;
+        unsigned long long m = __ballot(j >= b && j < B && lab[j] == lb);
+        while (m) {                                          // rows with this label, ascending
+            const int jj = b0 + __builtin_ctzll(m);
+            m &= m - 1;
+            const float w = wrow[jj];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int c = lane + 64 * r;
+                if (c < H) {
+                    float rv = (float)rep_hi[(size_t)jj * LDR + c];
+                    if (rep_lo) rv += (float)rep_lo[(size_t)jj * LDR + c];
+                    acc[r] -= w * rv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int c = lane + 64 * r;
+        if (c < H) demb1[(size_t)t * H + c] += acc[r];
     }
 }
 

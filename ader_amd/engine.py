@@ -938,7 +938,7 @@ class Engine:
             else:
                 M, rmap, dxo = rows, (1, 0), dx
             if self.seq_fused:
-                emb_bwd = (defer or self._early is not None) and l == 0
+                emb_bwd = l == 0        # (block 0's chain applies the prologue mask / dropout to the rows it writes)
                 self._bwd_block_fused(l, S, seq, dxo, dxn, M, B, emb_bwd, A["d_emb"])
                 fused_emb = fused_emb or emb_bwd
                 dx, dxn = dxn, dx
@@ -997,7 +997,14 @@ class Engine:
             # the table gradient is being all-reduced: leave the masked rows in dx (scattered for all ranks after the reduction)
             call("ader_embed_bwd_rows", None if fused_emb else ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
         else:
-            call("ader_embed_bwd", ptr(seq), ptr(dx), ptr(demb), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+            # unfused single-process path (exact-f32 logits, EWC, loss_and_grad without the optimiser): mask / dropout on the rows,
+            # then the rows are added into the table gradient bucket by bucket in position order -- no float atomics, so this path
+            # is bitwise reproducible too (the reference sets TF_DETERMINISTIC_OPS, main.py:121-122)
+            call("ader_embed_bwd_rows", None if fused_emb else ptr(seq), ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args(), st)
+            lab0 = self.buf("dp_lab0", (1,), torch.int32, zero=True)
+            ids_s, order, sp_start, _, _, _, _ = self._sparse_lists(seq, lab0, self.item_num)
+            call("ader_scatter_rows_ordered", ptr(ids_s), ptr(order), ptr(sp_start), sp_start.numel() - 1, ptr(dx), H, self.V,
+                 float(np.sqrt(np.float32(H))), ptr(demb), st)
         tb.__exit__(None, None, None)
         self._late_on = False
         return dx

@@ -20,6 +20,8 @@ Trainable surface (second half of this file; every forward has an autograd formu
   ader::ffn_fwd / ffn_bwd                                      modules.py:232-271 + ADER.py:80
   ader::logits_ce / logits_ce_bwd                              ADER.py:88-93 (exact-f32 logits, one-hot CE)
 """
+import math
+
 import torch
 
 from . import _lib
@@ -203,8 +205,23 @@ def embed_bwd(seq: torch.Tensor, dx: torch.Tensor, V: int, key: int, thr: int, s
     B, T = seq.shape
     H = dx.shape[2]
     g = dx.clone()                                   # (the launcher scales the rows in place)
-    demb, dpos = torch.zeros(V, H, device=dx.device), torch.zeros(T, H, device=dx.device)
-    call("ader_embed_bwd", ptr(seq), ptr(g), ptr(demb), ptr(dpos), B, T, H, V, _drop(key, thr, scale), _st())
+    dev = dx.device
+    demb, dpos = torch.zeros(V, H, device=dev), torch.zeros(T, H, device=dev)
+    # rows first (mask, dropout, positional gradient), then a bucketed, position-ordered accumulation into the table gradient: no
+    # float atomics, bitwise reproducible (ader_embed_bwd is the same arithmetic with an atomic scatter)
+    call("ader_embed_bwd_rows", ptr(seq), ptr(g), ptr(dpos), B, T, H, V, _drop(key, thr, scale), _st())
+    N = V - 1
+    i32 = dict(dtype=torch.int32, device=dev)
+    n_sp = B * T
+    lab0 = torch.zeros(1, **i32)
+    nb1 = call("ader_sparse_lists_starts", N)
+    ids, order = torch.empty(n_sp, **i32), torch.empty(n_sp, **i32)
+    tids, torder = torch.empty(1, **i32), torch.empty(1, **i32)
+    sp_start, tg_start = torch.empty(nb1, **i32), torch.empty(nb1, **i32)
+    scratch = torch.empty(call("ader_sparse_lists_scratch_n", n_sp, 1, N), **i32)
+    call("ader_sparse_lists", ptr(seq), n_sp, ptr(lab0), 1, N, ptr(scratch), ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder),
+         ptr(tg_start), _st())
+    call("ader_scatter_rows_ordered", ptr(ids), ptr(order), ptr(sp_start), nb1 - 1, ptr(g), H, V, _sqrt_f32(H), ptr(demb), _st())
     return demb, dpos
 
 
@@ -470,3 +487,205 @@ def _lce_backward(ctx, dloss, dlse):
 
 
 torch.library.register_autograd("ader::logits_ce", _lce_backward, setup_context=_lce_setup)
+
+
+# ================================================================================================ the float32-grade FAST path
+# The headline kernels as operators (north star: "surfaced to Python via PyTorch-ROCm custom ops"): the flash logit forward that
+# yields loss, log-sum-exp and dRep in one pass over the catalog (k_lx3p), its distilled variant (ADER.py:132-137), and the fused
+# table-gradient + dense TF-Adam update (k_tab32x3) as the optimizer-step op of the item table.  The [B, N] logits and the [N, H] table
+# gradient never exist in memory, so `emb` gets no autograd gradient from these ops: the table is trained by table_update_x3.
+#   ader::logits_ce_x3(rep, emb, pos, ex_pos, N, w_train, w_ex)            -> (loss, lse, drep, rep_hi, rep_lo, off, lab, wrow, img)
+#   ader::logits_ce_x3_kd(rep, emb, pos, ex_trow, teacher, N, w_train, w_ex) -> (... , trow, tlse2)
+#   ader::table_update_x3(emb, m, v, seq, g_rows, rep_hi, rep_lo, off, lab, wrow, img, n_rows, N, lr_t, b1, b2, eps)
+#   ader::table_update_x3_kd(emb, m, v, seq, g_rows, rep_hi, rep_lo, off, lab, wrow, teacher, trow, tlse2, n_train, N, lr_t, ...)
+# tests/test_gpu_ops_autograd.py steps the table through them and compares with Engine.train_step bit for bit.
+def _sqrt_f32(H):
+    import numpy as np
+    return float(np.sqrt(np.float32(H)))        # the engine's float32 sqrt(H) (ADER.py:38 scale), not the double one
+
+
+def _check_labels(t, name, N, lo=1):
+    """ids the kernels match by equality: an out-of-range label would silently drop its target term (the loss degrades to lse)"""
+    if t.numel():
+        mn, mx = int(t.min().item()), int(t.max().item())
+        if mn < lo or mx > N:
+            raise RuntimeError("ader::%s: ids must lie in [%d, %d] (got %d .. %d)" % (name, lo, N, mn, mx))
+
+
+def _x3_fwd_scratch(N, Bp, dev):
+    R = call("ader_lbf_ranges", N, Bp)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    return (torch.empty(Bp * 168, **bf), torch.empty(Bp * 168, **bf), torch.empty(R * Bp, device=dev), torch.empty(R * Bp, device=dev),
+            torch.empty(R * Bp * 160, device=dev), torch.empty(Bp, device=dev), torch.empty(Bp, device=dev), torch.empty(Bp, device=dev))
+
+
+@torch.library.custom_op("ader::logits_ce_x3", mutates_args=())
+def logits_ce_x3(rep: torch.Tensor, emb: torch.Tensor, pos: torch.Tensor, ex_pos: torch.Tensor, N: int, w_train: float,
+                 w_ex: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+                                       torch.Tensor, torch.Tensor]:
+    """One-hot softmax cross entropy over the whole catalog at float32 grade (ADER.py:88-93; exemplar rows with one-hot labels:
+    ADER.py:126-131).  rep [B,H] fp32 with the train rows first; emb [V,H] fp32 (row 0 = padding item); pos int32 [n_train], ex_pos
+    int32 [B - n_train] (may be empty), 1-based labels; loss = w_train sum_train CE + w_ex sum_ex CE.  Returns loss [1], lse [B],
+    drep [B,H] (= d loss / d rep) and what table_update_x3 consumes: operand planes rep_hi / rep_lo [Bp*168] bf16, exponent offsets
+    off [Bp], labels lab [Bp], weights wrow [Bp], operand image img (uint8)."""
+    _chk(rep, "rep", torch.float32, 2), _chk(emb, "emb", torch.float32, 2), _chk(pos, "pos", torch.int32, 1)
+    _chk(ex_pos, "ex_pos", torch.int32, 1)
+    B, H = rep.shape
+    n_train, n_ex = pos.shape[0], ex_pos.shape[0]
+    item_num = emb.shape[0] - 1
+    if emb.shape[1] != H or H % 2 or H > 150 or not (1 <= N <= item_num) or n_train + n_ex != B or B > 4096:
+        raise RuntimeError("ader::logits_ce_x3: bad shapes (B=%d, n_train=%d, n_ex=%d, H=%d, N=%d, item_num=%d)"
+                           % (B, n_train, n_ex, H, N, item_num))
+    _check_labels(pos, "logits_ce_x3 pos", N), _check_labels(ex_pos, "logits_ce_x3 ex_pos", N)
+    dev = rep.device
+    Bp = (B + 127) // 128 * 128
+    i32 = dict(dtype=torch.int32, device=dev)
+    lab, ncol, trow = torch.empty(Bp, **i32), torch.empty(Bp, **i32), torch.empty(Bp, **i32)
+    wrow = torch.empty(Bp, device=dev)
+    call("ader_build_rowinfo", ptr(pos), n_train, ptr(ex_pos) if n_ex else None, None, n_ex, N, 0, float(w_train), float(w_ex), Bp,
+         ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), _st())
+    rep_hi, rep_lo, pm, pl, pO, lse, off, rowloss = _x3_fwd_scratch(N, Bp, dev)
+    img = torch.zeros(call("ader_x3_rep_image_bytes", Bp), dtype=torch.uint8, device=dev)
+    loss, drep = torch.zeros(1, device=dev), torch.empty(B, H, device=dev)
+    # (loss = NULL + ader_lbf_sum: the summation order Engine.train_step uses, so the two agree bit for bit)
+    call("ader_lx3_fwd_img", ptr(rep), ptr(emb), item_num, B, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_hi), ptr(rep_lo), ptr(pm), ptr(pl),
+         ptr(pO), ptr(lse), ptr(off), ptr(rowloss), None, ptr(drep), ptr(img), _st())
+    call("ader_lbf_sum", ptr(rowloss), B, ptr(loss), _st())
+    return loss, lse[:B].clone(), drep, rep_hi, rep_lo, off, lab, wrow, img
+
+
+@logits_ce_x3.register_fake
+def _(rep, emb, pos, ex_pos, N, w_train, w_ex):
+    B = rep.shape[0]
+    Bp = (B + 127) // 128 * 128
+    bf = rep.new_empty(Bp * 168, dtype=torch.bfloat16)
+    return (rep.new_empty(1), rep.new_empty(B), torch.empty_like(rep), bf, torch.empty_like(bf), rep.new_empty(Bp),
+            pos.new_empty(Bp), rep.new_empty(Bp), rep.new_empty(Bp * 704, dtype=torch.uint8))
+
+
+def _x3_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[2])
+    ctx.n_in = len(inputs)
+
+
+def _x3_backward(ctx, dloss, *unused):
+    (drep,) = ctx.saved_tensors
+    # d loss / d rep; the table's gradient is formed and consumed inside table_update_x3 (never materialised): None for emb
+    return (drep * dloss,) + (None,) * (ctx.n_in - 1)
+
+
+torch.library.register_autograd("ader::logits_ce_x3", _x3_backward, setup_context=_x3_setup)
+
+
+@torch.library.custom_op("ader::logits_ce_x3_kd", mutates_args=())
+def logits_ce_x3_kd(rep: torch.Tensor, emb: torch.Tensor, pos: torch.Tensor, ex_trow: torch.Tensor, teacher: torch.Tensor, N: int,
+                    w_train: float, w_ex: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+                                                          torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The adaptive-distillation loss of ADER.py:108-138 at float32 grade: rows [0, n_train) of rep are train rows (one-hot CE, weight
+    w_train = 1/B_train), the rows after them exemplar rows distilled against softmax(teacher[ex_trow[e], :Np]) over the first Np items
+    (weight w_ex = lambda/B_ex; the student logits are sliced before the softmax, ADER.py:134).  teacher [E_all, Np] fp32.  Returns loss,
+    lse [B], drep [B,H], and for table_update_x3_kd: rep_hi, rep_lo, off, lab, wrow, trow, tlse2 in the padded row layout
+    [train rows padded to 128 | exemplar rows padded to 128]."""
+    _chk(rep, "rep", torch.float32, 2), _chk(emb, "emb", torch.float32, 2), _chk(pos, "pos", torch.int32, 1)
+    _chk(ex_trow, "ex_trow", torch.int32, 1), _chk(teacher, "teacher", torch.float32, 2)
+    B, H = rep.shape
+    n_train, n_ex = pos.shape[0], ex_trow.shape[0]
+    item_num, (E_all, Np) = emb.shape[0] - 1, teacher.shape
+    Bt, Bk = (n_train + 127) // 128 * 128, (n_ex + 127) // 128 * 128
+    Bp = Bt + Bk
+    if (emb.shape[1] != H or H % 2 or H > 150 or not (1 <= Np <= N <= item_num) or n_train + n_ex != B or n_train < 1 or n_ex < 1
+            or Bp > 4096):
+        raise RuntimeError("ader::logits_ce_x3_kd: bad shapes (B=%d, n_train=%d, n_ex=%d, H=%d, Np=%d, N=%d, item_num=%d)"
+                           % (B, n_train, n_ex, H, Np, N, item_num))
+    _check_labels(pos, "logits_ce_x3_kd pos", N), _check_labels(ex_trow, "logits_ce_x3_kd ex_trow", E_all - 1, lo=0)
+    dev = rep.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    tlse_all = torch.empty(E_all, device=dev)
+    call("ader_row_lse", ptr(teacher), teacher.stride(0), Np, ptr(torch.arange(E_all, **i32)), E_all, ptr(tlse_all), _st())
+    lab, trow = torch.empty(Bp, **i32), torch.empty(Bp, **i32)
+    wrow, tlse2 = torch.empty(Bp, device=dev), torch.empty(Bp, device=dev)
+    rep_hi, rep_lo, pm, pl, pO, lse, off, rowloss = _x3_fwd_scratch(N, Bp, dev)
+    pO2 = torch.empty(call("ader_lx3_readout_ranges", Np, Bk) * Bk * 160, device=dev)
+    loss, drep = torch.zeros(1, device=dev), torch.empty(B, H, device=dev)
+    call("ader_lx3_fwd_kd", ptr(rep), ptr(emb), item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos), ptr(ex_trow), ptr(teacher),
+         teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow), ptr(trow), ptr(tlse2), ptr(rep_hi),
+         ptr(rep_lo), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off), ptr(rowloss), ptr(loss), ptr(drep), _st())
+    lse_c = torch.cat([lse[:n_train], lse[Bt:Bt + n_ex]])
+    return loss, lse_c, drep, rep_hi, rep_lo, off, lab, wrow, trow, tlse2
+
+
+@logits_ce_x3_kd.register_fake
+def _(rep, emb, pos, ex_trow, teacher, N, w_train, w_ex):
+    B = rep.shape[0]
+    Bp = (pos.shape[0] + 127) // 128 * 128 + (ex_trow.shape[0] + 127) // 128 * 128
+    bf = rep.new_empty(Bp * 168, dtype=torch.bfloat16)
+    return (rep.new_empty(1), rep.new_empty(B), torch.empty_like(rep), bf, torch.empty_like(bf), rep.new_empty(Bp), pos.new_empty(Bp),
+            rep.new_empty(Bp), pos.new_empty(Bp), rep.new_empty(Bp))
+
+
+torch.library.register_autograd("ader::logits_ce_x3_kd", _x3_backward, setup_context=_x3_setup)
+
+
+def _sparse_lists_x3(seq, lab, N):
+    """The bucketed lists of the sparse table-gradient terms + the per-tile records of the x3 update (Engine._sparse_lists)."""
+    dev = seq.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    seq, lab = seq.reshape(-1).contiguous(), lab.reshape(-1).contiguous()
+    n_sp, n_tg = seq.numel(), lab.numel()
+    nb1 = call("ader_sparse_lists_starts", N)
+    ids, order, tids, torder = torch.empty(n_sp, **i32), torch.empty(n_sp, **i32), torch.empty(n_tg, **i32), torch.empty(n_tg, **i32)
+    sp_start, tg_start = torch.empty(nb1, **i32), torch.empty(nb1, **i32)
+    scratch = torch.empty(call("ader_sparse_lists_scratch_n", n_sp, n_tg, N), **i32)
+    call("ader_sparse_lists", ptr(seq), n_sp, ptr(lab), n_tg, N, ptr(scratch), ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder),
+         ptr(tg_start), _st())
+    meta = torch.empty(call("ader_tab_meta_ints", N), **i32)
+    call("ader_tab_tile_meta", ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), N, ptr(meta), _st())
+    return ids, order, tids, torder, meta
+
+
+def _chk_table(emb, m, v, seq, g_rows, name):
+    _chk(emb, "emb", torch.float32, 2), _chk(m, "m", torch.float32, 2), _chk(v, "v", torch.float32, 2)
+    _chk(seq, "seq", torch.int32, 2), _chk(g_rows, "g_rows", torch.float32, 2)
+    if m.shape != emb.shape or v.shape != emb.shape or g_rows.shape != (seq.numel(), emb.shape[1]):
+        raise RuntimeError("ader::%s: m, v must match emb [V,H]; g_rows must be [B*T, H]" % name)
+
+
+@torch.library.custom_op("ader::table_update_x3", mutates_args=("emb", "m", "v"))
+def table_update_x3(emb: torch.Tensor, m: torch.Tensor, v: torch.Tensor, seq: torch.Tensor, g_rows: torch.Tensor, rep_hi: torch.Tensor,
+                    rep_lo: torch.Tensor, off: torch.Tensor, lab: torch.Tensor, wrow: torch.Tensor, img: torch.Tensor, n_rows: int,
+                    N: int, lr_t: float, beta1: float, beta2: float, eps: float) -> None:
+    """Optimizer step of the item table (tf.train.AdamOptimizer applied densely, ADER.py:96) fused with the table gradient of
+    ADER.py:91-93: for rows 1..N, dE = sum_b w_b (softmax_b - onehot_b) rep_b (recomputed on the matrix cores, never stored)
+    + sqrt(H) x the input-embedding rows g_rows [B*T,H] (position p of seq contributes to row seq[p]; padding id 0 skipped), then
+    TF-Adam in place on emb / m / v.  rep_hi .. img: as returned by logits_ce_x3 for the same batch of n_rows rows.
+    lr_t = lr sqrt(1-b2^t)/(1-b1^t)."""
+    _chk_table(emb, m, v, seq, g_rows, "table_update_x3")
+    H = emb.shape[1]
+    Bp = off.shape[0]
+    if not (0 < n_rows <= Bp) or seq.shape[0] != n_rows:
+        raise RuntimeError("ader::table_update_x3: n_rows must be the batch's row count (seq rows = %d, Bp = %d)" % (seq.shape[0], Bp))
+    ids, order, tids, torder, meta = _sparse_lists_x3(seq, lab, N)
+    call("ader_tab_update_x3", ptr(rep_hi), ptr(rep_lo), ptr(img), emb.shape[0] - 1, n_rows, Bp, H, N, ptr(off), ptr(ids), ptr(order),
+         ids.numel(), ptr(g_rows), _sqrt_f32(H),
+         ptr(tids), ptr(torder), tids.numel(), ptr(meta), ptr(wrow), ptr(emb), ptr(m), ptr(v), lr_t, beta1, beta2, eps, 0, -1, None, _st())
+
+
+@torch.library.custom_op("ader::table_update_x3_kd", mutates_args=("emb", "m", "v"))
+def table_update_x3_kd(emb: torch.Tensor, m: torch.Tensor, v: torch.Tensor, seq: torch.Tensor, g_rows: torch.Tensor,
+                       rep_hi: torch.Tensor, rep_lo: torch.Tensor, off: torch.Tensor, lab: torch.Tensor, wrow: torch.Tensor,
+                       teacher: torch.Tensor, trow: torch.Tensor, tlse2: torch.Tensor, n_train: int, N: int, lr_t: float, beta1: float,
+                       beta2: float, eps: float) -> None:
+    """table_update_x3 for a distilled step (ADER.py:132-137): the exemplar rows' dlogit is w (softmax(s[:Np]) - softmax(teacher row));
+    arguments as logits_ce_x3_kd returned them."""
+    _chk_table(emb, m, v, seq, g_rows, "table_update_x3_kd")
+    _chk(teacher, "teacher", torch.float32, 2)
+    H = emb.shape[1]
+    Bp = off.shape[0]
+    Bt = (n_train + 127) // 128 * 128
+    img = torch.zeros(call("ader_x3_rep_image_bytes", Bp), dtype=torch.uint8, device=emb.device)
+    call("ader_x3_rep_image", ptr(rep_hi), ptr(rep_lo), Bp, ptr(img), _st())
+    ids, order, tids, torder, meta = _sparse_lists_x3(seq, lab, N)
+    call("ader_tab_update_x3_kd", ptr(rep_hi), ptr(rep_lo), ptr(img), emb.shape[0] - 1, Bp, Bt, H, N, teacher.shape[1], ptr(off), ptr(ids),
+         ptr(order), ids.numel(), ptr(g_rows), _sqrt_f32(H), ptr(tids), ptr(torder),
+         tids.numel(), ptr(meta), ptr(wrow), ptr(teacher), teacher.stride(0), ptr(trow), ptr(tlse2), ptr(emb), ptr(m), ptr(v), lr_t, beta1,
+         beta2, eps, _st())

@@ -119,25 +119,23 @@ def test_diginetica_ader_float32_grade_inside_the_poster_band():
 # README.md:88-93), float32 grade.  Every column is one flag set of the reference's command line.
 #   * ADER-equal / ADER-fix (distillation on): must land within +- 0.5 point of the published Recall@20 and MRR@20 (measured round 3:
 #     50.11 / 17.35 and 50.10 / 17.37 against 49.92 / 17.23 and 50.09 / 17.29).
-#   * ER-herding / ER-random (--disable_distillation: one-hot replay, ADER.py:126-131).  The poster does not state the base weight of
-#     its ER runs.  With main.py's default --lambda_ 0.8 this build lands 1 point BELOW the poster (48.33 / 16.53 and 48.19 / 16.40
-#     against 49.44 / 16.95 and 49.14 / 16.79) -- and so do the exact-f32 kernels (48.29), while the one-hot exemplar loss and
-#     gradients match the CPU restatement of ADER.py:108-131 at the op level (test_gpu_parity: mode "onehot_ex").  A scan of the base
-#     weight (profiles/e2e_r3/er_lambda_scan.txt) explains the gap: lambda_ 0.1 / 0.2 / 0.3 / 0.4 / 0.6 / 0.8 -> Recall@20 49.16 /
-#     49.23 / 49.01 / 48.94 / 48.70 / 48.33 (--fix_lambda, i.e. a constant 0.8: 47.39) -- one-hot replay wants a smaller weight than
-#     distillation, and at --lambda_ 0.2 ALL FOUR published metrics of both columns are met within 0.25 point (ER-herding 49.23 /
-#     16.90 / 36.77 / 16.04 against 49.44 / 16.95 / 36.88 / 16.08; ER-random 49.20 / 16.91 / 36.67 / 16.05 against 49.14 / 16.79 /
-#     36.61 / 15.92).  The ER-herding column is therefore asserted at --lambda_ 0.2, +- 0.5 point like the others (ER-random: measured, not in the suite).
+#   * ER-herding / ER-random / ER-loss (--disable_distillation: one-hot replay, ADER.py:126-131) are asserted AT THE REFERENCE'S DOCUMENTED
+#     COMMAND LINES (README.md:88-90: no --lambda_, i.e. main.py's default base weight 0.8) as a CHARACTERISED DEVIATION: this build lands
+#     1.1-1.5 points of Recall@20 BELOW the poster there (round 4, float32 grade: ER-herding 47.94 / 16.28, ER-random 48.04 / 16.33,
+#     ER-loss 47.93 / 16.24 against 49.44 / 16.95, 49.14 / 16.79, 49.31 / 16.90; the exact-f32 kernels give the same: 48.29) while the
+#     one-hot exemplar loss and its gradients match the CPU restatement of ADER.py:108-131 at the op level (test_gpu_parity: mode
+#     "onehot_ex") and the distilled columns of the same table are met within 0.2.  NOT reproduced at the documented flags -- the test
+#     pins this build's own values (+- 0.5) and bounds the gap, so that neither a regression nor a silent "fix by tuning" goes unnoticed.
+#     For information only (not asserted; profiles/e2e_r3/er_lambda_scan.txt): a scan of the base weight gives lambda_ 0.1 / 0.2 / 0.3 /
+#     0.4 / 0.6 / 0.8 -> Recall@20 49.16 / 49.23 / 49.01 / 48.94 / 48.70 / 48.33, i.e. at --lambda_ 0.2 the poster's ER numbers would be
+#     met within 0.25 point -- a fitted value, which the README's command lines do not carry.
 #   * ER-loss: the reference's `loss` selector ranks a 0-d scalar (util.py:482-488: `model.loss` is the batch mean), so what its code
 #     EXECUTES is "keep the first candidate of every label with a quota": `--selection loss_ref` reproduces that exemplar set (this
-#     build's `--selection loss` ranks by the per-row loss the method documents).  At --lambda_ 0.2: 49.24 / 16.92 / 36.64 / 16.05 with
-#     bf16 logit operands and 49.13-49.18 / 16.89-16.91 on the exact-f32 kernels against the poster's 49.31 / 16.90 / 36.65 / 16.02.
-#     With a third of the others' exemplars (one session per label) this column's 16-period average moves with the arithmetic path
-#     through the early-stopping decisions (float32 grade, same flags: 48.71).  It is asserted on the bf16 path: that run and the
-#     float32-grade one are bitwise reproducible, the exact-f32 kernels' atomic scatter is not (49.13 and 49.18 in two runs).
+#     build's `--selection loss` ranks by the per-row loss the method documents).
 POSTER = [
-    ("ER-herding", ["--disable_distillation", "True", "--lambda_", "0.2"], 49.44, 16.95, None),
-    ("ER-loss", ["--disable_distillation", "True", "--selection", "loss_ref", "--lambda_", "0.2", "--logits_dtype", "bf16"], 49.31, 16.90, None),
+    ("ER-herding", ["--disable_distillation", "True"], 49.44, 16.95, (47.94, 16.28)),
+    ("ER-random", ["--disable_distillation", "True", "--selection", "random"], 49.14, 16.79, (48.04, 16.33)),
+    ("ER-loss", ["--disable_distillation", "True", "--selection", "loss_ref"], 49.31, 16.90, (47.93, 16.24)),
     ("ADER-equal", ["--equal_exemplar", "True"], 49.92, 17.23, None),
     ("ADER-fix", ["--fix_lambda", "True"], 50.09, 17.29, None),
 ]
@@ -156,7 +154,7 @@ def test_diginetica_poster_columns_float32_grade(name, flags, r20_ref, m20_ref, 
         assert abs(m20 - m20_ref) <= 0.5, (name, "MRR@20", m20, m20_ref)
     else:       # characterised deviation from the poster (see above): regression pin of this build, and a bound on the gap
         assert abs(r20 - own[0]) <= 0.5 and abs(m20 - own[1]) <= 0.5, (name, r20, m20, own)
-        assert abs(r20 - r20_ref) <= 1.6 and abs(m20 - m20_ref) <= 0.9, (name, "gap to the poster grew", r20, m20)
+        assert abs(r20 - r20_ref) <= 2.0 and abs(m20 - m20_ref) <= 1.1, (name, "gap to the poster grew", r20, m20)
 
 
 def test_diginetica_one_attention_block_named_variant():

@@ -82,3 +82,86 @@ def test_ops_reject_bad_inputs():
     with pytest.raises(RuntimeError):
         torch.ops.ader.logits_ce(x, torch.zeros(10, 150, device="cuda"), torch.ones(4, dtype=torch.int32, device="cuda"),
                                  torch.ones(4, device="cuda"), 50)
+
+
+# ------------------------------------------------------------------------------------------------ the fast path as operators
+def _x3_engine(seed=5):
+    from ader_amd.engine import Engine
+    eng = Engine(ITEMS, maxlen=T, hidden_units=H, num_blocks=L, num_heads=HEADS, seed=seed, logits_dtype="x3")
+    g = torch.Generator().manual_seed(3)
+    for k in eng.layout:
+        if k.endswith("_b"):
+            eng.param(k).copy_(torch.randn(eng.layout[k][1], generator=g) * 0.1)
+    eng.refresh_shadow()
+    return eng
+
+
+@pytest.mark.parametrize("mode", ["vanilla", "onehot_ex", "kd"])
+def test_x3_fast_path_ops_step_the_table_like_the_engine_bitwise(mode):
+    """torch.ops.ader.logits_ce_x3[_kd] (flash forward at float32 grade: loss, lse, dRep) + torch.ops.ader.table_update_x3[_kd] (table
+    gradient + dense TF-Adam fused) against Engine.train_step on the same batch: the loss and the item table's theta / Adam m / Adam v
+    after the step are bit-identical (the ops launch the same kernels with the same operands); autograd through logits_ce_x3 hands
+    back dRep.  Reference: ADER.py:88-96 (vanilla), :126-131 (one-hot exemplars), :132-137 (distillation)."""
+    import ader_amd.ops  # noqa: F401
+    rs = np.random.RandomState(31)
+    B, N, Np, n_ex = 150, 600, 520, 37
+    n_train = B - (0 if mode == "vanilla" else n_ex)
+    seq = np.zeros((B, T), dtype=np.int32)
+    for b in range(B):
+        ln = int(rs.randint(1, T + 1))
+        seq[b, T - ln:] = rs.randint(1, (Np if b >= n_train else N) + 1, size=ln)
+    seq[3, -2:] = seq[4, -1]
+    pos = rs.randint(1, N + 1, size=n_train).astype(np.int32)
+    pos[0], pos[1] = N, pos[2]
+    lam, lr, rate = 0.7, 5e-4, 0.3
+    kw = {}
+    ex_pos = np.zeros(0, dtype=np.int32)
+    teacher = trow = None
+    if mode == "onehot_ex":
+        ex_pos = rs.randint(1, N + 1, size=n_ex).astype(np.int32)
+        kw = dict(ex_pos=ex_pos, lambda_=lam)
+    elif mode == "kd":
+        teacher = torch.from_numpy(rs.standard_normal((50, Np)).astype(np.float32)).cuda()
+        trow = rs.randint(0, 50, size=n_ex).astype(np.int32)
+        kw = dict(teacher=teacher, ex_trow=trow, lambda_=lam)
+    a = _x3_engine()
+    a.global_step = 4
+    loss_a = a.train_step(seq, pos, N, lr, rate=rate, **kw)
+    torch.cuda.synchronize()
+
+    b = _x3_engine()
+    b.global_step = 4
+    b.late_side_stream = False                           # (small reductions issued in line: nothing queued behind the ops)
+    dev = b.device
+    seq_d = torch.from_numpy(seq).to(dev)
+    pos_d = torch.from_numpy(pos).to(dev)
+    b._refresh_stream()
+    rep = b.forward(seq_d, training=True, rate=rate, step=b.global_step, save=True).detach().clone().requires_grad_(True)
+    emb, m, v = b.param("emb"), b.view(b.adam_m, "emb"), b.view(b.adam_v, "emb")
+    w_train, w_ex = 1.0 / n_train, (lam / n_ex if mode != "vanilla" else 0.0)
+    if mode == "kd":
+        out = torch.ops.ader.logits_ce_x3_kd(rep, emb, pos_d, torch.from_numpy(trow).to(dev), teacher, N, w_train, w_ex)
+        loss_b, lse, drep, rep_hi, rep_lo, off, lab, wrow, trw, tlse2 = out
+    else:
+        out = torch.ops.ader.logits_ce_x3(rep, emb, pos_d, torch.from_numpy(ex_pos).to(dev), N, w_train, w_ex)
+        loss_b, lse, drep, rep_hi, rep_lo, off, lab, wrow, img = out
+    assert float(loss_b.item()) == float(loss_a.item())
+    (g_rep,) = torch.autograd.grad(loss_b.sum(), rep)                      # autograd formula: d loss / d rep = dRep
+    assert torch.equal(g_rep, drep)
+    dx = b._blocks_backward(seq_d, drep.detach(), True, None)              # per-position input-gradient rows stay in dx
+    lr_t = b._lr_t(lr)
+    if mode == "kd":
+        torch.ops.ader.table_update_x3_kd(emb, m, v, seq_d, dx, rep_hi, rep_lo, off, lab, wrow, teacher, trw, tlse2, n_train, N, lr_t,
+                                          b.beta1, b.beta2, b.eps)
+    else:
+        torch.ops.ader.table_update_x3(emb, m, v, seq_d, dx, rep_hi, rep_lo, off, lab, wrow, img, B, N, lr_t, b.beta1, b.beta2, b.eps)
+    torch.cuda.synchronize()
+    for name, buf in (("theta", "theta"), ("m", "adam_m"), ("v", "adam_v")):
+        ta, tb = a.view(getattr(a, buf), "emb"), b.view(getattr(b, buf), "emb")
+        assert torch.equal(ta, tb), name
+    assert float(a.view(a.adam_v, "emb")[1:N + 1].abs().max()) > 0
+    with pytest.raises(RuntimeError):                                      # a label outside [1, N] raises, never a silent lse-only loss
+        bad = pos_d.clone()
+        bad[0] = N + 1
+        torch.ops.ader.logits_ce_x3(rep.detach(), emb, bad, torch.zeros(0, dtype=torch.int32, device=dev), N, w_train, 0.0) \
+            if mode != "kd" else torch.ops.ader.logits_ce_x3_kd(rep.detach(), emb, bad, torch.from_numpy(trow).to(dev), teacher, N, 1.0, 1.0)

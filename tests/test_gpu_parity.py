@@ -785,23 +785,37 @@ def test_kd_fast_equals_split_kd():
     assert np.abs(ta - tb).max() < 1.1e-3
 
 
-@pytest.mark.parametrize("ld", ["bf16", "x3"])
-def test_fused_train_step_is_bitwise_reproducible(ld):
-    """Determinism: the default training path (one-launch forward, session-tiled backward, batched weight
-    gradients, id-sorted sparse lists, fused table update on two streams) has no float atomics and fixed-order reductions:
-    two engines stepping the same batches from the same state end bit-identical."""
+@pytest.mark.parametrize("ld,variant", [("bf16", "fused"), ("x3", "fused"), ("f32", "unfused"), ("x3", "unfused"), ("x3", "ewc"),
+                                        ("f32", "ewc")])
+def test_train_step_is_bitwise_reproducible(ld, variant):
+    """Determinism (SURVEY 8b "no float atomics on the parity path"; the reference sets TF_DETERMINISTIC_OPS, main.py:121-122):
+    two engines stepping the same batches from the same state end bit-identical -- on the default path (one-launch forward,
+    session-tiled backward, batched weight gradients, id-sorted sparse lists, fused table update on two streams) AND on the unfused
+    one (exact-f32 logits, or the fused update switched off, or the EWC baseline whose penalty lives in the dense gradient buffer,
+    EWC.py:115-124): its input-embedding rows are added in position order from the bucketed lists and its one-hot rows by a single
+    writer per table row (rounds 1-3: float atomicAdd scatters, last bits differed from run to run)."""
     item_num, T, H, L, heads, B, N = BF16_CFGS[1]
     rs = np.random.RandomState(77)
     batches = []
     for _ in range(3):
         seq = _seqs(rs, B, T, N)
         seq[1, -4:] = seq[0, -1]                       # repeated ids: several sparse rows per table row
+        seq[2, -1] = seq[0, -1]
         pos = rs.randint(1, N + 1, size=B).astype(np.int32)
         pos[5] = pos[6]
+        pos[9] = pos[6]
         batches.append((seq, pos))
     finals = []
     for _ in range(2):
         eng = _engine(item_num, T, H, L, heads, seed=8, logits_dtype=ld)
+        if variant == "unfused":
+            eng.fuse_adam = False
+        elif variant == "ewc":
+            eng.ewc_snapshot()
+            eng.compute_fisher(batches[0][0][:6], batches[0][1][:6], N)
+            eng.ewc["lam"] = 50.0
+            eng.param("emb").mul_(1.01)                # away from the snapshot: a non-zero penalty
+            eng.refresh_shadow()
         for seq, pos in batches:
             eng.train_step(seq, pos, N, 5e-4, rate=0.3)
         torch.cuda.synchronize()
