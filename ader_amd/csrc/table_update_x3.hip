@@ -852,16 +852,28 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
 }
 
 // ============================================================================================= launch (C ABI: table_update.hip)
+// Timing-only knobs of the diagnostic builds (tools/build_variant.sh ... -DADER_DIAG): knock-outs, staggers, an LDS pad and the
+// one-tile kernel.  A production build reads NO environment variable here: a stray one must not be able to corrupt a training run.
 static size_t tab16x3_lds(int Bp, int Bk) {
-    static int pad = -1;                  // ADER_X3_LDSPAD: extra bytes (timing experiments: fewer workgroups per CU)
-    if (pad < 0) { const char* e = getenv("ADER_X3_LDSPAD"); pad = e ? atoi(e) : 0; }
+    int pad = 0;
+#ifdef ADER_DIAG
+    { static int pad_ = -1; if (pad_ < 0) { const char* e = getenv("ADER_X3_LDSPAD"); pad_ = e ? atoi(e) : 0; } pad = pad_; }
+#endif
     return (size_t)2 * X3_IMG_B + (size_t)Bp * sizeof(float) + 4 * TM_LIST * sizeof(int) + (size_t)Bk * 8 + pad;
 }
-static bool tab_pairs() {                 // ADER_X3_TILE=64: k_tab16x3 (one 64-row tile per workgroup, three per CU) instead of k_tab32x3
+static bool tab_pairs() {                 // (ADER_DIAG, ADER_X3_TILE=64: k_tab16x3 -- one 64-row tile per workgroup -- instead of k_tab32x3)
+#ifdef ADER_DIAG
     static int v = -1;
     if (v < 0) { const char* e = getenv("ADER_X3_TILE"); v = (e && atoi(e) == 64) ? 0 : 1; }
     return v == 1;
+#else
+    return true;
+#endif
 }
+
+// table_update_x3p.hip: the pipelined kernel (large catalogs); 1 = launched, 0 = shape not covered, otherwise an error
+int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st);
+static int g_x3_pipelined = 1;            // ader_x3_update_pipelined()
 
 template <bool EXTRA, bool KD>
 static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
@@ -887,11 +899,19 @@ static int tab32x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, siz
 }
 
 static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, bool kd, void* stream) {
+    a.ko = 0;
+#ifdef ADER_DIAG
     { static int ko = -1; if (ko < 0) { const char* e = getenv("ADER_X3_KO"); ko = e ? atoi(e) : 0; const char* s_ = getenv("ADER_X3_STAGGER"); ko |= (s_ ? atoi(s_) : 0) << 16; } a.ko = ko; }
+#endif
     if (a.Bp % X3_CH != 0 || (kd && a.kd_row0 % X3_CH != 0) || !a.rep_img || ((uintptr_t)a.rep_img & 15)) return -2;
     const size_t lds = tab16x3_lds(a.Bp, kd ? a.Bp - a.kd_row0 : 0);
     hipStream_t st = (hipStream_t)stream;
     a.tile_end = a.tile_off + tiles;
+    if (g_x3_pipelined && !kd && !extra && !(a.ko & 0xff)) {
+        const int rc = tabp_try_launch(a, fa, tiles, st);
+        if (rc == 1) return 0;
+        if (rc != 0) return rc;
+    }
     if (tab_pairs() && (a.tile_off & 1) == 0 && !(a.ko & 0xff)) {
         if (kd) return tab32x3_launch_t<false, true>(a, fa, tiles, lds, st);
         if (extra) return tab32x3_launch_t<true, false>(a, fa, tiles, lds, st);
@@ -903,6 +923,15 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
 }
 
 extern "C" {
+
+// Kernel choice of ader_tab_update_x3 for large catalogs: 1 (default) = the pipelined kernel k_tabp where its shape conditions hold
+// (table_update_x3p.hip), 0 = always k_tab32x3; a negative argument only queries.  Returns the previous setting.  Both kernels give
+// bit-identical results (tests/test_gpu_parity.py); the switch exists for kernel-vs-kernel tests and A/B timing.
+int ader_x3_update_pipelined(int mode) {
+    const int prev = g_x3_pipelined;
+    if (mode >= 0) g_x3_pipelined = mode ? 1 : 0;
+    return prev;
+}
 
 // LDS image of the x3 operand rows for ader_tab_update_x3[_kd]: img = ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned, built from
 // the two planes rep_hi / rep_lo [Bp,168] that ader_lx3_prep / ader_lx3_fwd[_kd] leave (Bp % 32 == 0).

@@ -174,3 +174,42 @@ def test_x3_headline_kernels_against_float64_at_full_size(batch, n_items):
     if n_items < N:
         assert torch.equal(eng.param("emb")[n_items + 1:], E0[n_items + 1:])
         assert float(eng.view(eng.adam_v, "emb")[n_items + 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n_items,rows", [(N, B), (300_037, 384), (300_037, 1000)])
+def test_pipelined_update_kernel_is_bit_identical_to_k_tab32x3(n_items, rows):
+    """ader_tab_update_x3 runs the role-split pipelined kernel k_tabp on large catalogs (csrc/table_update_x3p.hip: persistent
+    workgroups, GEMM / loader / Adam waves) and k_tab32x3 otherwise: the same arithmetic in the same order, so theta, Adam m and Adam v
+    of the WHOLE table after two steps must be bit-identical between the two (ader_x3_update_pipelined switches).  Batches with a hot item
+    (a bucket of hundreds of sparse rows: the heavy path), repeated labels, left padding, a ragged tail tile, 384 / 512 / 1,000 rows."""
+    from ader_amd import _lib
+    from ader_amd.engine import Engine
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for s in range(2):
+        seq = torch.randint(1, n_items + 1, (rows, T), generator=g, dtype=torch.int32)
+        seq[:50, :30] = 0
+        seq[60:120, -3:] = 777                      # a hot item: ~180 sparse rows in one bucket
+        seq[7, -1] = n_items
+        pos = torch.randint(1, n_items + 1, (rows,), generator=g, dtype=torch.int32)
+        pos[3] = pos[4] = pos[5]
+        pos[0] = n_items
+        batches.append((seq.numpy(), pos.numpy()))
+    out = []
+    try:
+        for mode in (1, 0):
+            _lib.call("ader_x3_update_pipelined", mode)
+            eng = Engine(n_items + 50, maxlen=T, hidden_units=H, num_blocks=2, num_heads=1, seed=0, logits_dtype="x3")
+            for seq, pos in batches:
+                eng.train_step(seq, pos, n_items, 5e-4, rate=0.3)
+            torch.cuda.synchronize()
+            eng.check_status()
+            out.append([eng.view(getattr(eng, b), "emb").clone() for b in ("theta", "adam_m", "adam_v")] + [float(eng.loss.item())])
+            del eng
+            torch.cuda.empty_cache()
+    finally:
+        _lib.call("ader_x3_update_pipelined", 1)
+    for x, y, name in zip(out[0][:3], out[1][:3], ("theta", "m", "v")):
+        assert torch.equal(x, y), name
+    assert out[0][3] == out[1][3]
+    assert float(out[0][2][1:n_items + 1].abs().max()) > 0 and float(out[0][2][n_items + 1:].abs().max()) == 0.0
