@@ -189,10 +189,12 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     STAMP(1)
     // the first input-embedding gradient rows of the tile (thread c holds column c), requested now, used after the GEMM
     float spv[SPV];
+    // (every sparse-row product / sum below is kept as two rounded operations -- "#pragma clang fp contract(off)" -- so that the x3
+    //  update kernels, which share this arithmetic, agree bit for bit whatever hipcc would fuse in each of them)
 #pragma unroll
     for (int i = 0; i < SPV; ++i) {     // unconditional loads (row 0, column 0 when there is no entry): a load under a branch is waited
         const bool on = tid < H && meta_l[0] + i < meta_l[1];        // for at the end of its branch -- three round trips in a row
-        spv[i] = f.sp_src[on ? (size_t)meta_l[3 + 2 * i] * H + tid : 0] * (on ? f.sp_scale : 0.0f);
+        { _Pragma("clang fp contract(off)") spv[i] = f.sp_src[on ? (size_t)meta_l[3 + 2 * i] * H + tid : 0] * (on ? f.sp_scale : 0.0f); }
     }
     STAMP(2)
     STAMP(3)
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
     lds_only_barrier();
     STAMP(8)
     {
+    #pragma clang fp contract(off)
         // sparse terms of the tile: item ids [tile0+1, tile0+65).  Thread c owns column c of every row.
         const int id_lo = tile0 + 1, id_hi = min(tile0 + TI, N) + 1;
         if (heavy) {
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
             // entries in list order (the same order, hence the same rounding, as the light path)
 #define HEAVY_LIST(K0_, K1_, IDS_, ROWS_, VAL_, OP_)                                                       \
             for (int base_ = (K0_); base_ < (K1_); base_ += 256) {                                         \
+                _Pragma("clang fp contract(off)")                                                            \
                 const int n_ = min(256, (K1_) - base_);                                                    \
                 if (tid < n_) { hv_l[tid] = (IDS_)[base_ + tid]; hv_l[256 + tid] = (ROWS_)[base_ + tid]; } \
                 __syncthreads();                                                                           \
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
 #pragma unroll
         for (int i = 0; i < SPV; ++i) {
             const bool on = tid < H && ms[0] + i < ms[1];
-            spv[h][i] = f.sp_src[on ? (size_t)ms[3 + 2 * i] * H + tid : 0] * (on ? f.sp_scale : 0.0f);
+            { _Pragma("clang fp contract(off)") spv[h][i] = f.sp_src[on ? (size_t)ms[3 + 2 * i] * H + tid : 0] * (on ? f.sp_scale : 0.0f); }
         }
     }
     f32x4v dE[2][10];
@@ -728,11 +732,13 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
         lds_only_barrier();
         STAMP(8)
         {
+        #pragma clang fp contract(off)
             const int id_lo = tile0 + 1, id_hi = (tile < a.tile_end ? min(tile0 + TI, N) : tile0) + 1;
             if (heavy) {
                 int* hv_l = (int*)(smem_raw + TI * HP * sizeof(float));
 #define HEAVY_LIST(K0_, K1_, IDS_, ROWS_, VAL_, OP_)                                                       \
                 for (int base_ = (K0_); base_ < (K1_); base_ += 256) {                                     \
+                    _Pragma("clang fp contract(off)")                                                        \
                     const int n_ = min(256, (K1_) - base_);                                                \
                     if (tid < n_) { hv_l[tid] = (IDS_)[base_ + tid]; hv_l[256 + tid] = (ROWS_)[base_ + tid]; } \
                     __syncthreads();                                                                       \
@@ -873,7 +879,7 @@ static bool tab_pairs() {                 // (ADER_DIAG, ADER_X3_TILE=64: k_tab1
 
 // table_update_x3p.hip: the pipelined kernel (large catalogs); 1 = launched, 0 = shape not covered, otherwise an error
 int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st);
-static int g_x3_pipelined = 1;            // ader_x3_update_pipelined()
+static int g_x3_pipelined = 0;            // ader_x3_update_pipelined(): off by default -- see the measurements at the setter
 
 template <bool EXTRA, bool KD>
 static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
@@ -924,9 +930,12 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
 
 extern "C" {
 
-// Kernel choice of ader_tab_update_x3 for large catalogs: 1 (default) = the pipelined kernel k_tabp where its shape conditions hold
-// (table_update_x3p.hip), 0 = always k_tab32x3; a negative argument only queries.  Returns the previous setting.  Both kernels give
-// bit-identical results (tests/test_gpu_parity.py); the switch exists for kernel-vs-kernel tests and A/B timing.
+// Kernel choice of ader_tab_update_x3 for large catalogs: 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
+// (table_update_x3p.hip), 0 (default) = always k_tab32x3; a negative argument only queries.  Returns the previous setting.  Both
+// kernels give bit-identical results (tests/test_gpu_fullsize.py).  Why 0 is the default (round 4, cfg-S, same box): k_tabp runs the
+// update in 0.93 ms against 1.00 ms, but its persistent 512-thread workgroups own every register of every CU, so the weight-gradient
+// products, reductions and the small Adam of the side stream can no longer run INSIDE the update (0.14 ms when they follow it): the
+// step is 2.26 ms against 2.20.  DESIGN.md section 6 has the stamps.
 int ader_x3_update_pipelined(int mode) {
     const int prev = g_x3_pipelined;
     if (mode >= 0) g_x3_pipelined = mode ? 1 : 0;

@@ -310,9 +310,9 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
  * [Bp,168]; ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned; Bp % 32 == 0).  Replaces the dense-Adam + table-gradient op
  * sites ADER.py:91-96 for the item table, as ader_tab_update does. */
 int ader_x3_rep_image_bytes(int Bp);
-/* kernel choice of ader_tab_update_x3 on large catalogs: 1 (default) = the role-split pipelined kernel k_tabp where its shape
- * conditions hold (csrc/table_update_x3p.hip: >= 4 tile pairs per CU, no EXTRA / KD term), 0 = always k_tab32x3; negative: query
- * only.  Returns the previous setting.  Bit-identical results either way (same op sites: ADER.py:91-96). */
+/* kernel choice of ader_tab_update_x3 on large catalogs: 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
+ * (csrc/table_update_x3p.hip: >= 4 tile pairs per CU, no EXTRA / KD term), 0 (default) = always k_tab32x3; negative: query only.
+ * Returns the previous setting.  Bit-identical results either way (same op sites: ADER.py:91-96). */
 int ader_x3_update_pipelined(int mode);
 int ader_x3_rep_image(const void* rep_hi, const void* rep_lo, int Bp, void* img, void* stream);
 int ader_tab_update_x3(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int B, int Bp, int H, int N,
