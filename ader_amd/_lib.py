@@ -69,6 +69,8 @@ _SIGS = {
     "ader_lx3_prep": [P, P, P, I, I, I, P],
     "ader_lx3_fwd_shard": [P, P, P, I, I, I, I, I, I, P, P, P, P, P],
     "ader_lx3_merge_parts": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    "ader_lx3_readout_shard": [P, I, I, I, I, I, I, P, L, P, P, P, P, P],
+    "ader_lx3_merge_parts_kd": [P, P, I, I, I, I, P, P, P, P, P, P, P],
     "ader_lx3_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lx3_fwd_img": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_tab_grad": [P, P, P, I, I, I, I, I, P, P, P, P, P],
@@ -79,6 +81,7 @@ _SIGS = {
     "ader_x3_rep_image": [P, P, I, P, P],
     "ader_tab_update_x3": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_tab_update_x3_kd": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, L, P, P, P, P, P, F, F, F, F, P],
+    "ader_tab_update_x3_kd_range": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, L, P, P, P, P, P, F, F, F, F, I, I, P],
     "ader_tab_update_sh": [P, P, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_tab_meta_ints": [I],
     "ader_sparse_lists_scratch_n": [I, I, I],
@@ -94,6 +97,7 @@ _SIGS = {
     "ader_fill": [P, Z, F, P],
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_reduce_slabs_batch": [P, P, P, P, P, P, P, P, I, P],
+    "ader_pack_plan": [P, I, I, I, I, I, P, P, P, P, P, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
     "ader_herding_select_generic": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }

@@ -1130,6 +1130,104 @@ int ader_lx3_fwd_shard(const void* rep_hi, const void* rep_lo, const float* emb,
     return 0;
 }
 
+// Distilled rows under the catalog-sharded scheme (ADER.py:132-137 with the table sharded over the ranks).  The student's softmax
+// partials of the exemplar rows over the rank's items below Np come from ader_lx3_fwd_shard called with N = Np; the TEACHER readout
+// O2 = sum_j softmax(teacher)_j E_j splits over the item shards as plain partial sums (every term is normalised by the teacher's
+// full log-sum-exp): this launcher adds up the rank's items [item_begin + 1, item_begin + item_count] (clipped to Np) for the Bk
+// gathered exemplar rows -- part2 [Bk][152], channels at [2, 2 + H) like the student partials; scratch pO2 sized
+// ader_lx3_readout_ranges(item_count, Bk) * Bk * 160 floats.  trow [Bk] teacher row (-1: padding row), tlse2 [Bk] its log2-domain
+// log-sum-exp over [0, Np).
+__global__ __launch_bounds__(256) void k_lx3_sum_ranges(const float* __restrict__ pO2, int ranges, int Bk, int H, float* __restrict__ part2) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= PART_LD) return;
+    float v = 0.0f;
+    if (c >= 2 && c - 2 < H) for (int i = 0; i < ranges; ++i) v += pO2[((size_t)i * Bk + b) * HP + (c - 2)];
+    part2[(size_t)b * PART_LD + c] = v;
+}
+int ader_lx3_readout_shard(const float* emb, int item_num, int Bk, int H, int Np, int item_begin, int item_count, const float* teacher,
+                           long ldt, const int* trow, const float* tlse2, float* pO2, float* part2, void* stream) {
+    if (Bk <= 0) return 0;
+    if (Bk % 128 != 0 || H > HP || (H & 1) || H < 2 || Np > item_num || item_begin < 0 || (item_begin & 3) || ((uintptr_t)emb & 7) ||
+        !teacher || !trow || !tlse2) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    int n_loc = Np - item_begin;
+    if (n_loc > item_count) n_loc = item_count;
+    if (n_loc < 0) n_loc = 0;
+    int ranges2 = 0;
+    if (n_loc > 0) {
+        int rc = lx3_attr();
+        if (rc) return rc;
+        Lx3Args x;
+        x.emb1 = emb + (size_t)H * (1 + item_begin); x.vrows = item_num - item_begin;
+        x.rep_hi = nullptr; x.rep_lo = nullptr;
+        x.Bp = Bk; x.H = H; x.N = n_loc; x.ranges = 0; x.pm = nullptr; x.pl = nullptr; x.pO = nullptr;
+        x.kd_row0 = 0; x.Np = n_loc; x.teacher = teacher + item_begin; x.ldt = ldt; x.trow = trow; x.tlse2 = tlse2; x.pO2 = pO2;
+        ranges2 = ader_lx3_readout_ranges(n_loc, Bk);
+        x.ranges2 = ranges2;
+        hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * (Bk / 128)), dim3(256), (size_t)2 * 2 * FB * LDR * sizeof(bf16), st, x);
+    }
+    hipLaunchKernelGGL(k_lx3_sum_ranges, dim3(Bk), dim3(256), 0, st, (const float*)pO2, ranges2, Bk, H, part2);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Cross-rank merge for the distilled rows of THIS rank: parts_s / parts_t [W][Bk][152] = the W ranks' student partials (over the
+// first Np items) and teacher-readout partial sums -> lse, backward offset, loss row w (lse - rep . O2) and dRep = w (O1 / l - O2)
+// (k_lbf_combine's distilled branch with the range partials replaced by rank partials).  rep [B,H] fp32 representations of the
+// rank's exemplar rows, wrow [Bk] (0 for padding rows).  One wave per row; fixed summation order.
+__global__ __launch_bounds__(256) void k_lx3_merge_parts_kd(const float* __restrict__ parts_s, const float* __restrict__ parts_t, int W,
+                                                            int Bk, int B, int H, const float* __restrict__ rep,
+                                                            const float* __restrict__ wrow, float* __restrict__ lse,
+                                                            float* __restrict__ off, float* __restrict__ rowloss,
+                                                            float* __restrict__ drep) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= Bk) return;
+    const float w = b < B ? wrow[b] : 0.0f;
+    if (b >= B) {
+        if (lane == 0) { lse[b] = 0.0f; rowloss[b] = 0.0f; off[b] = -INFINITY; }
+        return;
+    }
+    float M = -INFINITY;
+    for (int i = 0; i < W; ++i) M = fmaxf(M, parts_s[((size_t)i * Bk + b) * PART_LD]);
+    float L = 0.0f, o[3] = {0.0f, 0.0f, 0.0f}, o2[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < W; ++i) {
+        const float* pr = parts_s + ((size_t)i * Bk + b) * PART_LD;
+        const float* pt = parts_t + ((size_t)i * Bk + b) * PART_LD;
+        const float m = pr[0];
+        const float sc = (m != -INFINITY) ? __builtin_amdgcn_exp2f(m - M) : 0.0f;
+        L += pr[1] * sc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int c = lane + 64 * k; if (c < H) { o[k] += pr[2 + c] * sc; o2[k] += pt[2 + c]; } }
+    }
+    const float lse2 = M + log2f(L);
+    float dot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = lane + 64 * k;
+        if (c < H) {
+            dot += rep[(size_t)b * H + c] * o2[k];
+            drep[(size_t)b * H + c] = w * (o[k] / L - o2[k]);
+        }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        const float z = lse2 / LOG2E;
+        lse[b] = z;
+        rowloss[b] = w * (z - dot);
+        off[b] = (w > 0.0f) ? log2f(w) - lse2 : -INFINITY;
+    }
+}
+int ader_lx3_merge_parts_kd(const float* parts_s, const float* parts_t, int world, int Bk, int B, int H, const float* rep,
+                            const float* wrow, float* lse, float* off, float* rowloss, float* drep, void* stream) {
+    if (Bk <= 0) return 0;
+    if (B > Bk || H > 192 || world < 1) return -2;
+    hipLaunchKernelGGL(k_lx3_merge_parts_kd, dim3((Bk + 3) / 4), dim3(256), 0, (hipStream_t)stream, parts_s, parts_t, world, Bk, B, H, rep,
+                       wrow, lse, off, rowloss, drep);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // Merge of the W ranks' partials as ader_lbf_merge_parts, with the target logit in fp32: rep [B,H] fp32 representations of THIS
 // rank's rows, e_lab [B,H] fp32 table rows of their labels.
 int ader_lx3_merge_parts(const float* parts, int world, int Bp, int B, int H, const float* e_lab, const float* rep,

@@ -992,12 +992,30 @@ int ader_tab_update_x3(const void* rep_hi, const void* rep_lo, const void* rep_i
     return 0;
 }
 
-// ... and for a DISTILLED step (ADER.py:132-137): arguments as ader_tab_update_kd plus rep_img.
+// ... and for a DISTILLED step (ADER.py:132-137): arguments as ader_tab_update_kd plus rep_img; the _range form restricts the update to
+// the 128-item tiles [tile_begin, tile_begin + tile_count) (tile_count < 0: all) -- a rank's shard of a catalog-sharded table, with
+// Bp / kd_row0 / off / wrow / trow / tlse2 describing the GLOBAL batch ([all train rows | all exemplar rows]).
+int ader_tab_update_x3_kd_range(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int Bp, int kd_row0, int H,
+                                int N, int Np, const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src,
+                                float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta,
+                                const float* wrow, const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb,
+                                float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                                int tile_count, void* stream);
 int ader_tab_update_x3_kd(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int Bp, int kd_row0, int H, int N,
                           int Np, const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src,
                           float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow,
                           const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
                           float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream) {
+    return ader_tab_update_x3_kd_range(rep_hi, rep_lo, rep_img, item_num, Bp, kd_row0, H, N, Np, off, sp_ids, sp_rows, n_sp, sp_src, sp_scale,
+                                       tg_ids, tg_rows, n_tg, tile_meta, wrow, teacher, ldt, trow, tlse2, emb, adam_m, adam_v, lr_t, beta1,
+                                       beta2, eps, 0, -1, stream);
+}
+int ader_tab_update_x3_kd_range(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int Bp, int kd_row0, int H,
+                                int N, int Np, const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src,
+                                float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta,
+                                const float* wrow, const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb,
+                                float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                                int tile_count, void* stream) {
     if (Bp <= 0) return 0;
     if (Bp % 128 != 0 || kd_row0 % 128 != 0 || kd_row0 >= Bp || H > HP || (H & 1) || H < 2 || N > item_num || !rep_lo || !teacher ||
         !trow || !tlse2 || Np < 1 || Np > N) return -2;
@@ -1014,7 +1032,13 @@ int ader_tab_update_x3_kd(const void* rep_hi, const void* rep_lo, const void* re
     fa.emb1 = emb + H; fa.m1 = adam_m + H; fa.v1 = adam_v + H; fa.sh1w = nullptr;
     fa.lr_t = lr_t; fa.omb1 = 1.0f - beta1; fa.omb2 = 1.0f - beta2; fa.eps = eps;
     fa.extra1 = nullptr;
-    int rc = tab16x3_launch(a, fa, (N + TI - 1) / TI, false, true, stream);
+    const int all = (N + TI - 1) / TI;
+    int tb = (tile_begin < 0 ? 0 : tile_begin) * 2;
+    int te = tile_count < 0 ? all : tb + tile_count * 2;
+    if (te > all) te = all;
+    if (te <= tb) return 0;
+    a.tile_off = tb;
+    int rc = tab16x3_launch(a, fa, te - tb, false, true, stream);
     if (rc) return rc;
     HIP_LAUNCH_CHECK();
     return 0;

@@ -72,6 +72,16 @@ def shard_rows(x, world, rank, fill=0):
     return np.concatenate([x[lo:hi], np.full((pad,) + x.shape[1:], fill, dtype=x.dtype)])
 
 
+def global_ids_host(seq, pos, world):
+    """ids of every rank's positions for one step of the catalog-sharded scheme, on the HOST: [world, n_all] int32 with
+    n_all = rows * T + rows per rank (its input positions, then its labels), rows = ceil(n / world) after shard_rows' padding.
+    seq [n, T] / pos [n]: the GLOBAL batch (numpy) -- every rank builds the same batches, so every rank can form this without any
+    communication; Engine.train_step(ids_host=...) then needs no device-to-host synchronisation for the packed row exchange."""
+    seq, pos = np.asarray(seq), np.asarray(pos)
+    return np.stack([np.concatenate([shard_rows(seq, world, r).reshape(-1), shard_rows(pos, world, r)]).astype(np.int32)
+                     for r in range(world)])
+
+
 def bucket_ranges(total, table_elems, bucket_elems):
     """[(lo, hi)] covering [0, total): the used table rows in large buckets, then everything after the table."""
     out, lo = [], 0

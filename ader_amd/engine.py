@@ -162,6 +162,22 @@ def _check(cond, msg):
         raise RuntimeError(msg)
 
 
+def pack_counts_host(ids_host, n_pos, shard_items):
+    """[owner][destination] row counts of the packed catalog exchange from the GLOBAL batch on the host: ids_host [W, n_all] int32
+    (rank d's input positions, then its labels).  Returns (C_all, C_pos) as lists of lists -- what csrc/pack_plan.hip computes on the
+    device, without a device-to-host synchronisation."""
+    ids = np.asarray(ids_host)
+    W = ids.shape[0]
+    own = np.where(ids > 0, np.minimum((ids - 1) // shard_items, W - 1), -1)
+    dst = np.broadcast_to(np.arange(W)[:, None], ids.shape)
+
+    def counts(o, d):
+        m = o >= 0
+        return np.bincount(o[m] * W + d[m], minlength=W * W).reshape(W, W).tolist()
+
+    return counts(own, dst), counts(own[:, :n_pos], dst[:, :n_pos])
+
+
 class Engine:
     MAX_ROWS = 1024        # padded batch rows per launch of the exact-f32 logit kernels (per-row state in LDS) and of the eval paths
     MAX_ROWS_FAST = 4096   # ... of a train step whose logits run on the flash kernels (logits_dtype bf16 / x3): 128-row chunks
@@ -252,6 +268,7 @@ class Engine:
         # that the dense exchange keeps the step free of host synchronisation (ADER_DP_PACK=0/1 overrides).
         _p = os.environ.get("ADER_DP_PACK")
         self.dp_pack = (self.dp_world >= 8) if _p is None else (_p == "1")
+        self.comm_syncs = None   # catalog packed exchange: host synchronisations of the last step (0 with ids_host, else 1)
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self.kd_fast = True      # ... exemplar rows on the flash path too (teacher readout + fused KD update)
         # bf16 mode, fused table update: "sh" = k_tab16 (operand from the shadow rows, three workgroups per CU: the faster form),
@@ -1266,21 +1283,6 @@ class Engine:
             return out
         return self._ag(t)[:, self.dp_rank].contiguous()        # backends without all-to-all on device tensors (tests)
 
-    @staticmethod
-    def _group_order(key, G):
-        """Stable grouping permutation: indices of `key` (int64 [n], values in [0, G)) ordered by key, original order inside a
-        group -- a counting sort with a prefix sum (a handful of small launches instead of a radix sort)."""
-        n = key.numel()
-        oh = torch.zeros(n, G, dtype=torch.int32, device=key.device)
-        oh.scatter_(1, key.view(-1, 1), 1)
-        csum = oh.cumsum(0, dtype=torch.int32)
-        rank = csum.gather(1, key.view(-1, 1)).view(-1) - 1
-        cnt = csum[-1].long()
-        off = cnt.cumsum(0) - cnt
-        out = torch.empty(n, dtype=torch.int64, device=key.device)
-        out[off[key] + rank.long()] = torch.arange(n, device=key.device)
-        return out
-
     def _a2a_rows(self, rows, counts):
         """Uneven all-to-all of rows [K, H]: counts [W, W] (host ints), counts[i][j] = rows rank i sends to rank j; the local
         rows are ordered by destination.  Returns the received rows ordered by source."""
@@ -1303,7 +1305,8 @@ class Engine:
             segs.append(allr[i, o:o + outs[i]])
         return torch.cat(segs) if segs else out
 
-    def _train_step_catalog(self, seq, pos, max_item, lr, rate=0.0, n_train_global=None, **_unused):
+    def _train_step_catalog(self, seq, pos, max_item, lr, rate=0.0, n_train_global=None, ids_host=None, pack_counts=None,
+                            teacher=None, ex_trow=None, lambda_=0.0, n_ex_global=None, **_unused):
         """Vanilla train step with the item catalog sharded across the ranks (dense Adam touches every table row
         every step, so a replicated table costs (W-1)/W x 600 MB of xGMI traffic per rank per step; a sharded one costs only
         the rows the inputs touch).  Rank r owns table rows [1 + r*S, (r+1)*S]: theta / m / v / shadow of other rows are
@@ -1316,19 +1319,38 @@ class Engine:
              (ader_lbf_fwd_shard), exchanged so every rank merges the W partials of its own rows -> loss, dRep, offsets;
           4. local backward; per-position gradient rows, labels, weights and offsets all-gathered;
           5. fused gradient + Adam + shadow on the local shard for the global batch (ader_lbf_bwd_adam); nothing is sent back.
-        Same update as a single process on the global batch (sum over rows; tests/test_gpu_dp.py)."""
+        Same update as a single process on the global batch (sum over rows; tests/test_gpu_dp.py).
+        DISTILLED steps (float32 grade; ADER.py:132-137, main.py:223-256: `teacher` [*, Np] replicated on every rank, `ex_trow` the
+        teacher rows of this rank's exemplar rows, which follow its train rows in `seq`): the exemplar rows of all ranks form a
+        second block of the global batch ([all train rows | all exemplar rows]); their student softmax runs over the first Np items
+        only (ader_lx3_fwd_shard with N = Np), the teacher readout O2 = sum_j softmax(t)_j E_j is summed shard by shard
+        (ader_lx3_readout_shard), ader_lx3_merge_parts_kd turns the W partials into loss = w (lse - rep.O2) and dRep = w (O1/l - O2),
+        and the fused update subtracts the teacher term for its item range (ader_tab_update_x3_kd_range) -- nothing proportional to
+        the table is exchanged either (rounds 1-3: distilled steps fell back to the replicated table and a dense all-reduce)."""
         import torch.distributed as dist
         self._refresh_stream()
         W, r, grp = self.dp_world, self.dp_rank, self.dp_group
         seq, pos = self._dev_i32(seq), self._dev_i32(pos)
-        B, T, H, S = seq.shape[0], self.T, self.H, self.shard_items
+        B_all, T, H, S = seq.shape[0], self.T, self.H, self.shard_items
+        B = pos.shape[0]                                                   # train rows (the exemplar rows follow them in seq)
+        n_ex = B_all - B
+        kd = teacher is not None and n_ex > 0
         N = int(max_item)
         Bp = (B + 127) // 128 * 128
-        _check(pos.shape[0] == B and B <= self.MAX_ROWS and 1 <= N <= self.item_num,
-               "catalog-sharded step: pos rows == input rows <= %d and 1 <= max_item <= item_num" % self.MAX_ROWS)
+        Bk = (n_ex + 127) // 128 * 128 if kd else 0
+        _check((n_ex == 0 or kd) and 1 <= B and B_all <= self.MAX_ROWS and 1 <= N <= self.item_num,
+               "catalog-sharded step: 1 <= train rows, input rows <= %d, 1 <= max_item <= item_num; rows beyond the labels need "
+               "exemplar_logits" % self.MAX_ROWS)
+        Np = 0
+        if kd:
+            _check(self.lx3, "distilled catalog-sharded steps run at float32 grade (logits_dtype='x3')")
+            ex_trow = self._dev_i32(ex_trow if ex_trow is not None else np.arange(n_ex))
+            Np = teacher.shape[1]
+            _check(teacher.dtype == torch.float32 and teacher.stride(1) == 1 and Np <= N and ex_trow.shape[0] == n_ex,
+                   "exemplar_logits must be float32 [*, Np <= max_item] with one teacher row index per exemplar row")
         st = self._stream()
         step = self.global_step
-        n_pos, n_all = B * T, B * T + B
+        n_pos, n_all = B_all * T, B_all * T + B
         pack = self.dp_pack
         with self._sec("grad_exchange"):
             ids_l = torch.cat([seq.reshape(-1), pos])                          # my input positions, then my labels
@@ -1341,51 +1363,45 @@ class Engine:
                 recv = self._a2a(send)                                         # slice i: rows rank i owns among MY positions
                 call("ader_scatter_owned", ptr(recv), ptr(ids_l), n_all, n_pos, H, S, W, self._pp["emb"], ptr(e_lab), st)
             else:
-                # packed exchange: only owned rows travel.  Every rank derives the same owner map and the [owner, destination]
-                # row counts from the gathered ids; the counts go to the host (the one sync of the step: split sizes)
-                own = torch.where(ids_g > 0, torch.clamp((ids_g - 1) // S, max=W - 1), torch.full_like(ids_g, -1)).long()
-                dst = torch.arange(W, device=self.device).view(W, 1).expand(W, n_all)
-                key = torch.where(own >= 0, own * W + dst, torch.full_like(own, W * W))
-                cnt = torch.zeros(2, W * W + 1, dtype=torch.int64, device=self.device)
-                one = torch.ones_like(key)
-                cnt[0].scatter_add_(0, key.reshape(-1), one.reshape(-1))                       # all positions (inputs + labels)
-                cnt[1].scatter_add_(0, key[:, :n_pos].reshape(-1), one[:, :n_pos].reshape(-1))  # input positions only
-                C = cnt[:, :W * W].view(2, W, W).cpu().tolist()
-                C_all, C_pos = C[0], C[1]
+                # packed exchange: only owned rows travel.  ONE launch (csrc/pack_plan.hip) derives, from the gathered ids, the
+                # [owner, destination] row counts -- the same matrix on every rank -- and every index list of the exchange.  The
+                # counts are the split sizes of the uneven all-to-alls, which torch wants as host integers: when the caller knows
+                # the global batch on the host (`ids_host`, [W, n_all]: main.py and bench.py do -- every rank builds the same
+                # batches), they are computed there and the step has NO host synchronisation; otherwise they are read back (one sync).
+                i64 = torch.int64
+                cnt = self.buf("pk_cnt", (2, W, W), torch.int32)
+                send_id, ids_bk = self.buf("pk_send", (W * n_all,), i64), self.buf("pk_back", (W * n_all,), i64)
+                perm, bsrc = self.buf("pk_perm", (n_all,), i64), self.buf("pk_bsrc", (max(n_pos, 1),), i64)
+                call("ader_pack_plan", ptr(ids_g), W, n_all, n_pos, r, S, ptr(cnt), ptr(send_id), ptr(ids_bk), ptr(perm), ptr(bsrc), st)
+                if pack_counts is not None:                                     # (C_all, C_pos) prepared by the caller
+                    C_all, C_pos = pack_counts
+                    self.comm_syncs = 0
+                elif ids_host is not None:
+                    C_all, C_pos = pack_counts_host(ids_host, n_pos, S)
+                    self.comm_syncs = 0
+                else:
+                    C = cnt.cpu().tolist()
+                    C_all, C_pos = C[0], C[1]
+                    self.comm_syncs = 1
                 table = self.theta[:self.V_alloc * H].view(self.V_alloc, H)
-                # rows I own, ordered by (destination, position): the gathered ids are already laid out [destination][position],
-                # so this is a plain compaction of the owned entries
-                # (prefix sum + scatter with a trash slot: K is known from the counts, so no second host sync as nonzero() needs)
-                K = sum(C_all[r])
-                mine_f = own.reshape(-1) == r
-                slot_f = torch.where(mine_f, torch.cumsum(mine_f, 0) - 1, torch.full_like(own.reshape(-1), K))
-                idx_send = torch.empty(K + 1, dtype=torch.int64, device=self.device)
-                idx_send.scatter_(0, slot_f, torch.arange(W * n_all, device=self.device))
-                idx_send = idx_send[:K]
-                rows = table[ids_g.reshape(-1)[idx_send].long()]
+                K = sum(C_all[r])                                               # rows I send, ordered by (destination, position)
+                rows = table.index_select(0, send_id[:K])
                 got = self._a2a_rows(rows, C_all)                              # ordered by owner, then by my position index
-                perm = self._group_order(own[r] + 1, W + 1)                    # my positions: padding first, then by owner
-                n_pad = n_all - got.shape[0]
+                n_pad = n_all - got.shape[0]                                   # my padding positions (id 0) come first in perm
                 full = self.buf("cs_full", (n_all, H))
                 full.zero_()
                 full.index_copy_(0, perm[n_pad:], got)
-                row0 = table[0].clone()                                        # padding positions carry id 0: row 0 stays as it is
+                # (padding positions carry id 0 and zero rows: written over row 0, which the gather never reads -- it treats id 0 as
+                #  the zero row, modules.py:124-126 -- and which is restored right away to stay bit-identical with the other modes)
+                row0 = table[0].clone()
                 table.index_copy_(0, ids_l[:n_pos].long(), full[:n_pos])
                 table[0].copy_(row0)
                 e_lab.copy_(full[n_pos:])
-                # the same bookkeeping for the gradient rows that travel back after the backward pass
-                # (inside a destination / owner group the positions are in order, so the labels -- the last B positions of a
-                #  rank -- are the tail of every group: the input-position part of a group is its first C_pos entries)
-                o, segs = 0, []
-                for j in range(W):
-                    segs.append(idx_send[o:o + C_pos[r][j]])
-                    o += C_all[r][j]
-                ids_back = ids_g.reshape(-1)[torch.cat(segs)]                  # ids of the gradient rows I will receive
-                o, segs = n_pad, []
-                for i in range(W):
-                    segs.append(perm[o:o + C_pos[i][r]])
-                    o += C_all[i][r]
-                back_src = torch.cat(segs)                                     # my input positions, grouped by owner
+                # the gradient rows that travel back after the backward pass: ids of the rows I will receive (my owned entries among
+                # everybody's INPUT positions, in (source, position) order) and my input positions grouped by owner
+                Kb = sum(C_pos[r])
+                ids_back = ids_bk[:Kb].to(torch.int32)
+                back_src = bsrc[:sum(C_pos[o][r] for o in range(W))]
         self._table_stale = True
         lab_all = self.buf("cs_lab_all", (W, Bp), torch.int32)                 # labels in the padded row numbering of rep_g
         lab_all.zero_()
@@ -1393,6 +1409,8 @@ class Engine:
         # id-sorted lists of the sparse terms of the GLOBAL batch (side stream): positions of the all-gathered gradient rows, or,
         # packed, of the rows this rank will receive
         self._lists_async(ids_back if pack else ids_g[:, :n_pos], lab_all, N)
+        # (a shard's train rows and exemplar rows sit at different global rows: two dropout counter segments, as in loss_and_grad)
+        self.split_rows = B if (n_ex > 0 and getattr(self, "_ex_row0_set", False)) else None
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         rep_bf = None if self.lx3 else self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
@@ -1403,12 +1421,16 @@ class Engine:
         wrow[:B] = (pos > 0).to(torch.float32) * w_row          # label 0 = padding row of an equal-size shard: weight 0
         lab.zero_()
         lab[:B] = pos
-        drep = self.buf("drep", (B, H))
-        lse, rowloss = self.buf("lg_lse", (Bp,)), self.buf("lg_rowloss", (Bp,))
+        drep = self.buf("drep", (B_all, H))
+        rl_all = self.buf("lg_rowloss", (Bp + Bk,))
+        lse, rowloss = self.buf("lg_lse", (Bp,)), rl_all[:Bp]
+        Bg = W * (Bp + Bk)                                                     # rows of the global batch: [all train | all exemplar]
         with self._sec("logits_fwd"):
-            R = call("ader_lbf_ranges", S, W * Bp)
-            pm, pl = self.buf("lbf_pm", (R * W * Bp,)), self.buf("lbf_pl", (R * W * Bp,))
-            pO = self.buf("lbf_pO", (R * W * Bp * 160,))
+            n_part = call("ader_lbf_ranges", S, W * Bp) * W * Bp               # range partials: rows x item ranges of the larger block
+            if kd:
+                n_part = max(n_part, call("ader_lbf_ranges", S, W * Bk) * W * Bk)
+            pm, pl = self.buf("lbf_pm", (n_part,)), self.buf("lbf_pl", (n_part,))
+            pO = self.buf("lbf_pO", (n_part * 160,))
             part = self.buf("lbf_part", (W * Bp * 152,))
             if self.lx3:
                 # float32 grade: the fp32 representations travel (W * Bp * H floats), every rank cuts the hi / lo operand planes of
@@ -1417,16 +1439,50 @@ class Engine:
                 #  only by off = -inf -- exp2(NaN - inf) is NaN and would poison the whole shard: cleared at allocation, and rows
                 #  a larger earlier batch left behind are finite representations)
                 rep_pad = self.buf("cs_rep_pad", (Bp, H), zero=True)
-                rep_pad[:B].copy_(rep)
+                rep_pad[:B].copy_(rep[:B])
                 rep_f = self._ag(rep_pad)                                      # [W, Bp, H]
-                rep_g = self.buf("cs_rep_hi", (W * Bp * 168,), torch.bfloat16)
-                rep_lo_g = self.buf("cs_rep_lo", (W * Bp * 168,), torch.bfloat16)
-                call("ader_lx3_prep", ptr(rep_f), ptr(rep_g), ptr(rep_lo_g), W * Bp, W * Bp, H, st)
+                if kd:
+                    rep_pad_k = self.buf("cs_rep_pad_k", (Bk, H), zero=True)
+                    rep_pad_k[:n_ex].copy_(rep[B:])
+                    rep_f = torch.cat([rep_f.view(W * Bp, H), self._ag(rep_pad_k).view(W * Bk, H)])
+                rep_g = self.buf("cs_rep_hi", (Bg * 168,), torch.bfloat16)
+                rep_lo_g = self.buf("cs_rep_lo", (Bg * 168,), torch.bfloat16)
+                call("ader_lx3_prep", ptr(rep_f), ptr(rep_g), ptr(rep_lo_g), Bg, Bg, H, st)
                 call("ader_lx3_fwd_shard", ptr(rep_g), ptr(rep_lo_g), self._pp["emb"], self.item_num, W * Bp, H, N, r * S, S,
                      ptr(pm), ptr(pl), ptr(pO), ptr(part), st)
                 pr = self._a2a(part.view(W, Bp, 152))                          # partials of MY rows from every rank
                 call("ader_lx3_merge_parts", ptr(pr), W, Bp, B, H, ptr(e_lab), ptr(rep), ptr(wrow), ptr(lse), ptr(off),
                      ptr(rowloss), ptr(self.loss), ptr(drep), st)
+                if kd:
+                    # the exemplar block: per-row info of MY rows, gathered for the readout (teacher row, its log2-domain lse) ...
+                    w_ex = float(lambda_) / float(n_ex_global if n_ex_global is not None else n_ex)
+                    tl_all = self._teacher_lse(teacher, Np)
+                    metak = self.buf("cs_metak", (4, Bk), torch.int32)         # rows: off, wrow, teacher row, tlse2 (f32 bits)
+                    off_k, w_k, tr_k, tl2_k = (metak[0].view(torch.float32), metak[1].view(torch.float32), metak[2],
+                                               metak[3].view(torch.float32))
+                    tr_k.fill_(-1)
+                    tr_k[:n_ex] = ex_trow
+                    w_k.zero_()
+                    w_k[:n_ex] = (ex_trow >= 0).to(torch.float32) * w_ex
+                    tl2_k.zero_()
+                    tl2_k[:n_ex] = tl_all[ex_trow.clamp(min=0).long()] * 1.4426950408889634
+                    tinfo = self._ag(torch.stack([tr_k, metak[3]]))            # [W, 2, Bk]
+                    tr_g = tinfo[:, 0].contiguous().view(-1)
+                    tl2_g = tinfo[:, 1].contiguous().view(torch.float32).view(-1)
+                    # ... student partials over MY items below Np and the teacher readout over the same items, for ALL exemplar rows
+                    kd_off = W * Bp * 168
+                    part_k, part_t = self.buf("lbf_part_k", (W * Bk * 152,)), self.buf("lbf_part_t", (W * Bk * 152,))
+                    call("ader_lx3_fwd_shard", rep_g.data_ptr() + 2 * kd_off, rep_lo_g.data_ptr() + 2 * kd_off, self._pp["emb"],
+                         self.item_num, W * Bk, H, Np, r * S, S, ptr(pm), ptr(pl), ptr(pO), ptr(part_k), st)
+                    R2 = call("ader_lx3_readout_ranges", S, W * Bk)
+                    pO2 = self.buf("lbf_pO2", (R2 * W * Bk * 160,))
+                    call("ader_lx3_readout_shard", self._pp["emb"], self.item_num, W * Bk, H, Np, r * S, S, ptr(teacher),
+                         teacher.stride(0), ptr(tr_g), ptr(tl2_g), ptr(pO2), ptr(part_t), st)
+                    pr_k, pr_t = self._a2a(part_k.view(W, Bk, 152)), self._a2a(part_t.view(W, Bk, 152))
+                    lse_k = self.buf("lg_lse_k", (Bk,))
+                    call("ader_lx3_merge_parts_kd", ptr(pr_k), ptr(pr_t), W, Bk, n_ex, H, rep.data_ptr() + 4 * B * H, ptr(w_k),
+                         ptr(lse_k), ptr(off_k), rl_all.data_ptr() + 4 * Bp, drep.data_ptr() + 4 * B * H, st)
+                    call("ader_lbf_sum", ptr(rl_all), Bp + Bk, ptr(self.loss), st)
             else:
                 call("ader_lbf_prep", ptr(rep), ptr(rep_bf), B, Bp, H, st)
                 rep_g = self._ag(rep_bf)                                       # [W, Bp*168]
@@ -1458,6 +1514,13 @@ class Engine:
                 g_g = self._ag(dx)                                             # [W,B*T,H]
             off_g = meta_g[:, 0].contiguous().view(torch.float32)
             w_g = meta_g[:, 1].contiguous().view(torch.float32)
+            if kd:      # the exemplar block behind the train block: offsets, weights, teacher rows, teacher lse of every rank's rows
+                mk_g = self._ag(metak)                                         # [W,4,Bk]
+                zt = torch.zeros(W * Bp, dtype=torch.int32, device=self.device)
+                off_g = torch.cat([off_g.view(-1), mk_g[:, 0].contiguous().view(torch.float32).view(-1)])
+                w_g = torch.cat([w_g.view(-1), mk_g[:, 1].contiguous().view(torch.float32).view(-1)])
+                trow_g = torch.cat([zt - 1, mk_g[:, 2].contiguous().view(-1)])
+                tlse2_g = torch.cat([zt.view(torch.float32), mk_g[:, 3].contiguous().view(torch.float32).view(-1)])
             main.wait_stream(self._side) if getattr(self, "_side", None) is not None else None   # small gradients complete
             dist.all_reduce(self.grad[span:], group=grp)
             dist.all_reduce(self.loss, group=grp)
@@ -1465,12 +1528,19 @@ class Engine:
         tiles = S // 128
         with self._sec("logits_bwd_adam"):
             if self.lx3:
-                img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", W * Bp),), torch.uint8, zero=True)
-                call("ader_x3_rep_image", ptr(rep_g), ptr(rep_lo_g), W * Bp, ptr(img), st)
-                call("ader_tab_update_x3", ptr(rep_g), ptr(rep_lo_g), ptr(img), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
-                     ptr(ids), ptr(order), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids), ptr(torder),
-                     tids.numel(), ptr(tmeta), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
-                     self.beta2, self.eps, r * tiles, tiles, None, st)
+                img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", Bg),), torch.uint8, zero=True)
+                call("ader_x3_rep_image", ptr(rep_g), ptr(rep_lo_g), Bg, ptr(img), st)
+                if kd:
+                    call("ader_tab_update_x3_kd_range", ptr(rep_g), ptr(rep_lo_g), ptr(img), self.item_num, Bg, W * Bp, H, N, Np,
+                         ptr(off_g), ptr(ids), ptr(order), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
+                         ptr(torder), tids.numel(), ptr(tmeta), ptr(w_g), ptr(teacher), teacher.stride(0), ptr(trow_g), ptr(tlse2_g),
+                         ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1, self.beta2, self.eps, r * tiles,
+                         tiles, st)
+                else:
+                    call("ader_tab_update_x3", ptr(rep_g), ptr(rep_lo_g), ptr(img), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
+                         ptr(ids), ptr(order), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids), ptr(torder),
+                         tids.numel(), ptr(tmeta), ptr(w_g), ptr(self.theta), ptr(self.adam_m), ptr(self.adam_v), lr_t, self.beta1,
+                         self.beta2, self.eps, r * tiles, tiles, None, st)
             else:
                 call("ader_tab_update_sh", ptr(rep_g), ptr(self.shadow), self.item_num, W * Bp, W * Bp, H, N, ptr(off_g),
                      ptr(ids), ptr(order), ptr(sp_start), ids.numel(), ptr(g_g), float(np.sqrt(np.float32(H))), ptr(tids),
@@ -1520,8 +1590,10 @@ class Engine:
 
     def _train_step(self, seq, pos, max_item, lr, **kw):
         if (self.dp_world > 1 and self.dp_mode == "catalog" and (self.shadow is not None or self.lx3) and self.seq_fused
-                and kw.get("teacher") is None and kw.get("ex_pos") is None):
+                and kw.get("ex_pos") is None and (kw.get("teacher") is None or self.lx3)):
             return self._train_step_catalog(seq, pos, max_item, lr, **kw)
+        kw.pop("ids_host", None)           # (host-side knowledge of the global batch: only the packed catalog exchange uses it)
+        kw.pop("pack_counts", None)
         self.sync_table()
         sharded = self.dp_world > 1 and self.dp_sharded and self.shadow is not None      # (x3 / f32 logits: dense exchange)
         fuse = self.fuse_adam and (self.grad_hook is None or sharded)

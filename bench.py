@@ -206,16 +206,31 @@ def main():
         dp_.set_rows(rank * B, N)
         return eng_
 
+    # packed catalog exchange (the default from 8 ranks on): its all-to-all split sizes come from the ids of the GLOBAL batch, which
+    # every rank can form on the host (the synthetic batches of all ranks are a function of (s, rank)): no device-to-host sync per step
+    pack_kw = [{} for _ in range(nbatch)]
+
+    def prepare_pack_counts(eng_):
+        if world > 1 and eng_.dp_mode == "catalog" and eng_.dp_pack and not E:
+            from ader_amd.engine import pack_counts_host
+            for s_ in range(nbatch):
+                rows = []
+                for r_ in range(world):
+                    sq, ps = synth_batch(B, T, N, 1000 * s_ + r_, "cpu", args.regime)
+                    rows.append(np.concatenate([sq.numpy().reshape(-1), ps.numpy()]).astype(np.int32))
+                pack_kw[s_] = {"pack_counts": pack_counts_host(np.stack(rows), B * T, eng_.shard_items)}
+
     def timed(eng_, reps, sections=True):
         """5 untimed initialisation steps, W warm-up steps (per-kernel HIP events on the last three), then `reps` repetitions of
         EXACTLY K steps, each bracketed by a barrier + synchronize on both sides; per repetition the MAX over ranks."""
         sec_all = {}
+        prepare_pack_counts(eng_)
         for i in range(5):        # engine initialisation (workspace allocation, kernel attributes, side streams): never timed
-            eng_.train_step(*batches[i % nbatch], N, lr, **kw)
+            eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
         for i in range(args.warmup):
             if sections and i == max(0, args.warmup - 3):
                 eng_.timer = SectionTimer()
-            eng_.train_step(*batches[i % nbatch], N, lr, **kw)
+            eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
         eng_.check_status()
         if sections:
             if eng_.timer is not None:
@@ -233,7 +248,7 @@ def main():
             sync()
             t0 = time.perf_counter()
             for i in range(args.steps):
-                eng_.train_step(*batches[i % nbatch], N, lr, **kw)
+                eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
             sync()
             dt_ = time.perf_counter() - t0
             if world > 1:
@@ -257,7 +272,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for i in range(args.sustained_steps):
-            eng.train_step(*batches[i % nbatch], N, lr, **kw)
+            eng.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
         sync()
         dts_ = time.perf_counter() - t0
         if world > 1:
@@ -322,6 +337,7 @@ def main():
 
     P, span = eng.P, eng.layout["pos"][0]
     dp_mode, dp_pack = eng.dp_mode, eng.dp_pack
+    comm_syncs = eng.comm_syncs if eng.dp_pack else 0
     exchange = ("none" if world == 1 else
                 ("catalog-sharded table: input rows all-to-all + representations all-gather + softmax partials all-to-all + gradient "
                  "rows all-gather" if (dp_mode == "catalog" and args.logits in ("bf16", "x3") and not E) else
@@ -455,6 +471,10 @@ def main():
             else:
                 rb = 2.0 * (W - 1) / W * (N + 1) * H * 4 + (W - 1) * (B * T * 4 + B * T * H * 4) + small
             comm = {"dp_mode": dp_mode if cat > 1 or eng_sharded(args.logits) else "dense all-reduce", "packed_rows": bool(dp_pack),
+                    # per step of the catalog-sharded scheme: collectives issued, launches of exchange bookkeeping, host syncs
+                    "collectives_per_step": (8 if cat > 1 else None),
+                    "bookkeeping_launches_per_step": ((1 + 7) if (cat > 1 and dp_pack) else (2 if cat > 1 else None)),
+                    "host_syncs_per_step": (comm_syncs if cat > 1 else None),
                     "comm_ms": round(sum(sections.get(k, 0.0) for k in comm_names), 4),
                     "comm_ms_note": "host-side sections around the collectives in the warm-up steps (they include the kernels that pack / "
                                     "unpack the exchanged rows); the dense all-reduce overlaps the blocks backward",

@@ -254,6 +254,15 @@ int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int
  * the all-gathered representations from ader_lx3_prep; the merge takes the fp32 representations and label rows). */
 int ader_lx3_fwd_shard(const void* rep_hi, const void* rep_lo, const float* emb, int item_num, int Bp, int H, int N,
                        int item_begin, int item_count, float* pm, float* pl, float* pO, float* part, void* stream);
+/* ... distilled rows (ADER.py:132-137) under the same scheme: the teacher readout O2 = sum_j softmax(teacher)_j E_j over the rank's
+ * item shard for the Bk gathered exemplar rows (part2 [Bk][152], channels at [2, 2 + H); trow [Bk] teacher row or -1, tlse2 [Bk] the
+ * teacher's log2-domain log-sum-exp over [0, Np); scratch pO2: ader_lx3_readout_ranges(item_count, Bk) * Bk * 160 floats), and the
+ * merge of the W ranks' student partials (ader_lx3_fwd_shard called with N = Np) and readout sums for THIS rank's exemplar rows:
+ * loss row w (lse - rep . O2), dRep = w (O1 / l - O2), lse, backward offset. */
+int ader_lx3_readout_shard(const float* emb, int item_num, int Bk, int H, int Np, int item_begin, int item_count, const float* teacher,
+                           long ldt, const int* trow, const float* tlse2, float* pO2, float* part2, void* stream);
+int ader_lx3_merge_parts_kd(const float* parts_s, const float* parts_t, int world, int Bk, int B, int H, const float* rep,
+                            const float* wrow, float* lse, float* off, float* rowloss, float* drep, void* stream);
 int ader_lx3_merge_parts(const float* parts, int world, int Bp, int B, int H, const float* e_lab, const float* rep,
                          const float* wrow, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream);
 /* float32-grade variant of ader_lbf_fwd ("x3": every product as three bf16 MFMAs on hi/lo operand splits, fp32 accumulate;
@@ -325,6 +334,14 @@ int ader_tab_update_x3_kd(const void* rep_hi, const void* rep_lo, const void* re
                           float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta,
                           const float* wrow, const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb,
                           float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
+/* ... restricted to the 128-item tiles [tile_begin, tile_begin + tile_count) (a rank's shard of a catalog-sharded table; Bp, kd_row0
+ * and the per-row arrays describe the GLOBAL batch [all train rows | all exemplar rows]; tile_count < 0: all tiles) */
+int ader_tab_update_x3_kd_range(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int Bp, int kd_row0, int H,
+                          int N, int Np, const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src,
+                          float sp_scale, const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta,
+                          const float* wrow, const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb,
+                          float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                                int tile_count, void* stream);
 /* The bf16-mode form over 128-row tiles: the GEMM operand is the tile's bf16 shadow rows (`shadow` is read AND rewritten) and the
  * sorted lists are addressed through their 64-id bucket offsets sp_start / tg_start.  Faster than ader_tab_update(rep_lo = NULL) at
  * H = 150 on MI355X although it reads 336 B more per row (measurements: DESIGN.md). */
@@ -379,6 +396,14 @@ int ader_reduce_slabs(const float* src, long slab_stride, int S, int ld, int n_r
 /* up to 8 such reductions in one launch (arrays of n job descriptions; same arithmetic and summation order per job) */
 int ader_reduce_slabs_batch(const float* const* src, const long* slab_stride, const int* S, const int* ld, const int* n_rows,
                             const int* n_cols, float* const* dst, float* const* dst_extra, int n, void* stream);
+
+/* ---- data-parallel catalog-sharded step: bookkeeping of the packed row exchange in one launch (csrc/pack_plan.hip).  Serves the
+ *      gather of modules.py:127 and its gradient when the item table is sharded over the ranks (the reference is single-device,
+ *      main.py:96).  ids_g [W][n_all] gathered ids (n_pos input positions, then labels, per rank); rank r owns items
+ *      [1 + r shard_items, (r + 1) shard_items].  cnt [2][W][W] ints (owner x destination counts: all positions / input positions);
+ *      send_id / ids_back (<= W n_all), perm (n_all), back_src (<= n_pos): int64 index arrays, see the file header.  W <= 16. */
+int ader_pack_plan(const int* ids_g, int W, int n_all, int n_pos, int rank, int shard_items, int* cnt, long* send_id, long* ids_back,
+                   long* perm, long* back_src, void* stream);
 
 /* ---- herding exemplar selection: util.py:401-434 (the loop of ExemplarGenerator.herding, called per label from
  *      herding_selection util.py:447-457) -- ALL label groups of a period in one call ------------------------------------

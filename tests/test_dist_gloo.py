@@ -189,3 +189,36 @@ def test_split_groups_is_contiguous_and_balanced():
         ch = adist.split_groups(sizes, w)
         assert ch[0][0] == 0 and ch[-1][1] == len(sizes)
         assert all(a[1] == b[0] for a, b in zip(ch, ch[1:])) and all(lo <= hi for lo, hi in ch)
+
+
+def test_pack_counts_and_global_ids_on_the_host():
+    """Host side of the packed catalog exchange (no GPU): dist.global_ids_host lays out every rank's (input positions, labels) of a
+    global batch exactly as the ranks feed them (shard_rows padding included), and engine.pack_counts_host counts, per (owner,
+    destination), the rows that travel -- checked against a brute-force loop."""
+    import numpy as np
+    from ader_amd import dist as adist
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_eng_src", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                           "ader_amd", "engine.py"))
+    src = open(spec.origin).read()
+    ns = {"np": np}
+    start = src.index("def pack_counts_host(")
+    exec(src[start:src.index("class Engine:")], ns)            # (the function is pure numpy; importing the module needs the HIP library)
+    rs = np.random.RandomState(0)
+    n, T, W, S = 37, 5, 4, 16
+    seq = rs.randint(0, 70, size=(n, T)).astype(np.int32)
+    pos = rs.randint(1, 70, size=n).astype(np.int32)
+    ids = adist.global_ids_host(seq, pos, W)
+    per = -(-n // W)
+    assert ids.shape == (W, per * T + per)
+    for r in range(W):
+        lo, hi = adist.shard_bounds(n, W, r)
+        assert ids[r, :(hi - lo) * T].tolist() == seq[lo:hi].reshape(-1).tolist()
+        assert ids[r, per * T:per * T + (hi - lo)].tolist() == pos[lo:hi].tolist()
+        assert not ids[r, (hi - lo) * T:per * T].any() and not ids[r, per * T + (hi - lo):].any()      # padding rows: id 0, label 0
+    C_all, C_pos = ns["pack_counts_host"](ids, per * T, S)
+    for o in range(W):
+        for d in range(W):
+            own = [(min((i - 1) // S, W - 1) if i > 0 else -1) for i in ids[d].tolist()]
+            assert C_all[o][d] == sum(1 for x in own if x == o)
+            assert C_pos[o][d] == sum(1 for x in own[:per * T] if x == o)

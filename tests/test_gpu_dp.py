@@ -63,7 +63,12 @@ def _worker(rank, world, port, out, logits, sharded, B=B):
     lo, hi = adist.shard_bounds(B, world, rank)
     for step in range(2):
         dp.set_rows(lo, N)
-        eng.train_step(seq[lo:hi], pos[lo:hi], N, 5e-4, rate=0.3, n_train_global=B)
+        # packed exchange: step 0 gets the global batch's ids on the host (split sizes computed there: no device-to-host sync),
+        # step 1 lets the engine read the counts back from csrc/pack_plan.hip (one sync) -- both must give the single-process step
+        kw = {"ids_host": adist.global_ids_host(seq, pos, world)} if (sharded == "catalog_packed" and step == 0) else {}
+        eng.train_step(seq[lo:hi], pos[lo:hi], N, 5e-4, rate=0.3, n_train_global=B, **kw)
+        if sharded == "catalog_packed":
+            assert eng.comm_syncs == (0 if step == 0 else 1)
     eng.sync_table()       # catalog mode: the other ranks' rows come back only on request
     torch.cuda.synchronize()
     if rank == 1:          # the last rank: its own table shard and the gathered ones must both be right
@@ -135,13 +140,17 @@ def _kd_data():
     return seq, pos, ex_seq, teacher, trow
 
 
-def _kd_worker(rank, world, port, out, logits):
+def _kd_worker(rank, world, port, out, logits, mode="replicated"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ader_amd import dist as adist
     seq, pos, ex_seq, teacher, trow = _kd_data()
     eng = _engine(logits, rank, world)
     dp = adist.DataParallel(eng, rank, world)
+    if mode != "replicated":                     # distilled steps on the catalog-sharded table (dense / packed row exchange)
+        eng.dp_mode = "catalog"
+        eng.dp_pack = mode == "catalog_packed"
+        _poison_allocator()
     lo, hi = adist.shard_bounds(B, world, rank)
     elo, ehi = adist.shard_bounds(N_EX, world, rank)
     tch = torch.from_numpy(teacher).cuda()
@@ -149,6 +158,7 @@ def _kd_worker(rank, world, port, out, logits):
         dp.set_rows(lo, N, ex_row0=B + elo)
         eng.train_step(np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]), pos[lo:hi], N, 5e-4, rate=0.3, teacher=tch,
                        ex_trow=trow[elo:ehi], lambda_=0.6, n_train_global=B, n_ex_global=N_EX)
+    eng.sync_table()
     torch.cuda.synchronize()
     if rank == 1:
         torch.save(eng.theta.cpu(), out)
@@ -156,20 +166,24 @@ def _kd_worker(rank, world, port, out, logits):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("logits", ["f32", "bf16", "x3"])
-def test_two_ranks_distilled_step_matches_single_process(logits):
+@pytest.mark.parametrize("logits,mode", [("f32", "replicated"), ("bf16", "replicated"), ("x3", "replicated"), ("x3", "catalog"),
+                                         ("x3", "catalog_packed")])
+def test_two_ranks_distilled_step_matches_single_process(logits, mode):
     """ADER-mode step under data parallelism (main.py:223-256 with the rows of BOTH sub-batches sharded, losses scaled by the
     global sub-batch sizes, dense gradient all-reduce): two ranks == one process on the whole batch.  Dropout ON: the counters of
     both row segments of a shard (its train rows, its exemplar rows) are keyed by their global rows (AderDrop.split / base2), so
-    the two ranks draw exactly the masks of the single process.  bf16 / x3: the ranks take the flash forward with the table gradient
-    written out (ader_tab_grad_kd) and reduced; the single process takes the fused update."""
+    the two ranks draw exactly the masks of the single process.  bf16 / x3 replicated: the ranks take the flash forward with the table
+    gradient written out (ader_tab_grad_kd) and reduced; the single process takes the fused update.  x3 catalog / catalog_packed: the
+    distilled step on the catalog-sharded table -- exemplar rows as a second block of the global batch, student partials over the
+    rank's items below Np, teacher readout summed shard by shard, fused KD update on the rank's tile range (nothing table-sized is
+    exchanged); allocator poisoned with NaNs so that an unwritten pad row shows."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "theta.pt")
-        mp.spawn(_kd_worker, args=(2, port, out, logits), nprocs=2, join=True)
+        mp.spawn(_kd_worker, args=(2, port, out, logits, mode), nprocs=2, join=True)
         got = torch.load(out).numpy()
     seq, pos, ex_seq, teacher, trow = _kd_data()
     eng = _engine(logits)
@@ -349,9 +363,11 @@ def _y_worker(rank, world, port, out):
     eng.dp_mode = "catalog"                      # the `bench.py --gpus N` default; 8 ranks: packed (uneven) row exchange by default
     lo, hi = adist.shard_bounds(Y_B, world, rank)
     assert hi - lo == 512
+    ids_host = adist.global_ids_host(seq, pos, world)      # every rank builds the same global batch: split sizes without a sync
     for step in range(2):
         dp.set_rows(lo, Y_N)
-        eng.train_step(seq[lo:hi], pos[lo:hi], Y_N, 5e-4, rate=0.3, n_train_global=Y_B)
+        eng.train_step(seq[lo:hi], pos[lo:hi], Y_N, 5e-4, rate=0.3, n_train_global=Y_B, ids_host=ids_host)
+        assert eng.dp_pack and eng.comm_syncs == 0
     eng.sync_table()
     torch.cuda.synchronize()
     if rank == world - 1:
@@ -382,3 +398,120 @@ def test_eight_ranks_global_batch_4096_at_the_yoochoose_catalog_match_single_pro
     d = np.abs(got - ref)
     # (bounds of test_two_ranks_match_single_process at > 1024 rows: elements whose gradient is ~eps may move by +-lr per step)
     assert np.mean(d < 5e-6) > 0.995 and d.max() < 2.5e-3, (np.mean(d < 5e-6), d.max())
+
+
+# ---- configs[3] is an ADER run: from period 2 on every step carries distilled exemplar rows (main.py:223-256)
+Y_EX, Y_NP, Y_TROWS = 816, 24000, 600        # 8 x 102 exemplar rows per step (cfg-Y 512 + ~102 per 512 train rows); teacher [600, Np]
+
+
+def _y_kd_data():
+    rs = np.random.RandomState(13)
+    seq, pos = _y_data()
+    ex_seq = np.zeros((Y_EX, T), dtype=np.int32)
+    ln = np.clip(rs.geometric(0.2, size=Y_EX), 1, T)
+    for b in range(Y_EX):
+        ex_seq[b, T - ln[b]:] = rs.randint(1, Y_NP + 1, size=ln[b])
+    teacher = (rs.standard_normal((Y_TROWS, Y_NP)) * 2.0).astype(np.float32)
+    trow = rs.randint(0, Y_TROWS, size=Y_EX).astype(np.int32)
+    return seq, pos, ex_seq, teacher, trow
+
+
+def _y_kd_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ader_amd import dist as adist
+    seq, pos, ex_seq, teacher, trow = _y_kd_data()
+    eng = _y_engine(rank, world)
+    dp = adist.DataParallel(eng, rank, world)
+    eng.dp_mode = "catalog"
+    lo, hi = adist.shard_bounds(Y_B, world, rank)
+    elo, ehi = adist.shard_bounds(Y_EX, world, rank)
+    assert hi - lo == 512 and ehi - elo == 102
+    tch = torch.from_numpy(teacher).cuda()
+    # step 0: a vanilla step, steps 1, 2: distilled steps -- all three on the catalog-sharded table (packed row exchange: the 8-rank
+    # default), the rows of BOTH sub-batches sharded, exemplar rows as the second block of the global batch
+    dp.set_rows(lo, Y_N)
+    eng.train_step(seq[lo:hi], pos[lo:hi], Y_N, 5e-4, rate=0.3, n_train_global=Y_B)
+    for step in range(2):
+        dp.set_rows(lo, Y_N, ex_row0=Y_B + elo)
+        eng.train_step(np.concatenate([seq[lo:hi], ex_seq[elo:ehi]]), pos[lo:hi], Y_N, 5e-4, rate=0.3, teacher=tch,
+                       ex_trow=trow[elo:ehi], lambda_=0.9, n_train_global=Y_B, n_ex_global=Y_EX)
+    eng.sync_table()
+    torch.cuda.synchronize()
+    eng.check_status()
+    if rank == world - 1:
+        torch.save({"theta": eng.theta.cpu()[:(Y_ITEMS + 1) * H], "loss": float(eng.loss.item())}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_yoochoose_ader_steps_with_distilled_rows_match_the_oracle():
+    """BASELINE.json configs[3] is "YOOCHOOSE ADER": its steps carry exemplar rows distilled against stored teacher logits
+    (ADER.py:132-137, main.py:223-256).  EIGHT ranks share cuda:0 (gloo), 512 train + 102 exemplar rows each (global 4,096 + 816: more
+    rows than ONE process may put into a step, so the reference here is the CPU restatement), YOOCHOOSE's catalog: one vanilla step on
+    the catalog-sharded table, then two distilled steps on it as well (student partials over each rank's items below Np, teacher readout
+    summed shard by shard, fused KD update per tile range), dropout on.  Against three full-batch float32 oracle steps with the same
+    counter-keyed masks; the last distilled loss must agree as well."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "theta.pt")
+        mp.spawn(_y_kd_worker, args=(Y_W, port, out), nprocs=Y_W, join=True)
+        res = torch.load(out)
+    got, loss_got = res["theta"].numpy(), res["loss"]
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import ader_ref_cpu as R
+    seq, pos, ex_seq, teacher, trow = _y_kd_data()
+    eng0 = _y_engine()
+    params = {k: v.to(torch.float32) for k, v in eng0.export_params().items()}
+    del eng0
+    opt = R.TFAdam(params)
+    R.train_step(params, opt, seq, pos, Y_N, L, HEADS, 5e-4, training=True, rate=0.3, seed=4, step=0)
+    ol = None
+    for step in (1, 2):
+        ol = R.train_step(params, opt, np.concatenate([seq, ex_seq]), pos, Y_N, L, HEADS, 5e-4, training=True, rate=0.3, seed=4, step=step,
+                          ex_logits=torch.from_numpy(teacher[trow]), lambda_=0.9)
+    assert abs(loss_got - ol) < 2e-4 * max(1.0, abs(ol)), (loss_got, ol)
+    do = np.abs(got - params["emb"].numpy().reshape(-1)[:(Y_ITEMS + 1) * H])
+    # (bounds of test_two_ranks_match_single_process for x3 beyond 1,024 rows: Adam moves an element whose gradient is ~eps by up to
+    #  +-lr per step when the ~1e-5 relative difference of the bf16x3 products flips its sign)
+    assert do.max() < 1.6e-3 and np.mean(do < 2e-5) > 0.99, (do.max(), np.mean(do < 2e-5))
+
+
+def test_pack_plan_kernel_against_numpy():
+    """csrc/pack_plan.hip (the index bookkeeping of the packed catalog exchange in one launch) against a brute-force numpy
+    restatement: owner x destination counts, the send list in (destination, position) order, the permutation of a rank's positions
+    (padding first, then by owner, stable) and the gradient-return lists; W = 8 and 3, a shard that owns nothing, ids beyond the last
+    shard (clamped to the last owner), padding everywhere.  Index work: exact."""
+    from ader_amd import _lib
+    from ader_amd.engine import pack_counts_host
+    rs = np.random.RandomState(3)
+    for W, n_pos, n_lab, S, hi_id in ((8, 5000, 100, 128 * 7, 128 * 7 * 8 + 40), (3, 333, 7, 128, 300), (2, 64, 64, 256, 400)):
+        n_all = n_pos + n_lab
+        ids = rs.randint(0, hi_id + 1, size=(W, n_all)).astype(np.int32)
+        ids[rs.rand(W, n_all) < 0.5] = 0                                        # left padding of real sessions: half the positions
+        ids_d = torch.from_numpy(ids).cuda()
+        own = np.where(ids > 0, np.minimum((ids - 1) // S, W - 1), -1)
+        C_all, C_pos = pack_counts_host(ids, n_pos, S)
+        for r in range(W):
+            cnt = torch.zeros(2, W, W, dtype=torch.int32, device="cuda")
+            send, back = torch.zeros(W * n_all, dtype=torch.int64, device="cuda"), torch.zeros(W * n_all, dtype=torch.int64, device="cuda")
+            perm, bsrc = torch.zeros(n_all, dtype=torch.int64, device="cuda"), torch.zeros(n_pos, dtype=torch.int64, device="cuda")
+            _lib.call("ader_pack_plan", ids_d.data_ptr(), W, n_all, n_pos, r, S, cnt.data_ptr(), send.data_ptr(), back.data_ptr(),
+                      perm.data_ptr(), bsrc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            c = cnt.cpu().numpy()
+            assert c[0].tolist() == C_all and c[1].tolist() == C_pos
+            flat_own, flat_ids = own.reshape(-1), ids.reshape(-1)
+            mine = np.nonzero(flat_own == r)[0]
+            assert send[:len(mine)].cpu().numpy().tolist() == flat_ids[mine].tolist()
+            mine_pos = mine[(mine % n_all) < n_pos]
+            assert back[:len(mine_pos)].cpu().numpy().tolist() == flat_ids[mine_pos].tolist()
+            key = own[r]
+            exp_perm = np.concatenate([np.nonzero(key == k)[0] for k in range(-1, W)])
+            assert perm.cpu().numpy().tolist() == exp_perm.tolist()
+            exp_bsrc = np.concatenate([np.nonzero(key[:n_pos] == k)[0] for k in range(W)])
+            assert bsrc[:len(exp_bsrc)].cpu().numpy().tolist() == exp_bsrc.tolist()
