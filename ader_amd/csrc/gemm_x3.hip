@@ -499,10 +499,14 @@ int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, flo
 // Batched form: n <= 16 products dW[i] = A[i]^T . G[i] (M[i] rows each), db[i] = colsum(G[i]) (db[i] may be NULL), one
 // product launch + one reduce launch.  Host arrays of device pointers.  slab: ader_gemm_atb_batch_slabs(M, n)*160*160
 // floats.  Workgroups are shared out in proportion to the rows of each product (about one per CU in total).
-static bool atb_small() {                 // ADER_ATB=big: the 86 KB form (A/B)
+static bool atb_small() {                 // (diagnostic builds, -DADER_DIAG: ADER_ATB=big selects the 86 KB form for A/B runs)
+#ifdef ADER_DIAG
     static int v = -1;
     if (v < 0) { const char* e = getenv("ADER_ATB"); v = (e && !strcmp(e, "big")) ? 0 : 1; }
     return v == 1;
+#else
+    return true;
+#endif
 }
 static void atb_batch_plan(const int* M, int n, int* wg0) {
     const int tm = atb_small() ? SM_TM : TM;

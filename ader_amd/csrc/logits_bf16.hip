@@ -807,10 +807,15 @@ int lx3h_launch(const Lx3Args& x, void* stream);
 int lx3p_launch(const Lx3Args& x, void* stream);
 // ADER_X3_FWD = old | f | g | h | p: the round-2 kernel (k_lx3_fwd), the 16-row 16x16x32 form (k_lx3f), the 32x32x16 form (k_lx3g), the
 // 32-row 16x16x32 form (k_lx3h) or k_lx3g with the softmax / staging vector work inside the MFMA phases (k_lx3p; default, H = 150)
+// (read only by diagnostic builds, -DADER_DIAG: a production build takes no kernel choice from the environment)
 static int lx3_env() {
+#ifdef ADER_DIAG
     static int v = -1;
     if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 4 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'h' ? 3 : (e[0] == 'g' ? 2 : 4)))); }
     return v;
+#else
+    return 4;
+#endif
 }
 static int lx3_kind(int H, int Bp) {
     const int v = lx3_env();

@@ -276,8 +276,9 @@ class Engine:
         self.bf16_update = "sh"
         # x3 mode, fused table update: "tab16" = k_tab16x3 (16x16x32 tiles, three workgroups per CU, rep chunks by LDS-DMA as
         # conflict-free LDS images: the faster form), "tab32" = the round-2 kernel k_tab_upd<X3> (kept for kernel-vs-kernel tests)
-        self.x3_update = os.environ.get("ADER_X3_UPDATE", "tab16")
+        self.x3_update = "tab16"     # (an attribute, not an environment variable: a stray setting must not switch kernels)
         self._table_stale = False
+        self._pending_loss, self._img_ready = None, False     # late loss sum / operand images of a deferred fused update
         self._mv_sharded = False   # dp: Adam m/v of the table are current only for the rank's own rows (see _gather_if_sharded)
         # raw device addresses of every parameter / gradient tensor (the flat buffers never move)
         self._pp = {k: self.theta.data_ptr() + 4 * off for k, (off, _) in self.layout.items()}
@@ -720,8 +721,14 @@ class Engine:
         """Forward + backward of one step (no optimiser).  seq [B,T] holds the train rows first and the exemplar rows
         after (main.py:229); pos [n_train]; exemplars are either distilled (teacher [*,Np] + ex_trow [n_ex] row indices,
         ADER.py:132-137) or one-hot (ex_pos [n_ex], ADER.py:126-131).  Leaves the loss in self.loss (device scalar) and
-        the gradient of every parameter in self.grad."""
+        the gradient of every parameter in self.grad.  (_defer_table, the fused-update form train_step uses: the loss scalar is
+        summed beside the table update, so self.loss is final only after _fused_table_adam -- or the next call here.)"""
         self._refresh_stream()
+        if self._pending_loss is not None:
+            # a deferred step whose fused update never ran (an exception between the two calls, or loss_and_grad(_defer_table=True)
+            # used on its own): its loss sum is still owed -- settle it before the row losses are overwritten
+            call("ader_lbf_sum", ptr(self._pending_loss[0]), self._pending_loss[1], ptr(self.loss), self._stream())
+            self._pending_loss = None
         seq = self._dev_i32(seq)
         pos = self._dev_i32(pos)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
@@ -1150,7 +1157,7 @@ class Engine:
         span = self.layout["pos"][0]
 
         def small_update():     # everything that feeds / is the update of the non-table parameters
-            pl_ = getattr(self, "_pending_loss", None)
+            pl_ = self._pending_loss
             if pl_ is not None:
                 call("ader_lbf_sum", ptr(pl_[0]), pl_[1], ptr(self.loss), self._stream())
                 self._pending_loss = None
@@ -1175,7 +1182,7 @@ class Engine:
         with self._sec("logits_bwd_adam"):
             if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
                 img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", D["Bp"]),), torch.uint8, zero=True)
-                if not (getattr(self, "_img_ready", False) and not D.get("kd")):
+                if not (self._img_ready and not D.get("kd")):
                     call("ader_x3_rep_image", ptr(D["rep_bf"]), ptr(D["rep_lo"]), D["Bp"], ptr(img), st)
                 self._img_ready = False
             if self.lx3 and D.get("kd"):

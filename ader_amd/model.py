@@ -175,13 +175,19 @@ class Session:
                 rep = e.encode(seq) if rep is None else rep
                 out.append(e.logits_from_rep(rep, int(feed["max_item"])).cpu().numpy())
             elif n == "pred_last":
+                # pred_last = argsort(argsort(-test_logits)) (ADER.py:99-103): the 0-based rank of EVERY item, ties -> lower index
+                # first.  rank(i) = #{j: l_j > l_i} + #{j < i: l_j == l_i}: from one sort and its run starts, no second sort.
                 items = np.asarray(feed["test_item"], dtype=np.int64)
-                N = int(items.max())
-                assert np.array_equal(items, np.arange(1, N + 1)), "predict() ranks the contiguous catalog 1..N (util.py:323)"
+                N = int(items.max()) if items.size else 0
+                if items.size == 0 or not np.array_equal(items, np.arange(1, N + 1)):
+                    raise RuntimeError("predict(): test_item must be the contiguous catalog 1..N (the reference's only call site, "
+                                       "util.py:323)")
                 rep = e.encode(seq) if rep is None else rep
                 lg = e.logits_from_rep(rep, N)
-                order = torch.argsort(-lg, dim=-1, stable=True)           # ties -> lower index first
-                out.append(torch.argsort(order, dim=-1, stable=True).to(torch.int32).cpu().numpy())
+                order = torch.argsort(lg, dim=-1, descending=True, stable=True)          # ties keep index order
+                rk = torch.empty_like(order, dtype=torch.int32)
+                rk.scatter_(1, order, torch.arange(N, device=lg.device, dtype=torch.int32).expand_as(order))
+                out.append(rk.cpu().numpy())
             else:
                 raise KeyError("unsupported fetch %r" % n)
         return out[0] if single else out

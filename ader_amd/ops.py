@@ -95,6 +95,7 @@ def logits_ce_fwd(rep: torch.Tensor, shadow: torch.Tensor, labels: torch.Tensor,
     item_num = shadow.numel() // 168 - 1
     if not (1 <= N <= item_num) or labels.shape[0] != B or weights.shape[0] != B or H % 2:
         raise RuntimeError("ader::logits_ce_fwd: bad shapes (N=%d, item_num=%d, B=%d)" % (N, item_num, B))
+    _check_labels(labels, "logits_ce_fwd labels", N)
     Bp = (B + 127) // 128 * 128
     dev = rep.device
     lab, w = torch.zeros(Bp, dtype=torch.int32, device=dev), torch.zeros(Bp, device=dev)
@@ -437,6 +438,7 @@ def logits_ce(rep: torch.Tensor, emb: torch.Tensor, labels: torch.Tensor, weight
     B, H = rep.shape
     if emb.shape[1] != H or not (1 <= N <= emb.shape[0] - 1) or labels.shape[0] != B or weights.shape[0] != B or B > 1024:
         raise RuntimeError("ader::logits_ce: bad shapes")
+    _check_labels(labels, "logits_ce labels", N)
     dev = rep.device
     Bp, lab, ncol, w, trow, tlse = _rowinfo(labels, weights, N, dev)
     part = torch.empty(call("ader_logits_parts", N) * Bp * 3, device=dev)
@@ -455,7 +457,12 @@ def _(rep, emb, labels, weights, N):
 def logits_ce_bwd(rep: torch.Tensor, emb: torch.Tensor, labels: torch.Tensor, weights: torch.Tensor, lse: torch.Tensor,
                   N: int) -> tuple[torch.Tensor, torch.Tensor]:
     """-> (drep [B,H], demb [V,H]) for d loss = 1"""
+    _chk(rep, "rep", torch.float32, 2), _chk(emb, "emb", torch.float32, 2), _chk(labels, "labels", torch.int32, 1)
+    _chk(weights, "weights", torch.float32, 1), _chk(lse, "lse", torch.float32, 1)
     B, H = rep.shape
+    if emb.shape[1] != H or not (1 <= N <= emb.shape[0] - 1) or labels.shape[0] != B or weights.shape[0] != B or lse.shape[0] != B or B > 1024:
+        raise RuntimeError("ader::logits_ce_bwd: bad shapes")
+    _check_labels(labels, "logits_ce_bwd labels", N)
     dev = rep.device
     Bp, lab, ncol, w, trow, tlse = _rowinfo(labels, weights, N, dev)
     lse_p = torch.zeros(Bp, device=dev)

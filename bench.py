@@ -201,7 +201,7 @@ def main():
         eng_ = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=logits,
                       dp_rank=rank, dp_world=world)
         dp_ = adist.DataParallel(eng_, rank, world)
-        if world > 1 and logits in ("bf16", "x3") and not E:
+        if world > 1 and (logits == "x3" or (logits == "bf16" and not E)):     # (distilled rows on the sharded table: float32 grade)
             eng_.dp_mode = args.dp_mode
         dp_.set_rows(rank * B, N)
         return eng_
@@ -340,7 +340,7 @@ def main():
     comm_syncs = eng.comm_syncs if eng.dp_pack else 0
     exchange = ("none" if world == 1 else
                 ("catalog-sharded table: input rows all-to-all + representations all-gather + softmax partials all-to-all + gradient "
-                 "rows all-gather" if (dp_mode == "catalog" and args.logits in ("bf16", "x3") and not E) else
+                 "rows all-gather" if (dp_mode == "catalog" and (args.logits == "x3" or (args.logits == "bf16" and not E))) else
                  ("row-sharded table update + all-gather of the updated rows" if (eng.dp_sharded and eng.shadow is not None)
                   else "dense gradient all-reduce (table part started right after the logits backward, under the blocks backward)")))
 
@@ -360,7 +360,7 @@ def main():
         ms = dt / args.steps * 1e3
         x3 = args.logits == "x3"
         lpeak = BF16_MFMA_PEAK_TFLOPS if args.logits in ("bf16", "x3") else F32_MFMA_PEAK_TFLOPS
-        cat = world if (world > 1 and dp_mode == "catalog" and args.logits in ("bf16", "x3") and not E) else 1
+        cat = world if (world > 1 and dp_mode == "catalog" and (args.logits == "x3" or (args.logits == "bf16" and not E))) else 1
         # algorithmic work per launch (DESIGN.md "roofline accounting").  In the flash modes the forward launch also
         # produces dRep (softmax-weighted readout), so it is credited both GEMMs; recomputation and the 3x of the hi/lo split are
         # never credited.  Catalog-sharded N > 1: a rank streams N / world items for world * B rows -- the same products.

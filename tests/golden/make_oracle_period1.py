@@ -1,0 +1,106 @@
+"""Pin of the MODEL-MATH ORACLE against a value the reference itself publishes (build container only; ~10 CPU-minutes).
+
+TensorFlow cannot run here and the reference holds no test vectors for the model path, so oracle/ader_ref_cpu.py restates the
+TF graph from the call sites (parity "unpinned" at the op level).  What the reference DOES publish is the per-period test
+Recall@20 / MRR@20 of its runs (results.svg -> tests/golden/results_svg_curves.json).  Period 1 needs no exemplars and no
+previous state: it is plain training of the SASRec graph on the shipped split -- exactly what the oracle restates.  This script
+trains the ORACLE ITSELF (torch-CPU float32, autograd, TF-Adam; the reference's flags main.py:76-107: batch 256, lr 5e-4,
+dropout 0.3 -- or 0 with --finetune, main.py:141 --, early stopping on valid Recall@20 with patience 5, best epoch restored)
+on DIGINETICA period 1 with the host feeders (pinned bit-exactly by tests/golden/{sampler,split,dataloader}.*), evaluates the
+test sessions of period 1 and writes tests/golden/oracle_period1.json.  tests/test_oracle_model.py asserts the recorded numbers
+against the figure's period-1 points (ADER, Dropout and Joint are the same configuration in period 1: three reference runs).
+
+    python tests/golden/make_oracle_period1.py [--finetune] [--max-epochs N]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ader_amd.data import DataLoader, Evaluator, Sampler  # noqa: E402  (numpy-only host feeders)
+from oracle import ader_ref_cpu as R  # noqa: E402
+
+ITEM_NUM, T, H, L, HEADS = 43136, 50, 150, 2, 1           # main.py:133-134, 99-105
+
+
+class OracleModel:
+    """What Evaluator needs: the 0-based rank of the target among items 1..max_item (util.py:323-325), from the oracle's logits."""
+
+    def __init__(self, params):
+        self.params = params
+
+    def rank_targets(self, seq, pos, max_item):
+        with torch.no_grad():
+            rep = R.forward_rep(self.params, np.asarray(seq), L, HEADS)
+            logits = R.logits_from_rep(self.params, rep, max_item)
+            tgt = torch.as_tensor(np.asarray(pos), dtype=torch.long) - 1
+            t = logits.gather(1, tgt[:, None])
+            idx = torch.arange(max_item)[None, :]
+            return ((logits > t) | ((logits == t) & (idx < tgt[:, None]))).sum(1).numpy()      # ties: lower index first (ADER.py:103)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--finetune", action="store_true", help="dropout 0 (main.py:141): the Finetune / EWC configuration of period 1")
+    ap.add_argument("--max-epochs", type=int, default=100)
+    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    np.random.seed(0)
+    random.seed(0)
+    torch.manual_seed(0)                                   # main.py:123-125 (random_seed 0)
+    rate = 0.0 if args.finetune else 0.3
+    dl = DataLoader("DIGINETICA")
+    train_sess, _ = dl.train_loader(0)
+    smp = Sampler(train_sess, T, 256)
+    valid_subseq, _train_subseq = smp.split_data(valid_portion=0.1, return_train=True)
+    batch_num = smp.batch_num()
+    test_sess, _ = dl.evaluate_loader(1)
+    max_item = dl.max_item()
+    params = R.init_params(ITEM_NUM, T, H, L, seed=0)
+    opt = R.TFAdam(params)
+    model = OracleModel(params)
+    best, best_state, best_epoch, stop, step, log = 0.0, None, 1, 0, 0, []
+    t0 = time.time()
+    for epoch in range(1, args.max_epochs + 1):
+        for _ in range(batch_num):
+            seq, pos = smp.next_batch()
+            R.train_step(params, opt, seq, pos, max_item, L, HEADS, 5e-4, training=True, rate=rate, seed=0, step=step)
+            step += 1
+        ev = Evaluator(valid_subseq, True, T, 1024, max_item, "valid", model, None)
+        ev.evaluate(epoch)
+        perf = ev.results()[1]
+        log.append({"epoch": epoch, "valid_recall20": perf, "valid_mrr20": ev.results()[0], "seconds": round(time.time() - t0, 1)})
+        print(log[-1], flush=True)
+        if best >= perf:                                    # main.py:271-280
+            stop += 1
+            if stop >= 5:
+                break
+        else:
+            stop, best_epoch, best = 0, epoch, perf
+            best_state = {k: v.clone() for k, v in params.items()}
+    for k in params:
+        params[k].copy_(best_state[k])
+    ev = Evaluator(test_sess, False, T, 1024, max_item, "test", model, None)
+    ev.evaluate(best_epoch)
+    r = ev.results()
+    out = {"dataset": "DIGINETICA", "period": 1, "config": "finetune (dropout 0)" if args.finetune else "default (dropout 0.3)",
+           "max_item": max_item, "batch_num": batch_num, "best_epoch": best_epoch, "epochs_run": len(log), "steps": step,
+           "test": {"mrr20": r[0], "recall20": r[1], "mrr10": r[2], "recall10": r[3]}, "valid_log": log,
+           "torch": torch.__version__, "threads": args.threads, "minutes": round((time.time() - t0) / 60.0, 1)}
+    path = os.path.join(ROOT, "tests", "golden", "oracle_period1.json")
+    allr = json.load(open(path)) if os.path.exists(path) else {}
+    allr["finetune" if args.finetune else "default"] = out
+    json.dump(allr, open(path, "w"), indent=1)
+    print(json.dumps(out["test"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,30 +20,39 @@ def _batch():
     return seq, rs.randint(1, N + 1, size=B).astype(np.int32)
 
 
-def test_one_step_through_torch_ops_matches_the_engine():
+@pytest.mark.parametrize("rate", [0.0, 0.3])
+def test_one_step_through_torch_ops_matches_the_engine(rate):
+    """rate 0.3: every dropout site (prologue, attention probabilities, both FFN sites) is ON, with the engine's counter keys, so
+    the backward operators' mask REPLAY (embed_bwd, attn_bwd, ffn_bwd recompute the masks instead of storing them) is checked too."""
     import ader_amd.ops  # noqa: F401  (registers torch.ops.ader.*)
-    from ader_amd.engine import Engine
+    from ader_amd.engine import Engine, SITE_EMB, dropout_key, site_attn, site_ffn1, site_ffn2
     eng = Engine(ITEMS, maxlen=T, hidden_units=H, num_blocks=L, num_heads=HEADS, seed=5, logits_dtype="f32", gemm="f32")
     g = torch.Generator().manual_seed(1)
     for k in eng.layout:                 # LN beta away from 0: the query mask sign(|sum LN(x)|) must not hinge on rounding noise
         if k.endswith("_b"):
             eng.param(k).copy_(torch.randn(eng.layout[k][1], generator=g) * 0.1)
     seq_h, pos_h = _batch()
-    loss_e = float(eng.loss_and_grad(seq_h, pos_h, N, rate=0.0).item())
+    eng.global_step = 3
+    loss_e = float(eng.loss_and_grad(seq_h, pos_h, N, rate=rate).item())
     torch.cuda.synchronize()
+    thr = int(round(rate * 16777216.0))
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) if rate else 1.0
+
+    def dk(site):                        # (key, threshold, scale) of a site as Engine._drop builds them (seed 5, step 3)
+        return (dropout_key(5, 3, site), thr, scale) if rate else (0, 0, 1.0)
 
     p = {k: eng.param(k).detach().clone().requires_grad_(True) for k in eng.layout}
     seq = torch.from_numpy(seq_h).cuda()
     lab = torch.from_numpy(pos_h).cuda()
     A = torch.ops.ader
-    x = A.embed_fwd(seq, p["emb"], p["pos"], 0, 0, 1.0).reshape(B * T, H)
+    x = A.embed_fwd(seq, p["emb"], p["pos"], *dk(SITE_EMB)).reshape(B * T, H)
     for l in range(L):
         b = "b%d." % l
         q_in, _, _, kmask, qmask = A.layernorm(x, p[b + "ln1_g"], p[b + "ln1_b"])
         x1 = A.attn_fwd(x, q_in, p[b + "wq"], p[b + "bq"], p[b + "wk"], p[b + "bk"], p[b + "wv"], p[b + "bv"], kmask, qmask, B, T,
-                        HEADS, 0, 0, 1.0)[0]
+                        HEADS, *dk(site_attn(l)))[0]
         y = A.layernorm(x1, p[b + "ln2_g"], p[b + "ln2_b"])[0]
-        x = A.ffn_fwd(y, p[b + "w1"], p[b + "b1"], p[b + "w2"], p[b + "b2"], seq, 0, 0, 1.0, 0, 0, 1.0)[0]
+        x = A.ffn_fwd(y, p[b + "w1"], p[b + "b1"], p[b + "w2"], p[b + "b2"], seq, *dk(site_ffn1(l)), *dk(site_ffn2(l)))[0]
     x_last = x.view(B, T, H)[:, T - 1, :].contiguous()
     rep = A.layernorm(x_last, p["lnf_g"], p["lnf_b"])[0]
     w = torch.full((B,), 1.0 / B, device="cuda")
