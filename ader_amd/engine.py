@@ -774,6 +774,15 @@ class Engine:
         self._deferred = None
         # data-parallel shard with exemplar rows: its train rows and its exemplar rows sit at different global positions
         self.split_rows = n_train if (n_ex > 0 and getattr(self, "_ex_row0_set", False)) else None
+        if use_bf16 and not (kd_fast or kd_fast_unfused):
+            # the row descriptors of the flash logit kernels depend on the labels only: built BEFORE the forward stack (round 3: a
+            # 5 us launch + a launch gap between k_seq_fwd and the logit forward, on the critical path of every step)
+            Bb = n_train if split_kd else B            # rows of the bf16 / x3 path
+            Bp = (Bb + 127) // 128 * 128
+            lab, ncol = self.buf("ri_lab", (Bp,), torch.int32), self.buf("ri_ncol", (Bp,), torch.int32)
+            wrow, trow = self.buf("ri_w", (Bp,)), self.buf("ri_trow", (Bp,), torch.int32)
+            call("ader_build_rowinfo", ptr(pos), n_train, None if split_kd else ptr(ex_pos), None, 0 if split_kd else n_ex, N, 0,
+                 float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
         if kd_fast or kd_fast_unfused:
@@ -792,12 +801,6 @@ class Engine:
         drep = self.buf("drep", (B, H))
         extra = None
         if use_bf16:
-            Bb = n_train if split_kd else B            # rows of the bf16 path
-            Bp = (Bb + 127) // 128 * 128
-            lab, ncol = self.buf("ri_lab", (Bp,), torch.int32), self.buf("ri_ncol", (Bp,), torch.int32)
-            wrow, trow = self.buf("ri_w", (Bp,)), self.buf("ri_trow", (Bp,), torch.int32)
-            call("ader_build_rowinfo", ptr(pos), n_train, None if split_kd else ptr(ex_pos), None, 0 if split_kd else n_ex, N, 0,
-                 float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
             R = call("ader_lbf_ranges", N, Bp)
             rep_bf = self.buf("lbf_rep", (Bp * 168,), torch.bfloat16)
             rep_lo = self.buf("lbf_rep_lo", (Bp * 168,), torch.bfloat16) if self.lx3 else None

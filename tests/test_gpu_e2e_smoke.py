@@ -83,3 +83,25 @@ def test_two_data_parallel_ranks_of_the_driver_match_one_process():
     for (m1, r1), (m2, r2) in zip(ta, tb):
         assert abs(r1 - r2) < 0.01 and abs(m1 - m2) < 0.01, (ta, tb)
     assert abs(sa[0] - sb[0]) <= 0.02 * sa[0], (sa, sb)           # herding on slightly different representations
+
+
+def test_period_1_training_curve_tracks_the_oracle_epoch_by_epoch(golden_dir):
+    """End-to-end pin of the HIP path against the CPU oracle on real data: DIGINETICA period 1, float32 grade, the reference's default
+    flags, eight epochs.  tests/golden/oracle_period1.json holds the validation Recall@20 / MRR@20 the ORACLE reached epoch by epoch
+    when it was trained on the same split from the same initial parameters, the same batch order (host feeders, random_seed 0) and
+    the same counter-keyed dropout masks (tests/golden/make_oracle_period1.py).  Both follow the same trajectory up to float32
+    summation order: every epoch's validation metrics must agree within 0.8 point (observed: <= 0.5 while the curve climbs 6 -> 49 %)."""
+    import json
+    import re
+    from ader_amd import main as M
+    rec = json.load(open(os.path.join(golden_dir, "oracle_period1.json")))["default"]["valid_log"]
+    with tempfile.TemporaryDirectory() as d:
+        args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--max_periods", "1", "--num_epochs", "8", "--results_root", d])
+        M.run(args, log=lambda s="": None)
+        text = open(os.path.join(d, "DIGINETICA-ADER", "Training_logs.txt")).read()
+    got = [(float(m20), float(r20)) for m20, r20 in re.findall(r"epoch:\d+, valid \(MRR@20: ([0-9.]+), RECALL@20: ([0-9.]+)", text)]
+    assert len(got) == 8
+    for e, (m20, r20) in enumerate(got):
+        assert abs(r20 - rec[e]["valid_recall20"]) <= 0.008, (e + 1, r20, rec[e]["valid_recall20"])
+        assert abs(m20 - rec[e]["valid_mrr20"]) <= 0.008, (e + 1, m20, rec[e]["valid_mrr20"])
+    assert got[-1][1] > 0.48          # (the curve has reached its plateau: ~49.6 % at epoch 8)

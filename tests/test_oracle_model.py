@@ -2,6 +2,8 @@
 vectors for the TF graph and TensorFlow cannot run here, so these are the hand-derived cases of
 SURVEY section 4 plus fp64 finite differences -- they pin the restatement's internal consistency, not
 TF output ("parity unpinned" for the model math)."""
+import os
+
 import numpy as np
 import torch
 
@@ -134,3 +136,24 @@ def test_rank_matches_double_argsort():
         for t in (1, 7, 20):
             assert R.rank_of_target(lg[b], t) == ranks[b, t - 1]
     assert R.metrics([0, 9, 10, 19, 20]) == (sum(1 / (r + 1) for r in (0, 9, 10, 19)) / 5, 4 / 5, (1 + 0.1) / 5, 2 / 5)
+
+
+def test_oracle_trained_on_period_1_lands_on_the_published_curve(golden_dir):
+    """The only reference-held values the ORACLE ITSELF can be checked against: the figure's period-1 points (results.svg ->
+    results_svg_curves.json).  tests/golden/make_oracle_period1.py trained oracle/ader_ref_cpu.py (torch-CPU float32, TF-Adam, the
+    reference's flags and early stopping, the golden-pinned host feeders) on DIGINETICA period 1 in the build container (13 CPU
+    minutes) and recorded its test metrics; period 1 of ADER, Dropout and Joint is one and the same configuration (vanilla loss,
+    dropout 0.3), i.e. three independent runs of the reference: 49.45 / 49.17 / 49.21 Recall@20, 17.71 / 17.63 / 17.66 MRR@20.
+    The oracle must land inside that cloud (+- 0.35 point around its mean: the reference's own spread is 0.28)."""
+    import json
+    rec = json.load(open(os.path.join(golden_dir, "oracle_period1.json")))["default"]
+    curves = json.load(open(os.path.join(golden_dir, "results_svg_curves.json")))["curves"]["DIGINETICA"]
+    r_ref = [curves[m]["recall20"][0] for m in ("ADER", "Dropout", "Joint")]
+    m_ref = [curves[m]["mrr20"][0] for m in ("ADER", "Dropout", "Joint")]
+    r20, m20 = 100.0 * rec["test"]["recall20"], 100.0 * rec["test"]["mrr20"]
+    assert rec["max_item"] == 18569 and rec["batch_num"] == 196 and rec["steps"] == rec["epochs_run"] * 196
+    assert abs(r20 - sum(r_ref) / 3) <= 0.35, (r20, r_ref)
+    assert abs(m20 - sum(m_ref) / 3) <= 0.35, (m20, m_ref)
+    # the validation curve rises monotonically to its best epoch and early stopping ran its 5 epochs of patience
+    v = [e["valid_recall20"] for e in rec["valid_log"]]
+    assert v.index(max(v)) + 1 == rec["best_epoch"] and rec["epochs_run"] == rec["best_epoch"] + 5
