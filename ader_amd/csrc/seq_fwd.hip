@@ -14,6 +14,24 @@
 // heads == 1, T <= 64, H even and <= 150 (the engine falls back to the per-op kernels otherwise).  gfx950 only.
 #include "seq_common.h"
 
+#ifdef SF_STAMP     // diagnostic build only (tools/build_variant.sh ... -DSF_STAMP): clocks per phase of waves 0 and 9 of each workgroup
+__device__ unsigned long long sf_dbg[2 * 40 * 1024];
+#define SFS_INIT unsigned long long seg[40], tprev; for (int i_ = 0; i_ < 40; ++i_) seg[i_] = 0; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#define SFS(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0); seg[k_] += t_ - tprev; tprev = t_; }
+#define SFB(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0); if (l == 0) seg[1 + k_] += t_ - tprev; else seg[17 + k_] += t_ - tprev; tprev = t_; }
+#define SFS_DUMP { if (lane == 0 && (wave == 0 || wave == 9) && blockIdx.x < 1024) for (int k_ = 0; k_ < 40; ++k_) \
+                       sf_dbg[(blockIdx.x * 2 + (wave == 9)) * 40 + k_] = seg[k_]; }
+extern "C" int ader_dbg_read_sf(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sf_dbg), (size_t)n * 8); }
+#else
+#define SFS_INIT
+#define SFS(k_)
+#define SFB(k_)
+#define SFS_DUMP {}
+#endif
+
 __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R0 = (bf16*)smem_raw;
@@ -30,6 +48,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
     const uint32_t H4 = (uint32_t)H * 4u;
     const uint32_t didx_row0 = (uint32_t)b * (uint32_t)T * (uint32_t)H;      // dropout counter of element (row0, 0)
     bf16x8 bh[10], bl[10];
+    SFS_INIT
     // per-block descriptors are indexed with a runtime l: read them straight from the kernarg segment (indexing the by-value
     // struct would make the compiler copy it to scratch)
     typedef const AderSeqBlock __attribute__((address_space(4))) * BlkPtr;
@@ -90,6 +109,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         load_bfrags((const bf16*)blks[0].w[0], nb, r, hh, bh, bl);       // Wq of block 0 (in flight across the barrier)
     }
     lds_barrier();
+    SFS(0)
     // ---- leading padding.  Sessions are left-padded (util.py:161-169); on real data ~90 % of the positions are padding.  A padded
     // position influences no real one -- its key is masked (modules.py:188-193), its outputs are re-zeroed (ADER.py:80) and its
     // gradient is exactly zero -- so rows [0, tv0) are skipped: no LayerNorm, no epilogue, no activation store (the backward
@@ -176,13 +196,16 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 }
             }
         }
+        SFB(0)
         lds_barrier();
         // ---- Q = LN(x).Wq + bq (modules.py:172) -> memory, hi/lo -> R1 (in place)
         {
             PHASE_IDS;
             PRUNE_IDS;
+            SFB(1)
             f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
             load_bfrags((const bf16*)k.w[1], nb, r, hh, bh, bl);
+            SFB(2)
             const Out o = make_out(k.Q, b, T, H, pruned);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
@@ -203,11 +226,13 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             }
 #undef Q_EPI
         }
+        SFB(3)
         // ---- K = x.Wk + bk (modules.py:173) -> memory, hi/lo -> R2 (the fp32 tile is dead)
         {
             PHASE_IDS;
             f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
             load_bfrags((const bf16*)k.w[2], nb, r, hh, bh, bl);
+            SFB(4)
             const Out o = make_out(k.K, b, T, H, false);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
@@ -221,11 +246,13 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 }
             }
         }
+        SFB(5)
         // ---- V = x.Wv + bv (modules.py:174) -> memory, hi/lo -> R0 (in place)
         {
             PHASE_IDS;
             f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
             const Out o = make_out(k.V, b, T, H, false);
+            SFB(6)
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
             bf16* Th = R0 + t0 * LDR + n;
@@ -239,7 +266,9 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 }
             }
         }
+        SFB(7)
         __syncthreads();        // full barrier: LN(x) rows written to memory by other waves are re-read after the attention
+        SFB(8)
         // ---- attention (modules.py:177-223).  Scores and softmax are computed ONCE per session by four waves -- wave (mq, kb)
         //      owns the 32x32 block S^T[keys 32kb..][queries 32mq..] (keys on the MFMA rows, the lane's query on the column, so a
         //      query's statistics are lane-local up to one exchange with the wave holding its other 32 keys) -- and the dropped
@@ -253,6 +282,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) qres[j] = bload(oq, boff0 + ROWJ(j) * H4);    // residual rows, added after P.V
         }
+        SFB(9)
         bf16* Ph = R1;                                   // [64 queries][LDP] hi, then lo: overlays the Q tile once S is done
         bf16* Pl = R1 + TR * LDP;
         {
@@ -331,10 +361,12 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 }
             }
         }
+        SFB(10)
         lds_barrier();
         {
             PHASE_IDS;
             f32x16 O;
+            SFB(11)
 #pragma unroll
             for (int j = 0; j < 16; ++j) O[j] = 0.0f;
             const int q4 = (lane_p & 15) >> 2, p4 = lane_p & 3, g1_ = (lane_p >> 4) & 1;
@@ -372,6 +404,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 bstore(o, boff0 + rjT * H4, v);
             }
         }
+        SFB(12)
         lds_barrier();
         // ---- LN2 (ADER.py:75): y -> memory, Xf (fp32, the FFN residual) and hi/lo -> R0
         {
@@ -417,6 +450,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
                 }
             }
         }
+        SFB(13)
         lds_barrier();
         // ---- h1 = dropout(relu(y.W1 + b1)) (modules.py:254-257) -> memory, hi/lo -> R1
         {
@@ -451,6 +485,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             }
 #undef F1_EPI
         }
+        SFB(14)
         lds_barrier();
         // ---- x2 = (dropout(h1.W2 + b2) + y) * (seq != 0) (modules.py:258-266, ADER.py:80)
         {
@@ -487,9 +522,11 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             }
 #undef F2_EPI
         }
+        SFB(15)
         lds_barrier();
 #undef k
     }
+    SFS(33)
     // ---- final LayerNorm of position T-1 (ADER.py:83-85) -> rep[b]
     if (wave == 0) {
         float x[3], y[3], mean, sd, xs, ys, gf[3], bf_[3];
@@ -502,6 +539,8 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         }
         if (lane == 0) { a.meanf[b] = mean; a.stdf[b] = sd; }
     }
+    SFS(34)
+    SFS_DUMP
 }
 
 static const size_t kSeqFwdLds = (size_t)3 * RSZ * sizeof(bf16) + (size_t)7 * TR * sizeof(float);

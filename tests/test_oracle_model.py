@@ -157,3 +157,12 @@ def test_oracle_trained_on_period_1_lands_on_the_published_curve(golden_dir):
     # the validation curve rises monotonically to its best epoch and early stopping ran its 5 epochs of patience
     v = [e["valid_recall20"] for e in rec["valid_log"]]
     assert v.index(max(v)) + 1 == rec["best_epoch"] and rec["epochs_run"] == rec["best_epoch"] + 5
+    # second configuration: dropout 0 (period 1 of the figure's Finetune and EWC curves: 46.31 / 46.19 Recall@20, 16.50 / 16.39 MRR)
+    ft = json.load(open(os.path.join(golden_dir, "oracle_period1.json")))["finetune"]
+    r_ft = [curves[m]["recall20"][0] for m in ("Finetune", "EWC")]
+    m_ft = [curves[m]["mrr20"][0] for m in ("Finetune", "EWC")]
+    assert ft["steps"] == ft["epochs_run"] * 196 and ft["epochs_run"] == ft["best_epoch"] + 5
+    assert abs(100.0 * ft["test"]["recall20"] - sum(r_ft) / 2) <= 0.35, (ft["test"], r_ft)
+    assert abs(100.0 * ft["test"]["mrr20"] - sum(m_ft) / 2) <= 0.35, (ft["test"], m_ft)
+    # and the oracle reproduces the reference's dropout effect at period 1 (about +3 points of Recall@20)
+    assert 2.0 <= r20 - 100.0 * ft["test"]["recall20"] <= 4.0

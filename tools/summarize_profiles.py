@@ -52,6 +52,19 @@ sq = {k: v for k, v in counters(os.path.join(src, "pmc_sq", "p_counter_collectio
 json.dump({"note": "rocprofv3 --pmc SQ_* (own pass, tools/profile_round.sh); per-launch sums over all waves.  SQ_WAVE_CYCLES, "
                    "SQ_WAIT_*, SQ_ACTIVE_INST_* are in units of 4 clocks; SQ_VALU_MFMA_BUSY_CYCLES in clocks summed over SIMDs.",
            "kernels": sq}, open(os.path.join(dst, "%s_pmc_sq.json" % tag), "w"), indent=1)
+tcc = collections.defaultdict(dict)
+for sub in ("pmc_tcc1", "pmc_tcc2", "pmc_tcc3"):
+    f = os.path.join(src, sub, "p_counter_collection.csv")
+    if os.path.exists(f):
+        for k, v in counters(f).items():
+            if "k_" in k:
+                tcc[k].update(v)
+if tcc:
+    json.dump({"note": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum / TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_32B_sum / "
+                       "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum (three own passes); per-launch sums over the L2 channels.  RDREQ = read "
+                       "requests the L2 sends to the fabric, RDREQ_DRAM = those routed to the memory controllers (the Infinity Cache "
+                       "sits behind that interface: its hits are not separable at the L2)", "kernels": tcc},
+              open(os.path.join(dst, "%s_pmc_tcc.json" % tag), "w"), indent=1)
 # profiles/CURRENT.json: which summaries bench.py may quote by default (with provenance)
 import subprocess
 cur_p = os.path.join(dst, "CURRENT.json")
