@@ -335,7 +335,7 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
                                                      float* __restrict__ drep, const float* __restrict__ emb1_f,
                                                      const float* __restrict__ rep_f) {
     __shared__ float sc[1024];          // per-range scale 2^(pm - M) (0 for empty ranges)
-    __shared__ float red[640];
+    __shared__ float red[640], red2[640];
     __shared__ float sM, sL;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int R = a.ranges, H = a.H;
@@ -377,22 +377,28 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
     const int t = lab[b] - 1;
     const float w = wrow[b];
     const int g = tid / 160, h = tid - g * 160;
-    float oh = 0.0f;
+    float oh = 0.0f, o2 = 0.0f;
     if (h < H) {
 #pragma unroll 8
         for (int i = g; i < R; i += 4) oh += a.pO[((size_t)i * a.Bp + b) * HP + h] * sc[i];
+        if (kd) {
+            // distilled row: the teacher readout O2 = sum_j softmax(t)_j E_j, range partials summed like the student's (four
+            // interleaved groups, fixed order; a single thread walking all ranges was 0.16 ms of dependent loads at 512 ranges)
+            const int Bk = a.Bp - a.kd_row0;
+#pragma unroll 8
+            for (int i = g; i < a.ranges2; i += 4) o2 += a.pO2[((size_t)i * Bk + (b - a.kd_row0)) * HP + h];
+        }
     }
     __syncthreads();
     red[tid] = oh;
+    red2[tid] = o2;
     __syncthreads();
     float part = 0.0f, et = 0.0f;
     if (tid < H) {
         oh = ((red[tid] + red[160 + tid]) + red[320 + tid]) + red[480 + tid];
         if (kd) {
-            // distilled row: the target "row" is the teacher readout O2 = sum_j softmax(t)_j E_j (range partials summed in fixed
-            // order) and  sum_j pt_j s_j = rep . O2  with the operands the MFMA path multiplied
-            const int Bk = a.Bp - a.kd_row0;
-            for (int i = 0; i < a.ranges2; ++i) et += a.pO2[((size_t)i * Bk + (b - a.kd_row0)) * HP + tid];
+            // the target "row" of a distilled row is O2, and  sum_j pt_j s_j = rep . O2  with the operands the MFMA path multiplied
+            et = ((red2[tid] + red2[160 + tid]) + red2[320 + tid]) + red2[480 + tid];
             part = (X3 ? rep_f[(size_t)bc_ * H + tid] : (float)a.rep_bf[(size_t)b * LDR + tid]) * et;
         } else if (t >= 0) {                         // target logit with the same bf16-rounded operands as the MFMA path
             if (X3) { et = emb1_f[(size_t)t * H + tid]; part = rep_f[(size_t)bc_ * H + tid] * et; }
@@ -645,7 +651,12 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
         float tc[16], tn[16];
 #pragma unroll
         for (int s_ = 0; s_ < XRD; ++s_) if (s_ < nb_blocks) LX3_LOAD(s_, blk_begin + s_);
-        if (nb_blocks > 0) LBF_TLOAD(tc, blk_begin);
+#if defined(LX3RO_KO) && LX3RO_KO == 1
+#define RO_TLOAD(t_, blk_) { _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) t_[j_] = -3.0f; }
+#else
+#define RO_TLOAD(t_, blk_) LBF_TLOAD(t_, blk_)
+#endif
+        if (nb_blocks > 0) RO_TLOAD(tc, blk_begin);
         __syncthreads();
         int cur = 0, i = 0;
         while (i < nb_blocks) {
@@ -655,8 +666,10 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
                 const int blk = blk_begin + i;
                 const int i0 = blk * FB;
                 LX3_STORE(s_, cur);
+#if !(defined(LX3RO_KO) && LX3RO_KO == 2)
                 if (i + XRD < nb_blocks) LX3_LOAD(s_, blk + XRD);
-                if (i + 1 < nb_blocks) { LBF_TLOAD(tn, blk + 1); }
+#endif
+                if (i + 1 < nb_blocks) { RO_TLOAD(tn, blk + 1); }
                 __syncthreads();
                 const bf16* Eh = E_l + cur * 2 * FB * LDR;
                 f32x16 S;
@@ -669,6 +682,9 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
                 bf16x8 pl0, pl1;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { pl0[j] = (bf16)(S[j] - (float)pa0[j]); pl1[j] = (bf16)(S[8 + j] - (float)pa1[j]); }
+#if defined(LX3RO_KO) && LX3RO_KO == 3
+                if (a.H == 1)
+#endif
 #pragma unroll
                 for (int nb = 0; nb < 5; ++nb) {
                     const bf16* base = Eh + (4 * hh + q4) * LDR + 32 * nb + 16 * g1 + 4 * p4;
@@ -804,6 +820,9 @@ bool lx3f_supports(int H);
 int lx3f_launch(const Lx3Args& x, void* stream);
 int lx3g_launch(const Lx3Args& x, void* stream);
 int lx3h_launch(const Lx3Args& x, void* stream);
+// the teacher readout of distilled steps on k_lx3g's block images (k_lx3r); lx3r_supports: H = 150, 16-byte aligned teacher rows
+bool lx3r_supports(const Lx3Args& x);
+int lx3r_launch(const Lx3Args& x, void* stream);
 int lx3p_launch(const Lx3Args& x, void* stream);
 // ADER_X3_FWD = old | f | g | h | p: the round-2 kernel (k_lx3_fwd), the 16-row 16x16x32 form (k_lx3f), the 32x32x16 form (k_lx3g), the
 // 32-row 16x16x32 form (k_lx3h) or k_lx3g with the softmax / staging vector work inside the MFMA phases (k_lx3p; default, H = 150)
@@ -1093,7 +1112,8 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
                        kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
     if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
-    hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
+    if (lx3r_supports(x)) { rc = lx3r_launch(x, stream); if (rc) return rc; }
+    else hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        emb + H, rep);
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
@@ -1146,7 +1166,10 @@ __global__ __launch_bounds__(256) void k_lx3_sum_ranges(const float* __restrict_
     const int b = blockIdx.x, c = threadIdx.x;
     if (c >= PART_LD) return;
     float v = 0.0f;
-    if (c >= 2 && c - 2 < H) for (int i = 0; i < ranges; ++i) v += pO2[((size_t)i * Bk + b) * HP + (c - 2)];
+    if (c >= 2 && c - 2 < H) {
+#pragma unroll 8
+        for (int i = 0; i < ranges; ++i) v += pO2[((size_t)i * Bk + b) * HP + (c - 2)];
+    }
     part2[(size_t)b * PART_LD + c] = v;
 }
 int ader_lx3_readout_shard(const float* emb, int item_num, int Bk, int H, int Np, int item_begin, int item_count, const float* teacher,
@@ -1169,7 +1192,8 @@ int ader_lx3_readout_shard(const float* emb, int item_num, int Bk, int H, int Np
         x.kd_row0 = 0; x.Np = n_loc; x.teacher = teacher + item_begin; x.ldt = ldt; x.trow = trow; x.tlse2 = tlse2; x.pO2 = pO2;
         ranges2 = ader_lx3_readout_ranges(n_loc, Bk);
         x.ranges2 = ranges2;
-        hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * (Bk / 128)), dim3(256), (size_t)2 * 2 * FB * LDR * sizeof(bf16), st, x);
+        if (lx3r_supports(x)) { rc = lx3r_launch(x, stream); if (rc) return rc; }
+        else hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * (Bk / 128)), dim3(256), (size_t)2 * 2 * FB * LDR * sizeof(bf16), st, x);
     }
     hipLaunchKernelGGL(k_lx3_sum_ranges, dim3(Bk), dim3(256), 0, st, (const float*)pO2, ranges2, Bk, H, part2);
     HIP_LAUNCH_CHECK();

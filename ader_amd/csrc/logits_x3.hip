@@ -879,6 +879,188 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// k_lx3r: the TEACHER READOUT of a distilled step (ADER.py:132-137) as its own launch: O2[b,:] = sum_{j < Np} softmax(teacher_b)_j E_j
+// for the 128-row chunks of exemplar rows -- k_lx3g's readout half (same block images, same hand-pipelined transposed reads, same
+// 30 MFMAs per block and wave) fed by the teacher logits instead of an S phase: lane (row r32, half hh) loads the 16 teacher
+// logits of its accumulator positions (four 16-byte loads), p = exp2(t log2e - tlse2) is exact (the teacher's log-sum-exp is known),
+// split hi / lo.  HBM-bound (teacher tile + table block per 32 items): both streams run TWO blocks ahead of their use in registers
+// (table: two staging sets, converted into the third LDS buffer at the head of an iteration; teacher: two sets), and the block
+// barrier orders LDS traffic only -- __syncthreads would drain those loads.  Replaces k_lx3_fwd<2, 2, true> (logits_bf16.hip: one
+// block of lookahead, per-lane branches around the teacher loads; 0.30 ms against 0.2 at cfg-S + 128 exemplar rows) for H = 150,
+// 16-byte aligned teacher rows.  Output partials pO2 [range][Bk][160] as before.
+__global__ __launch_bounds__(256, 2) void k_lx3r(Lx3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [3 buffers][block image]
+    constexpr int H = 150;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int Bk = a.Bp - a.kd_row0;
+    const int nchunk = Bk / G3_ROWS;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot / nchunk);
+    const int bc = slot % nchunk;
+    if (range >= a.ranges2) return;
+    const int Np = a.Np;
+    const int nblk_all = (Np + F3_FB - 1) / F3_FB;
+    const int per = (nblk_all + a.ranges2 - 1) / a.ranges2;
+    const int blk_begin = range * per, blk_end = min(nblk_all, blk_begin + per);
+    const int nb_blocks = max(0, blk_end - blk_begin);
+    const int bk0 = bc * G3_ROWS + wave * 32;              // first exemplar row of the wave (row of the padded batch: + kd_row0)
+    for (int i = tid; i < 3 * X3B_IMG_B / 16; i += 256) ((uint4*)smem_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+    f32x16 O[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    // table staging: k_lx3g's memory-order mapping (lane -> item 8 wave + (l >> 3), 16-byte piece (l & 7) + 8 r of the row)
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.emb1, 0, a.vrows * H * 4, 0x00020000);
+    const int itb = 8 * wave + (lane >> 3), qb = lane & 7;
+    const int voffb = itb * (4 * H) + 16 * qb;
+    const int dstb = X3B_KC * (qb >> 1) + 16 * itb + 8 * (qb & 1);
+    f32x4_t sc[2][5];
+#define R3_LOAD(set_, blk_)                                                                               \
+    {                                                                                                     \
+        const int so_ = (blk_) * (F3_FB * 4) * H;                                                         \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r)                                                     \
+            sc[set_][r] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(trs, voffb + 128 * r, so_, 0)); \
+    }
+#define R3_STORE(set_, buf_)                                                                              \
+    {                                                                                                     \
+        unsigned char* dst_ = smem_raw + (buf_) * X3B_IMG_B;                                              \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                   \
+            const int p_ = qb + 8 * r;                                                                    \
+            float x_[4];                                                                                  \
+            x_[0] = (r == 4 && p_ >= 38) ? 0.f : sc[set_][r][0]; x_[1] = (r == 4 && p_ >= 38) ? 0.f : sc[set_][r][1]; \
+            x_[2] = (r == 4 && p_ >= 37) ? 0.f : sc[set_][r][2]; x_[3] = (r == 4 && p_ >= 37) ? 0.f : sc[set_][r][3]; \
+            bf16x4 h_, l_;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
+            *(bf16x4*)(dst_ + dstb + 4 * X3B_KC * r) = h_;                                                \
+            *(bf16x4*)(dst_ + X3B_PLANE_B + dstb + 4 * X3B_KC * r) = l_;                                  \
+        }                                                                                                 \
+    }
+    // teacher logits of this lane's accumulator positions: row r32, items 8 q + 4 hh + 0..3 of the block (register 4 q + k)
+    const int tr = a.trow[a.kd_row0 + bk0 + r32];
+    const float tl2 = a.tlse2[a.kd_row0 + bk0 + r32];
+    const float* trp = a.teacher + (size_t)(tr < 0 ? 0 : tr) * a.ldt + 4 * hh;
+    float tt[2][16];
+    // Everything inside the block loop is unconditional -- a load under a branch becomes a phi of two register sets (hipcc then spilled
+    // a whole staging set: loads straight into scratch).  Table blocks past the range are real rows (or zeros from the descriptor's
+    // range check) that are stored into a buffer nobody reads; teacher blocks are clamped to the last FULL block of [0, Np).  The one
+    // partial block of a launch (Np % 32 != 0; last range only) is peeled: element-wise clamped loads, validity applied to p.
+    const int nfull_all = Np / F3_FB;                      // >= 1 (launcher)
+#define R3_TLOAD(set_, blk_)                                                                              \
+    {                                                                                                     \
+        const int i0_ = min((blk_), nfull_all - 1) * F3_FB;                                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            const f32x4_t v_ = *(const f32x4_t*)(trp + i0_ + 8 * q);                                      \
+            tt[set_][4 * q] = v_[0]; tt[set_][4 * q + 1] = v_[1]; tt[set_][4 * q + 2] = v_[2]; tt[set_][4 * q + 3] = v_[3]; \
+        }                                                                                                 \
+    }
+#define R3_TSLOW(set_, blk_)                                                                              \
+    {                                                                                                     \
+        const int i0_ = (blk_) * F3_FB;                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                     \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                 \
+                tt[set_][4 * q + k] = trp[min(i0_ + 8 * q + k, Np - 1 - 4 * hh)];                         \
+    }
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int t_off = X3B_KC * (2 * g1 + (p4 >> 1)) + 16 * (4 * hh + q4) + 8 * (p4 & 1);
+#define R3_LOADT(set_, nb_, pl_)                                                                          \
+        { const bf16* tp_ = (const bf16*)(Bh + t_off + 4 * X3B_KC * (nb_) + (pl_) * X3B_PLANE_B);            \
+          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 64); set_[2] = tr_read(tp_ + 128); set_[3] = tr_read(tp_ + 192); }
+    const int nb_full = max(0, min(blk_end, nfull_all) - blk_begin);       // full blocks of this range (the rest: the partial one)
+    // prologue: blocks 0, 1 -> LDS buffers 0, 1; blocks 2, 3 -> staging sets 0, 1; teacher blocks 0, 1 -> sets 0, 1
+    R3_LOAD(0, blk_begin);
+    R3_LOAD(1, blk_begin + 1);
+    R3_TLOAD(0, blk_begin);
+    R3_TLOAD(1, blk_begin + 1);
+    __syncthreads();                                       // zero fill done
+    R3_STORE(0, 0);
+    R3_STORE(1, 1);
+    R3_LOAD(0, blk_begin + 2);
+    R3_LOAD(1, blk_begin + 3);
+    int bcur = 0;                                          // i % 3
+    // one iteration (block i, register sets e_ = i & 1): block i + 2 (requested two iterations ago) goes into the buffer block i - 1
+    // was read from, block i + 4 is requested; P from the teacher set, which is then refilled with block i + 2
+#define R3_ITER(e_)                                                                                       \
+    {                                                                                                     \
+        lds_only_barrier();                                /* blocks i, i + 1 in LDS; every wave is done with block i - 1 */ \
+        const int bnew = bcur == 0 ? 2 : bcur - 1;         /* (i + 2) % 3 */                              \
+        R3_STORE(e_, bnew);                                                                               \
+        R3_LOAD(e_, blk_begin + i + 4);                                                                   \
+        const char* Bh = (const char*)(smem_raw + bcur * X3B_IMG_B);                                      \
+        bf16x4 ft[3][4];                                                                                  \
+        R3_LOADT(ft[0], 0, 0);                                                                            \
+        R3_LOADT(ft[1], 0, 1);                                                                            \
+        R3_LOADT(ft[2], 1, 0);                                                                            \
+        f32x16 S;                                                                                         \
+        const int lim_ = (tr >= 0) ? Np - (blk_begin + i) * F3_FB - 4 * hh : 0;     /* items of this lane's positions inside [0, Np) */ \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
+            const float x_ = __builtin_amdgcn_exp2f(fmaf(tt[e_][j], LOG2E, -tl2));                        \
+            S[j] = ((j & 3) + 8 * (j >> 2) < lim_) ? x_ : 0.0f;                                           \
+        }                                                                                                 \
+        R3_TLOAD(e_, blk_begin + i + 2);                                                                  \
+        const bf16x8 pa0 = pack8(S, 0), pa1 = pack8(S, 1);                                                \
+        bf16x8 pl0, pl1;                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { pl0[j] = (bf16)(S[j] - (float)pa0[j]); pl1[j] = (bf16)(S[8 + j] - (float)pa1[j]); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        _Pragma("unroll") for (int hs = 0; hs < 10; ++hs) {                                               \
+            bf16x4* T_ = ft[hs % 3];                                                                      \
+            bf16x8 v0, v1;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { v0[j] = T_[0][j]; v0[4 + j] = T_[1][j]; v1[j] = T_[2][j]; v1[4 + j] = T_[3][j]; } \
+            if ((hs & 1) == 0) {                                                                          \
+                O[hs >> 1] = mfma_bf16(pl0, v0, O[hs >> 1]);                                              \
+                O[hs >> 1] = mfma_bf16(pl1, v1, O[hs >> 1]);                                              \
+                O[hs >> 1] = mfma_bf16(pa0, v0, O[hs >> 1]);                                              \
+                O[hs >> 1] = mfma_bf16(pa1, v1, O[hs >> 1]);                                              \
+            } else {                                                                                      \
+                O[hs >> 1] = mfma_bf16(pa0, v0, O[hs >> 1]);                                              \
+                O[hs >> 1] = mfma_bf16(pa1, v1, O[hs >> 1]);                                              \
+            }                                                                                             \
+            if (hs + 3 < 10) R3_LOADT(ft[hs % 3], (hs + 3) >> 1, (hs + 3) & 1);                           \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
+        bcur = bcur == 2 ? 0 : bcur + 1;                                                                  \
+        ++i;                                                                                              \
+    }
+    int i = 0;
+    while (i < nb_full) {
+        R3_ITER(0)
+        if (i >= nb_full) break;                           // workgroup-uniform
+        R3_ITER(1)
+    }
+    if (nb_blocks > nb_full) {                             // the partial block (its table rows are already on their way)
+        if (i & 1) { R3_TSLOW(1, blk_begin + i); R3_ITER(1) } else { R3_TSLOW(0, blk_begin + i); R3_ITER(0) }
+    }
+#undef R3_TSLOW
+#undef R3_ITER
+#undef R3_LOADT
+#undef R3_TLOAD
+#undef R3_STORE
+#undef R3_LOAD
+    float* o2 = a.pO2 + ((size_t)range * Bk + bk0) * HP;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o2[(size_t)acc_row(j, hh) * HP + 32 * nb + r32] = O[nb][j];
+}
+
+// teacher readout launch: x.ranges2 item ranges x (Bp - kd_row0) / 128 chunks.  false: the shape is not k_lx3r's (caller falls back)
+bool lx3r_supports(const Lx3Args& x) {
+    return x.H == 150 && x.Np >= F3_FB && (x.ldt & 3) == 0 && (((uintptr_t)x.teacher) & 15) == 0 && (long)(x.vrows + 5 * F3_FB) * x.H * 4 < (1l << 31);      // (block offsets are 32-bit; the stream runs 4 blocks ahead)
+}
+int lx3r_launch(const Lx3Args& x, void* stream) {
+    static bool f = false;
+    if (!f) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lx3r, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3B_IMG_B);
+        if (e != hipSuccess) return (int)e;
+        f = true;
+    }
+    hipLaunchKernelGGL(k_lx3r, dim3(x.ranges2 * ((x.Bp - x.kd_row0) / G3_ROWS)), dim3(256), 3 * X3B_IMG_B, (hipStream_t)stream, x);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // k_lx3h: k_lx3g's shape (128 batch rows per workgroup, 32 per wave, two workgroups per CU, three LDS block buffers, the block in
 // flight converted between the two MFMA phases) on v_mfma_f32_16x16x32_bf16 -- two 16-row blocks per wave share every LDS operand
 // fragment, so the LDS bytes per flop are those of the 32x32x16 form while the matrix instruction is the one the chip holds a

@@ -665,7 +665,10 @@ def test_split_kd_step_matches_all_f32_kd_step():
     assert np.abs(ta - tb).max() < 1.1e-3                 # one Adam step moves a parameter by at most lr
 
 
-@pytest.mark.parametrize("cfg,n_ex,Np", [(BF16_CFGS[1], 37, 4000), (BF16_CFGS[0], 70, 650), (BF16_CFGS[1], 200, 4321)])
+# (Np % 4 == 0: the teacher-readout kernel k_lx3r -- 4000: whole blocks; 4004: a 4-item partial block, two exemplar chunks; 648: one block
+#  per range, empty ranges, a partial block alone in its range; Np % 4 != 0: unaligned teacher rows -> the round-2 readout kernel)
+@pytest.mark.parametrize("cfg,n_ex,Np", [(BF16_CFGS[1], 37, 4000), (BF16_CFGS[0], 70, 650), (BF16_CFGS[1], 200, 4321),
+                                         (BF16_CFGS[1], 150, 4004), (BF16_CFGS[0], 70, 648)])
 def test_kd_fast_x3_step_matches_exact_oracle(cfg, n_ex, Np):
     """The all-flash distilled step at float32 grade (logits_dtype = x3): loss and the whole gradient (from Adam's first moment
     after one step, m = 0.1 g) against the plain float64 oracle of ADER.py:108-137 at the bounds of the exact-f32 kernels with
