@@ -266,13 +266,6 @@ struct AtbBatch {
     const float* A[ATB_MAX]; const float* G[ATB_MAX]; float* dW[ATB_MAX]; float* db[ATB_MAX];
     int M[ATB_MAX]; int wg0[ATB_MAX + 1]; int n;
 };
-__global__ __launch_bounds__(320) void k_gemm_atb_x3_batch(AtbBatch b, float* __restrict__ slab, int H) {
-    int y = 0;
-#pragma unroll 1
-    while (y + 1 < b.n && (int)blockIdx.x >= b.wg0[y + 1]) ++y;
-    atb_x3_body(b.A[y], b.G[y], slab + (size_t)blockIdx.x * HP * HP, b.M[y], H, blockIdx.x - b.wg0[y], b.wg0[y + 1] - b.wg0[y]);
-}
-
 // dW[y] = sum of product y's slabs (fixed order), row H of the augmented slab -> db[y].  grid (blocks of 64 outputs, n).
 __global__ __launch_bounds__(256) void k_atb_reduce_batch(AtbBatch b, const float* __restrict__ slab, int H) {
     __shared__ float red[16][16];     // 16 slab groups x 16 outputs: small workgroups that fit next to the table update
@@ -303,8 +296,8 @@ __global__ __launch_bounds__(256) void k_atb_reduce_batch(AtbBatch b, const floa
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Small-footprint form of the batched weight-gradient products: the one that runs INSIDE the fused table update.
-// k_gemm_atb_x3_batch (86 KB of LDS, 256 registers x 5 waves) can not share a CU with update workgroups (k_tab16x3: three per CU,
-// 168 registers, ~47 KB each), so it used to start when the update drained: a ~0.1 ms tail on every step.  This form is cut to the
+// The batched launch of atb_x3_body (86 KB of LDS, 256 registers x 5 waves; removed in round 4) could not share a CU with update
+// workgroups (three per CU, 168 registers, ~47 KB each), so it started when the update drained: a ~0.1 ms tail on every step.  This form is cut to the
 // hole ONE retiring update workgroup leaves: 256 threads, <= 168 registers, 43.5 KB of LDS, so the high-priority side stream gets
 // its workgroups placed as update workgroups retire.  32-row tiles (the K of one v_mfma_f32_16x16x32_bf16), operands stored as the
 // conflict-free hi / lo images of x3_image.h (both operands are read k-major: ds_read_b64_tr_b16), wave w owns output-channel
@@ -499,17 +492,8 @@ int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, flo
 // Batched form: n <= 16 products dW[i] = A[i]^T . G[i] (M[i] rows each), db[i] = colsum(G[i]) (db[i] may be NULL), one
 // product launch + one reduce launch.  Host arrays of device pointers.  slab: ader_gemm_atb_batch_slabs(M, n)*160*160
 // floats.  Workgroups are shared out in proportion to the rows of each product (about one per CU in total).
-static bool atb_small() {                 // (diagnostic builds, -DADER_DIAG: ADER_ATB=big selects the 86 KB form for A/B runs)
-#ifdef ADER_DIAG
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ADER_ATB"); v = (e && !strcmp(e, "big")) ? 0 : 1; }
-    return v == 1;
-#else
-    return true;
-#endif
-}
 static void atb_batch_plan(const int* M, int n, int* wg0) {
-    const int tm = atb_small() ? SM_TM : TM;
+    const int tm = SM_TM;
     long tiles_total = 0;
     for (int i = 0; i < n; ++i) tiles_total += (M[i] + tm - 1) / tm;
     wg0[0] = 0;
@@ -535,12 +519,6 @@ int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* 
     if (n <= 0) return 0;
     if (n > ATB_MAX) return -2;
     if (H >= HP || H < 2 || (H & 1) || H > 2 * PFA * 5) return -2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_atb_x3_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAtbX3Lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     AtbBatch b;
     for (int i = 0; i < n; ++i) {
         if (M[i] <= 0) return -2;
@@ -548,9 +526,8 @@ int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* 
     }
     b.n = n;
     atb_batch_plan(M, n, b.wg0);
-    if (atb_small() && H == 150) hipLaunchKernelGGL(k_gemm_atb_x3_sm<150>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
-    else if (atb_small()) hipLaunchKernelGGL(k_gemm_atb_x3_sm<0>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
-    else hipLaunchKernelGGL(k_gemm_atb_x3_batch, dim3(b.wg0[n]), dim3(320), kAtbX3Lds, (hipStream_t)stream, b, slab, H);
+    if (H == 150) hipLaunchKernelGGL(k_gemm_atb_x3_sm<150>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
+    else hipLaunchKernelGGL(k_gemm_atb_x3_sm<0>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_atb_reduce_batch, dim3(((H + 1) * H + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, b, slab, H);
     HIP_LAUNCH_CHECK();

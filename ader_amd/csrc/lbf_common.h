@@ -76,7 +76,7 @@ struct TabArgs {
     const float* teacher; long ldt; const int* trow; const float* tlse2;
 };
 
-// arguments of the x3 flash forward kernels (logits_bf16.hip: k_lx3_fwd, logits_x3.hip: k_lx3f)
+// arguments of the x3 flash forward kernels (logits_bf16.hip: k_lx3_fwd, logits_x3.hip: k_lx3g / k_lx3p / k_lx3r)
 struct Lx3Args {
     const float* emb1;          // fp32 table, row of item 1
     int vrows;                  // table rows available from emb1 (item_num)

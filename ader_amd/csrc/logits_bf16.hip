@@ -814,37 +814,32 @@ __global__ __launch_bounds__(256, OCC) void k_lx3_fwd(Lx3Args a) {
     }
 }
 
-// the 16x16x32 x3 forward of logits_x3.hip (k_lx3f): three workgroups per CU, conflict-free block images, no register ring
-int lx3f_ranges(int N, int Bp);
+// the x3 forwards of logits_x3.hip on conflict-free block images: k_lx3g (32x32x16, any supported H), k_lx3p (the same with the
+// vector work inside the MFMA phases; H = 150: the default) and the teacher readout of distilled steps k_lx3r
 bool lx3f_supports(int H);
-int lx3f_launch(const Lx3Args& x, void* stream);
 int lx3g_launch(const Lx3Args& x, void* stream);
-int lx3h_launch(const Lx3Args& x, void* stream);
-// the teacher readout of distilled steps on k_lx3g's block images (k_lx3r); lx3r_supports: H = 150, 16-byte aligned teacher rows
+int lx3p_launch(const Lx3Args& x, void* stream);
+// lx3r_supports: H = 150, 16-byte aligned teacher rows, at least one whole block
 bool lx3r_supports(const Lx3Args& x);
 int lx3r_launch(const Lx3Args& x, void* stream);
-int lx3p_launch(const Lx3Args& x, void* stream);
-// ADER_X3_FWD = old | f | g | h | p: the round-2 kernel (k_lx3_fwd), the 16-row 16x16x32 form (k_lx3f), the 32x32x16 form (k_lx3g), the
-// 32-row 16x16x32 form (k_lx3h) or k_lx3g with the softmax / staging vector work inside the MFMA phases (k_lx3p; default, H = 150)
+// ADER_X3_FWD = old | g | p: the round-2 kernel (k_lx3_fwd), k_lx3g, or k_lx3p (default; falls back to k_lx3g for H != 150)
 // (read only by diagnostic builds, -DADER_DIAG: a production build takes no kernel choice from the environment)
 static int lx3_env() {
 #ifdef ADER_DIAG
     static int v = -1;
-    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 4 : (e[0] == 'o' ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'h' ? 3 : (e[0] == 'g' ? 2 : 4)))); }
+    if (v < 0) { const char* e = getenv("ADER_X3_FWD"); v = !e ? 4 : (e[0] == 'o' ? 0 : (e[0] == 'g' ? 2 : 4)); }
     return v;
 #else
     return 4;
 #endif
 }
+// 2: the block-image kernels (Bp % 128 == 0 and a supported H), 0: k_lx3_fwd
 static int lx3_kind(int H, int Bp) {
-    const int v = lx3_env();
     if (!lx3f_supports(H)) return 0;
-    if (v == 1 && Bp % 64 == 0) return 1;
-    if (v >= 2 && Bp % 128 == 0) return 2;
-    return 0;
+    return (lx3_env() >= 2 && Bp % 128 == 0) ? 2 : 0;
 }
 static int lx3gh_launch(const Lx3Args& x, void* stream) {
-    return lx3_env() == 3 ? lx3h_launch(x, stream) : (lx3_env() == 4 ? lx3p_launch(x, stream) : lx3g_launch(x, stream));
+    return lx3_env() == 4 ? lx3p_launch(x, stream) : lx3g_launch(x, stream);
 }
 
 // ============================================================================================= C ABI
@@ -1058,13 +1053,13 @@ int ader_lx3_fwd_img(const float* rep, const float* emb, int item_num, int B, in
     Lx3Args x;
     x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
     const int nk = lx3_kind(H, Bp);
-    x.Bp = Bp; x.H = H; x.N = N; x.ranges = nk == 1 ? lx3f_ranges(N, Bp) : ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
+    x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
     x.kd_row0 = Bp; x.Np = 0; x.teacher = nullptr; x.ldt = 0; x.trow = nullptr; x.tlse2 = nullptr; x.pO2 = nullptr; x.ranges2 = 0;
     LbfArgs a;
     a.sh1 = nullptr; a.vrows = item_num; a.tile_off = 0; a.rep_bf = (const bf16*)rep_hi; a.B = B; a.Bp = Bp; a.H = H; a.N = N;
     a.ranges = x.ranges; a.pm = pm; a.pl = pl; a.pO = pO; a.off = nullptr; a.demb1 = nullptr; lbf_no_kd(a);
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H, (char*)rep_img);
-    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
+    if (nk) { rc = lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
     if (loss) hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);     // NULL: ader_lbf_sum later (off the critical path)
@@ -1100,7 +1095,7 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     Lx3Args x;
     x.emb1 = emb + H; x.vrows = item_num; x.rep_hi = (const bf16*)rep_hi; x.rep_lo = (const bf16*)rep_lo;
     const int nk = lx3_kind(H, Bp);
-    x.Bp = Bp; x.H = H; x.N = N; x.ranges = nk == 1 ? lx3f_ranges(N, Bp) : ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
+    x.Bp = Bp; x.H = H; x.N = N; x.ranges = ader_lbf_ranges(N, Bp); x.pm = pm; x.pl = pl; x.pO = pO;
     x.kd_row0 = kd_row0; x.Np = Np; x.teacher = teacher; x.ldt = ldt; x.trow = trow; x.tlse2 = tlse2; x.pO2 = pO2;
     x.ranges2 = ader_lx3_readout_ranges(Np, Bp - kd_row0);
     LbfArgs a;
@@ -1110,7 +1105,7 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     a.pO2 = pO2; a.ranges2 = x.ranges2;
     hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, n_train, n_ex,
                        kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
-    if (nk) { rc = nk == 1 ? lx3f_launch(x, stream) : lx3gh_launch(x, stream); if (rc) return rc; }
+    if (nk) { rc = lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     if (lx3r_supports(x)) { rc = lx3r_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);

@@ -1,24 +1,22 @@
-// Full-catalog logits + softmax cross-entropy at float32 grade, flash forward on 16x16x32 tiles (k_lx3f).
+// Full-catalog logits + softmax cross-entropy at float32 grade: the flash forward kernels on the conflict-free block images.
 // Reference: ADER.py:88-93 (logits = rep . item_emb^T, one-hot softmax CE) in float32: every product as three bf16 MFMAs on hi/lo
 // operand splits (hi.hi + lo.hi + hi.lo, ~2^-16 relative, fp32 accumulate, fp32 softmax).
 //
 // Same algorithm as k_lx3_fwd (logits_bf16.hip): per 32-item block S^T = E.rep^T, online max / sum-exp, and the probabilities go
 // back into the matrix core as the A operand of O[b,:] += P^T.E (the softmax-weighted readout = dRep up to the target term), so
-// nothing [rows, N]-sized is ever written.  What is different is the shape, chosen for what the round-2 kernel was short of:
-//   * 64 batch rows per workgroup, 16 per wave, on v_mfma_f32_16x16x32_bf16: rep fragments (hi + lo) 40 registers and O 40 instead
-//     of 80 + 80, no register ring of table blocks beyond the ONE block in flight -- <= 168 registers, three workgroups per CU and no
-//     scratch (k_lx3_fwd sat at 256 registers with spills inside the block loop and reloaded every operand right before its MFMA);
-//   * the table block is split into hi/lo on its way into LDS as the bank-conflict-free image of x3_image.h (16-byte k-chunks
-//     [kc][item][8 channels]; one ds_write_b128 per plane and slot instead of eight 4-byte stores with conflicts), and both operand
-//     reads -- ds_read_b128 rows for S^T, ds_read_b64_tr_b16 k-major for the readout -- are pipelined by hand two steps ahead
-//     of their MFMAs;
-//   * three independent workgroups per SIMD-set keep the matrix pipe fed while one of them converts / stores its next block.
+// nothing [rows, N]-sized is ever written.  The table block is split into hi/lo on its way into LDS as the bank-conflict-free image
+// of x3_image.h (16-byte k-chunks [kc][item][8 channels]), and both operand reads -- ds_read_b128 rows for S^T, ds_read_b64_tr_b16
+// k-major for the readout -- are pipelined by hand ahead of their MFMAs.
+//   k_lx3g  32 batch rows per wave on v_mfma_f32_32x32x16_bf16 (128 per workgroup, two workgroups per CU); any supported H
+//   k_lx3p  k_lx3g with the softmax / staging vector work issued inside the MFMA phases (H = 150: the default forward)
+//   k_lx3r  the teacher readout of distilled steps (ADER.py:132-137) on the same images
+// (k_lx3f, 16 rows per wave on 16x16x32 tiles, and k_lx3h, k_lx3g's blocking on 16x16x32 tiles, were measured 25 % and 4 % slower in
+// round 3 -- DESIGN.md 6a -- and removed in round 4.)
 // Output partials (pm, pl, pO per item range) and the merge (k_lbf_combine<true>) are those of k_lx3_fwd.  gfx950 only.
 #include "lbf_common.h"
 #include "x3_image.h"
 #include "../../include/ader_hip.h"
 
-#define F3_ROWS 64                 // batch rows per workgroup (4 waves x 16)
 #define F3_FB 32                   // items per streamed block
 #define F3_RND 3                   // staging rounds: 12 units of (8 items x 8 k-chunks), 4 waves
 
@@ -26,209 +24,10 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(8))) F3Vec { f32x4_t v; };      // 16-byte vector at an 8-byte aligned address (rows are 8 H bytes)
 
-template <int HT>       // HT: hidden size known at compile time (150: the reference default, main.py:104) or 0 = a.H
-__global__ __launch_bounds__(256, 3) void k_lx3f(Lx3Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [2 buffers][block image]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15, g = lane >> 4;
-    const int nchunk = a.Bp / F3_ROWS;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int range = xcd + 8 * (slot / nchunk);           // the row chunks of an item range sit on one XCD: the table block is
-    const int bc = slot % nchunk;                          // fetched from HBM once and served to the others by that XCD's L2
-    if (range >= a.ranges) return;
-    const int H = HT ? HT : a.H;
-    const int N = (bc * F3_ROWS >= a.kd_row0) ? a.Np : a.N;            // columns of this chunk's softmax (distilled rows: first Np)
-    const int nblk_all = (a.N + F3_FB - 1) / F3_FB;
-    const int per = (nblk_all + a.ranges - 1) / a.ranges;
-    const int blk_begin = range * per, blk_end = min((N + F3_FB - 1) / F3_FB, blk_begin + per);
-    const int nb_blocks = max(0, blk_end - blk_begin);
-    const int b0 = bc * F3_ROWS + wave * 16;
-    // pads of both images (k-chunks >= ceil(H/8), bytes between the quads) stay zero: the block stores never touch them
-    for (int i = tid; i < 2 * X3_IMG_B / 16; i += 256) ((uint4*)smem_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
-    // rep fragments: lane (batch row c16, k-group g) holds rep[b0 + c16][32 ks + 8 g + 0..7]
-    bf16x8 rh[5], rl[5];
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-        rh[ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + c16) * LDR + 32 * ks + 8 * g);
-        rl[ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + c16) * LDR + 32 * ks + 8 * g);
-    }
-    f32x4v O[10];
-#pragma unroll
-    for (int cb = 0; cb < 10; ++cb) O[cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.0f;
-    // ---- staging: a block = 32 table rows of H floats.  Round r (0..2) of wave w covers items 8 w.. and k-chunks 8 r..:
-    // lane l -> item + (l & 7), k-chunk + (l >> 3): the 8 lanes of an LDS write group store 8 consecutive 16-byte
-    // slots (conflict-free), and a wave's two 16-byte loads per slot touch 2 cache lines per table row.
-    const int nfull = H >> 3, rem = H & 7;                 // full k-chunks; channels of the partial one (0, 4 or 6: see launcher)
-    // round r of this lane: item it_ (= 8 wave + (lane & 7): a wave stages the same 8 items in every round), k-chunk 8 r + kc0
-    const int it_ = 8 * wave + (lane & 7), kc0 = lane >> 3;
-    const int voff = 4 * (it_ * H + 8 * kc0);              // byte offset inside the block (round r: + 256 r)
-    const int voffp = voff + 4 * (rem - 4);                // second vector of the partial k-chunk: ends with the row
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.emb1, 0, a.vrows * H * 4, 0x00020000);
-    const int dst0 = x3_kc_off(kc0) + 16 * it_;            // byte offset inside a plane (round r: + 2 quads r)
-#define F3_KC(r_) (8 * (r_) + kc0)
-#define F3_PART(r_) (rem && F3_KC(r_) == nfull)
-#define F3_VALID(r_) (F3_KC(r_) < nfull || F3_PART(r_))
-    f32x4_t sa[F3_RND], sb[F3_RND];
-    // Block loads through a buffer descriptor of the table (base in scalar registers, ONE 32-bit per-lane offset, the block's
-    // offset as the scalar offset, the round's as the instruction's immediate): no 64-bit per-lane pointers, and rows beyond the
-    // table's last one (only in its last block; their items are >= N: outside the softmax) come back as zeros from the hardware
-    // range check.  Lanes without a k-chunk read whatever follows their row (never stored).  NOTHING is selected on the loaded data
-    // here -- a select would make hipcc wait for each load right behind its issue.
-#define F3_LOAD(blk_)                                                                                     \
-    {                                                                                                     \
-        const int so_ = (blk_) * (F3_FB * 4) * H;              /* byte offset of the block (< 2^31: checked by the launcher) */ \
-        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
-            const u32x4_t va_ = __builtin_amdgcn_raw_buffer_load_b128(trs, voff + 256 * r, so_, 0);         \
-            const u32x4_t vb_ = __builtin_amdgcn_raw_buffer_load_b128(trs, (F3_PART(r) ? voffp : voff + 16) + 256 * r, so_, 0); \
-            sa[r] = __builtin_bit_cast(f32x4_t, va_); sb[r] = __builtin_bit_cast(f32x4_t, vb_);           \
-        }                                                                                                 \
-    }
-    // hi = bf16(x), lo = bf16(x - hi), 8 channels -> one 16-byte slot per plane
-#define F3_STORE(buf_)                                                                                    \
-    {                                                                                                     \
-        unsigned char* dst_ = smem_raw + (buf_) * X3_IMG_B;                                               \
-        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
-            float x_[8];                                                                                  \
-            x_[0] = sa[r][0]; x_[1] = sa[r][1]; x_[2] = sa[r][2]; x_[3] = sa[r][3];                       \
-            if (F3_PART(r)) {       /* rem = 6: channels 4,5 are elements 2,3 of the shifted vector; rem = 4: none */ \
-                x_[4] = (rem == 6) ? sb[r][2] : 0.f; x_[5] = (rem == 6) ? sb[r][3] : 0.f; x_[6] = 0.f; x_[7] = 0.f; \
-            } else { x_[4] = sb[r][0]; x_[5] = sb[r][1]; x_[6] = sb[r][2]; x_[7] = sb[r][3]; }            \
-            bf16x8 h_, l_;                                                                                \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
-            if (F3_VALID(r)) {                                                                            \
-                *(bf16x8*)(dst_ + dst0 + 2 * X3_QUAD * r) = h_;                                           \
-                *(bf16x8*)(dst_ + X3_PLANE_B + dst0 + 2 * X3_QUAD * r) = l_;                              \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-    const int q4 = c16 >> 2, p4 = c16 & 3;
-    // per-lane byte offsets into a block image: row read of (item c16, k-group g); transposed read of (item 4g + q4, 4 channels p4)
-    const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
-    const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
-    if (nb_blocks > 0) F3_LOAD(blk_begin);
-    __syncthreads();                                       // zero fill done
-    if (nb_blocks > 0) F3_STORE(0);
-    if (nb_blocks > 1) F3_LOAD(blk_begin + 1);
-    for (int i = 0; i < nb_blocks; ++i) {
-        __syncthreads();                                   // block i is in LDS; every wave is done with block i-1
-        if (i + 1 < nb_blocks) F3_STORE((i + 1) & 1);      // (its loads were issued one iteration ago)
-        if (i + 2 < nb_blocks) F3_LOAD(blk_begin + i + 2);
-        const char* Bh = (const char*)(smem_raw + (i & 1) * X3_IMG_B);
-        const int i0 = (blk_begin + i) * F3_FB;
-        // S^T block ib = 16 items x 16 batch rows: A = table rows (lane: item c16 of the block, k = 8g..8g+7), B = rep fragments
-#define F3_LOADA(set_, ks_)                                                                               \
-        { const char* ap_ = Bh + a_off + X3_QUAD * (ks_);      /* k-chunk 4 ks + g, item c16 (block 1: + 16 items = 256 B) */ \
-          set_[0] = *(const bf16x8*)ap_; set_[1] = *(const bf16x8*)(ap_ + X3_PLANE_B);                    \
-          set_[2] = *(const bf16x8*)(ap_ + 256); set_[3] = *(const bf16x8*)(ap_ + X3_PLANE_B + 256); }
-#define F3_LOADT(set_, cb_)                                                                               \
-        { const bf16* tp_ = (const bf16*)(Bh + t_off + X3_QUAD * ((cb_) >> 1) + 512 * ((cb_) & 1));         \
-          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 128);                                           \
-          set_[2] = tr_read(tp_ + X3_PLANE_B / 2); set_[3] = tr_read(tp_ + X3_PLANE_B / 2 + 128); }
-        f32x4v S0 = (f32x4v){0.f, 0.f, 0.f, 0.f}, S1 = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        bf16x8 fa[2][4];
-        F3_LOADA(fa[0], 0);
-        F3_LOADA(fa[1], 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            bf16x8* A_ = fa[ks & 1];                             // {hi items 0-15, lo items 0-15, hi items 16-31, lo items 16-31}
-            S0 = mfma16_bf16(A_[1], rh[ks], S0);
-            S1 = mfma16_bf16(A_[3], rh[ks], S1);
-            S0 = mfma16_bf16(A_[0], rl[ks], S0);
-            S1 = mfma16_bf16(A_[2], rl[ks], S1);
-            S0 = mfma16_bf16(A_[0], rh[ks], S0);
-            S1 = mfma16_bf16(A_[2], rh[ks], S1);
-            if (ks + 2 < 5) F3_LOADA(fa[ks & 1], ks + 2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the first transposed reads of the readout do not depend on S: in flight under the softmax section
-        bf16x4 ft[2][4];
-        F3_LOADT(ft[0], 0);
-        F3_LOADT(ft[1], 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // lane (batch row c16, g) holds the logits of items i0 + 4g + j (S0) and i0 + 16 + 4g + j (S1)
-        if (i0 + F3_FB > N) {                              // tail block: items >= N are outside the softmax
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (i0 + 4 * g + j >= N) S0[j] = -INFINITY;
-                if (i0 + 16 + 4 * g + j >= N) S1[j] = -INFINITY;
-            }
-        }
-        float tmax = fmaxf(fmaxf(fmaxf(S0[0], S0[1]), fmaxf(S0[2], S0[3])), fmaxf(fmaxf(S1[0], S1[1]), fmaxf(S1[2], S1[3])));
-        // the four lanes (c16, g = 0..3) hold different items of the SAME batch row; m_run is kept equal in all four, so the
-        // cross-lane exchange is only needed on the (rare) rescale path
-        float t2 = tmax * LOG2E;
-        if (__any(t2 > m_run + RESCALE_THR)) {
-            t2 = fmaxf(t2, __shfl_xor(t2, 16, 64));
-            t2 = fmaxf(t2, __shfl_xor(t2, 32, 64));
-            const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;
-            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float ar = __shfl(alpha, 4 * g + j, 64);          // O rows are batch rows 4g + j: their state is in lane 4g + j
-#pragma unroll
-                for (int cb = 0; cb < 10; ++cb) O[cb][j] *= ar;
-            }
-        }
-        const float nm = -m_run;
-        float ls = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            S0[j] = __builtin_amdgcn_exp2f(fmaf(S0[j], LOG2E, nm)); ls += S0[j];
-            S1[j] = __builtin_amdgcn_exp2f(fmaf(S1[j], LOG2E, nm)); ls += S1[j];
-        }
-        l_run += ls;
-        bf16x8 ph_, pl_;        // k order of the fragment: items 4g..4g+3 of S block 0, then of S block 1
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16 h0 = (bf16)S0[j], h1 = (bf16)S1[j];
-            ph_[j] = h0; ph_[4 + j] = h1;
-            pl_[j] = (bf16)(S0[j] - (float)h0); pl_[4 + j] = (bf16)(S1[j] - (float)h1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int cb = 0; cb < 10; ++cb) {
-            bf16x4* T_ = ft[cb & 1];
-            bf16x8 bh, bl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { bh[j] = T_[0][j]; bh[4 + j] = T_[1][j]; bl[j] = T_[2][j]; bl[4 + j] = T_[3][j]; }
-            O[cb] = mfma16_bf16(pl_, bh, O[cb]);
-            O[cb] = mfma16_bf16(ph_, bl, O[cb]);
-            O[cb] = mfma16_bf16(ph_, bh, O[cb]);
-            if (cb + 2 < 10) F3_LOADT(ft[cb & 1], cb + 2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef F3_LOADA
-#undef F3_LOADT
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    if (g == 0) {
-        a.pm[(size_t)range * a.Bp + b0 + c16] = m_run;
-        a.pl[(size_t)range * a.Bp + b0 + c16] = l_tot;
-    }
-    // O[cb][j] = readout of batch row b0 + 4g + j, channel x3_channel(cb, c16) (< 160 always; channels >= H are zero)
-    float* o = a.pO + ((size_t)range * a.Bp + b0) * HP;
-#pragma unroll
-    for (int cb = 0; cb < 10; ++cb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[(size_t)(4 * g + j) * HP + x3_channel(cb, c16)] = O[cb][j];
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// The same forward on v_mfma_f32_32x32x16_bf16 with 32 batch rows per wave (128 per workgroup, two workgroups per CU): every LDS
-// operand fragment feeds twice the flops of the 16x16x32 form, whose 16-row waves keep the LDS pipe as busy as the matrix pipe
-// (reads 1,920 + block stores 940 of the 2,880 clocks the MFMAs of a block take on a SIMD; measured 1.16-1.20 ms against
-// 1.05-1.08 ms for k_lx3_fwd).  Register plan (<= 256): rep fragments 80, O 80, S / P 16, one block in flight 24, operand sets 16 / 32.
-#undef F3_LOAD
-#undef F3_STORE
-#undef F3_KC
-#undef F3_PART
-#undef F3_VALID
+// k_lx3g: 32 batch rows per wave on v_mfma_f32_32x32x16_bf16 (128 per workgroup, two workgroups per CU): every LDS operand fragment
+// feeds twice the flops of a 16x16x32 form with 16-row waves, which keeps the LDS pipe as busy as the matrix pipe.
+// Register plan (<= 256): rep fragments 80, O 80, S / P 16, one block in flight 24, operand sets 16 / 32.
 #define G3_ROWS 128
 #ifdef G3_STAMP     // diagnostic build only (tools/build_variant.sh ... -DG3_STAMP): per-segment clocks of wave 0 of every workgroup
 __device__ unsigned long long g3_dbg[8 * 1024];
@@ -1060,223 +859,9 @@ int lx3r_launch(const Lx3Args& x, void* stream) {
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_lx3h: k_lx3g's shape (128 batch rows per workgroup, 32 per wave, two workgroups per CU, three LDS block buffers, the block in
-// flight converted between the two MFMA phases) on v_mfma_f32_16x16x32_bf16 -- two 16-row blocks per wave share every LDS operand
-// fragment, so the LDS bytes per flop are those of the 32x32x16 form while the matrix instruction is the one the chip holds a
-// higher clock on under load (MI355X_MICROARCH.md, DVFS item 7: ~1.12-1.15x FLOP/s at equal cycles per FLOP).  Block image: the
-// quads of x3_image.h (as k_lx3f).  Register plan: rep fragments 80, O 80, S 16, P 16, operand sets 24, block in flight 24.
-template <int HT>
-__global__ __launch_bounds__(256, 2) void k_lx3h(Lx3Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [3 buffers][block image]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15, g = lane >> 4;
-    const int nchunk = a.Bp / G3_ROWS;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int range = xcd + 8 * (slot / nchunk);
-    const int bc = slot % nchunk;
-    if (range >= a.ranges) return;
-    const int H = HT ? HT : a.H;
-    const int N = (bc * G3_ROWS >= a.kd_row0) ? a.Np : a.N;
-    const int nblk_all = (a.N + F3_FB - 1) / F3_FB;
-    const int per = (nblk_all + a.ranges - 1) / a.ranges;
-    const int blk_begin = range * per, blk_end = min((N + F3_FB - 1) / F3_FB, blk_begin + per);
-    const int nb_blocks = max(0, blk_end - blk_begin);
-    const int b0 = bc * G3_ROWS + wave * 32;
-    for (int i = tid; i < 3 * X3_IMG_B / 16; i += 256) ((uint4*)smem_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
-    // rep fragments of the two 16-row blocks: lane (batch row 16 rb + c16, k-group g) holds rep[row][32 ks + 8 g + 0..7]
-    bf16x8 rh[2][5], rl[2][5];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            rh[rb][ks] = *(const bf16x8*)(a.rep_hi + (size_t)(b0 + 16 * rb + c16) * LDR + 32 * ks + 8 * g);
-            rl[rb][ks] = *(const bf16x8*)(a.rep_lo + (size_t)(b0 + 16 * rb + c16) * LDR + 32 * ks + 8 * g);
-        }
-    f32x4v O[2][10];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 10; ++cb) O[rb][cb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
-    const int nfull = H >> 3, rem = H & 7;
-    const int it_ = 8 * wave + (lane & 7), kc0 = lane >> 3;
-    const int voff = 4 * (it_ * H + 8 * kc0);
-    const int voffp = voff + 4 * (rem - 4);
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.emb1, 0, a.vrows * H * 4, 0x00020000);
-    const int dst0 = x3_kc_off(kc0) + 16 * it_;             // byte offset inside a plane (round r: + 2 quads)
-    f32x4_t sa[F3_RND], sb[F3_RND];
-#define H3_STORE(buf_)                                                                                    \
-    {                                                                                                     \
-        unsigned char* dst_ = smem_raw + (buf_) * X3_IMG_B;                                               \
-        _Pragma("unroll") for (int r = 0; r < F3_RND; ++r) {                                              \
-            float x_[8];                                                                                  \
-            x_[0] = sa[r][0]; x_[1] = sa[r][1]; x_[2] = sa[r][2]; x_[3] = sa[r][3];                       \
-            if (F3_PART(r)) {                                                                             \
-                x_[4] = (rem == 6) ? sb[r][2] : 0.f; x_[5] = (rem == 6) ? sb[r][3] : 0.f; x_[6] = 0.f; x_[7] = 0.f; \
-            } else { x_[4] = sb[r][0]; x_[5] = sb[r][1]; x_[6] = sb[r][2]; x_[7] = sb[r][3]; }            \
-            bf16x8 h_, l_;                                                                                \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
-            if (F3_VALID(r)) {                                                                            \
-                *(bf16x8*)(dst_ + dst0 + 2 * X3_QUAD * r) = h_;                                           \
-                *(bf16x8*)(dst_ + X3_PLANE_B + dst0 + 2 * X3_QUAD * r) = l_;                              \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-    const int q4 = c16 >> 2, p4 = c16 & 3;
-    const int a_off = 1152 * (g >> 1) + 512 * (g & 1) + 16 * c16;
-    const int t_off = 1152 * (p4 >> 1) + 16 * (4 * g + q4) + 8 * (p4 & 1);
-    if (nb_blocks > 0) F3_LOAD(blk_begin);
-    __syncthreads();                                       // zero fill done
-    if (nb_blocks > 0) H3_STORE(0);
-    if (nb_blocks > 1) { F3_LOAD(blk_begin + 1); H3_STORE(1); }
-    int bcur = 0;
-    for (int i = 0; i < nb_blocks; ++i) {
-        __syncthreads();                                   // blocks i and i + 1 are in LDS; every wave is done with block i - 1
-        const bool more = i + 2 < nb_blocks;
-        if (more) F3_LOAD(blk_begin + i + 2);
-        const char* Bh = (const char*)(smem_raw + bcur * X3_IMG_B);
-        const int bnew = bcur == 0 ? 2 : bcur - 1;
-        const int i0 = (blk_begin + i) * F3_FB;
-        // half step hs = (k-step ks = hs >> 1, item block ib = hs & 1): A = table rows (lane: item 16 ib + c16, k-chunk 4 ks + g),
-        // B = the rep fragments of both row blocks -- one {hi, lo} pair of ds_read_b128 feeds six MFMAs
-#define H3_LOADA(set_, hs_)                                                                               \
-        { const char* ap_ = Bh + a_off + X3_QUAD * ((hs_) >> 1) + 256 * ((hs_) & 1);                      \
-          set_[0] = *(const bf16x8*)ap_; set_[1] = *(const bf16x8*)(ap_ + X3_PLANE_B); }
-#define H3_LOADT(set_, cb_)                                                                               \
-        { const bf16* tp_ = (const bf16*)(Bh + t_off + X3_QUAD * ((cb_) >> 1) + 512 * ((cb_) & 1));         \
-          set_[0] = tr_read(tp_); set_[1] = tr_read(tp_ + 128);                                           \
-          set_[2] = tr_read(tp_ + X3_PLANE_B / 2); set_[3] = tr_read(tp_ + X3_PLANE_B / 2 + 128); }
-        f32x4v S[2][2];         // [row block][item block]
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) S[rb][ib] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        bf16x8 fa[3][2];
-        H3_LOADA(fa[0], 0);
-        H3_LOADA(fa[1], 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int hs = 0; hs < 10; ++hs) {
-            bf16x8* A_ = fa[hs % 3];                             // {hi, lo}
-            const int ks = hs >> 1, ib = hs & 1;
-            S[0][ib] = mfma16_bf16(A_[1], rh[0][ks], S[0][ib]);
-            S[1][ib] = mfma16_bf16(A_[1], rh[1][ks], S[1][ib]);
-            S[0][ib] = mfma16_bf16(A_[0], rl[0][ks], S[0][ib]);
-            S[1][ib] = mfma16_bf16(A_[0], rl[1][ks], S[1][ib]);
-            S[0][ib] = mfma16_bf16(A_[0], rh[0][ks], S[0][ib]);
-            S[1][ib] = mfma16_bf16(A_[0], rh[1][ks], S[1][ib]);
-            if (hs + 2 < 10) H3_LOADA(fa[(hs + 2) % 3], hs + 2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) H3_STORE(bnew);
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x4 ft[3][4];
-        H3_LOADT(ft[0], 0);
-        H3_LOADT(ft[1], 1);
-        H3_LOADT(ft[2], 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // lane (c16, g) holds, for batch row 16 rb + c16, the logits of items i0 + 16 ib + 4 g + j
-        if (i0 + F3_FB > N) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (i0 + 16 * ib + 4 * g + j >= N) S[rb][ib][j] = -INFINITY;
-        }
-        float t2[2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-            t2[rb] = LOG2E * fmaxf(fmaxf(fmaxf(S[rb][0][0], S[rb][0][1]), fmaxf(S[rb][0][2], S[rb][0][3])),
-                                   fmaxf(fmaxf(S[rb][1][0], S[rb][1][1]), fmaxf(S[rb][1][2], S[rb][1][3])));
-        // the four lanes (c16, g = 0..3) hold different items of the SAME batch rows; m_run is kept equal in all four, so the
-        // cross-lane exchange is only needed on the (rare) rescale path
-        if (__any(t2[0] > m_run[0] + RESCALE_THR || t2[1] > m_run[1] + RESCALE_THR)) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                float t = t2[rb];
-                t = fmaxf(t, __shfl_xor(t, 16, 64));
-                t = fmaxf(t, __shfl_xor(t, 32, 64));
-                const float m_new = (t > m_run[rb] + RESCALE_THR) ? t : m_run[rb];
-                const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[rb] - m_new);
-                l_run[rb] *= alpha;
-                m_run[rb] = m_new;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float ar = __shfl(alpha, 4 * g + j, 64);      // O rows are batch rows 4g + j of the block: state in lane 4g + j
-#pragma unroll
-                    for (int cb = 0; cb < 10; ++cb) O[rb][cb][j] *= ar;
-                }
-            }
-        }
-        bf16x8 ph_[2], pl_[2];  // k order of the fragment: items 4g..4g+3 of item block 0, then of item block 1
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const float nm = -m_run[rb];
-            float ls = 0.0f;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[rb][ib][j], LOG2E, nm));
-                    ls += p;
-                    const bf16 h = (bf16)p;
-                    ph_[rb][4 * ib + j] = h;
-                    pl_[rb][4 * ib + j] = (bf16)(p - (float)h);
-                }
-            l_run[rb] += ls;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int cb = 0; cb < 10; ++cb) {
-            bf16x4* T_ = ft[cb % 3];
-            bf16x8 bh, bl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { bh[j] = T_[0][j]; bh[4 + j] = T_[1][j]; bl[j] = T_[2][j]; bl[4 + j] = T_[3][j]; }
-            O[0][cb] = mfma16_bf16(pl_[0], bh, O[0][cb]);
-            O[1][cb] = mfma16_bf16(pl_[1], bh, O[1][cb]);
-            O[0][cb] = mfma16_bf16(ph_[0], bl, O[0][cb]);
-            O[1][cb] = mfma16_bf16(ph_[1], bl, O[1][cb]);
-            O[0][cb] = mfma16_bf16(ph_[0], bh, O[0][cb]);
-            O[1][cb] = mfma16_bf16(ph_[1], bh, O[1][cb]);
-            if (cb + 3 < 10) H3_LOADT(ft[cb % 3], cb + 3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        bcur = bcur == 2 ? 0 : bcur + 1;
-    }
-#undef H3_LOADA
-#undef H3_LOADT
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 16, 64);
-        l_tot += __shfl_xor(l_tot, 32, 64);
-        if (g == 0) {
-            a.pm[(size_t)range * a.Bp + b0 + 16 * rb + c16] = m_run[rb];
-            a.pl[(size_t)range * a.Bp + b0 + 16 * rb + c16] = l_tot;
-        }
-        float* o = a.pO + ((size_t)range * a.Bp + b0 + 16 * rb) * HP;
-#pragma unroll
-        for (int cb = 0; cb < 10; ++cb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[(size_t)(4 * g + j) * HP + x3_channel(cb, c16)] = O[rb][cb][j];
-    }
-}
-
-// item ranges of k_lx3f per 64-row chunk: a multiple of 8 (blocks b and b + 8 share an XCD: the chunks of a range are placed on
-// one), as many as keep ranges * chunks within the 768 resident workgroups (3 per CU), at least one 32-item block each
-int lx3f_ranges(int N, int Bp) {
-    const int nblk = (N + F3_FB - 1) / F3_FB;
-    const int nchunk = Bp / F3_ROWS;
-    int r = (768 / (nchunk < 1 ? 1 : nchunk)) / 8 * 8;
-    if (r > (nblk + 7) / 8 * 8) r = (nblk + 7) / 8 * 8;
-    if (r < 8) r = 8;
-    return r;
-}
 bool lx3f_supports(int H) { return (H & 1) == 0 && H >= 8 && H <= HP && ((H & 7) == 0 || (H & 7) == 4 || (H & 7) == 6); }
 
-// x.ranges must be lx3f_ranges(x.N, x.Bp); Bp % 64 == 0
+// x.ranges must be ader_lbf_ranges(x.N, x.Bp); Bp % 128 == 0
 int lx3g_launch(const Lx3Args& x, void* stream) {
     static bool f = false;
     if (!f) {
@@ -1302,35 +887,5 @@ int lx3p_launch(const Lx3Args& x, void* stream) {
     if ((long)x.vrows * x.H * 4 >= (1l << 31)) return -2;
     if (x.H != 150) return lx3g_launch(x, stream);                 // (the pipelined form exists for the reference's hidden size only)
     hipLaunchKernelGGL(k_lx3p<150>, dim3(x.ranges * (x.Bp / G3_ROWS)), dim3(256), 3 * X3B_IMG_B, (hipStream_t)stream, x);
-    return 0;
-}
-
-int lx3h_launch(const Lx3Args& x, void* stream) {
-    static bool f = false;
-    if (!f) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lx3h<150>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_IMG_B);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lx3h<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_IMG_B);
-        if (e != hipSuccess) return (int)e;
-        f = true;
-    }
-    if ((long)x.vrows * x.H * 4 >= (1l << 31)) return -2;          // the block offsets of the buffer loads are 32-bit
-    if (x.H == 150) hipLaunchKernelGGL(k_lx3h<150>, dim3(x.ranges * (x.Bp / G3_ROWS)), dim3(256), 3 * X3_IMG_B, (hipStream_t)stream, x);
-    else hipLaunchKernelGGL(k_lx3h<0>, dim3(x.ranges * (x.Bp / G3_ROWS)), dim3(256), 3 * X3_IMG_B, (hipStream_t)stream, x);
-    return 0;
-}
-
-int lx3f_launch(const Lx3Args& x, void* stream) {
-    static bool f = false;
-    if (!f) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lx3f<150>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_IMG_B);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)k_lx3f<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3_IMG_B);
-        if (e != hipSuccess) return (int)e;
-        f = true;
-    }
-    if ((long)x.vrows * x.H * 4 >= (1l << 31)) return -2;          // the block offsets of the buffer loads are 32-bit
-    if (x.H == 150) hipLaunchKernelGGL(k_lx3f<150>, dim3(x.ranges * (x.Bp / F3_ROWS)), dim3(256), 2 * X3_IMG_B, (hipStream_t)stream, x);
-    else hipLaunchKernelGGL(k_lx3f<0>, dim3(x.ranges * (x.Bp / F3_ROWS)), dim3(256), 2 * X3_IMG_B, (hipStream_t)stream, x);
     return 0;
 }

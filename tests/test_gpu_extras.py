@@ -238,7 +238,7 @@ def test_ewc_driver_two_periods():
 def test_batched_weight_gradient_products_match_float64(H):
     """ader_gemm_atb_x3_batch (the small-footprint form that runs inside the fused table update; H = 150 is the templated
     instantiation, 64 the generic one): dW = A^T . G and db = column sums of G for several products of ragged row counts,
-    against float64 (bf16x3: <= 3e-5 of the tensor's max), and identical to the large form (ADER_ATB=big) within the same bound.
+    against float64 (bf16x3: <= 3e-5 of the tensor's max).
     Reference: the kernel gradients of modules.py:172-174 and :254-261."""
     import ctypes
     from ader_amd._lib import call, ptr
