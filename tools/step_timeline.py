@@ -9,3 +9,4 @@ for r in rows[a:b]:
     s = int(r['Start_Timestamp']) - t0
     e = int(r['End_Timestamp']) - t0
     print("%8.1f %8.1f %7.1f  q%s %s" % (s / 1000, e / 1000, (e - s) / 1000, r.get('Queue_Id', ''), r['Kernel_Name'][:70]))
+print("# step period (start of this k_seq_fwd to the next one): %.1f us" % ((int(rows[b]['Start_Timestamp']) - t0) / 1000))
