@@ -47,21 +47,22 @@ struct AttnX3Args {
 };
 
 // dst_hi/lo[t][c] = split(src[t][c0 + c]) for t < T, c < dh (pairs); padding untouched (zeroed once by the caller)
+template <int NT = 128>
 __device__ __forceinline__ void stage_split(bf16* Th, bf16* Tl, const float* __restrict__ src, int T, int H, int c0, int dh, int tid) {
     const int HH = dh >> 1, n2 = T * HH;
     // 8 independent loads in flight per thread before any conversion (the tile comes from L2 / Infinity Cache: latency-bound)
-    for (int i0 = 0; i0 < n2; i0 += 128 * 8) {
+    for (int i0 = 0; i0 < n2; i0 += NT * 8) {
         float2 v[8];
         int t[8], c2[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = i0 + tid + 128 * u;
+            const int idx = i0 + tid + NT * u;
             t[u] = idx / HH; c2[u] = idx - t[u] * HH;
             v[u] = (idx < n2) ? *(const float2*)(src + (size_t)t[u] * H + c0 + 2 * c2[u]) : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (i0 + tid + 128 * u < n2) {
+            if (i0 + tid + NT * u < n2) {
                 bf16x2 h, l;
                 h[0] = (bf16)v[u].x; h[1] = (bf16)v[u].y;
                 l[0] = (bf16)(v[u].x - (float)h[0]); l[1] = (bf16)(v[u].y - (float)h[1]);
@@ -111,7 +112,7 @@ __device__ __forceinline__ void rows_times_frags(const bf16* Th, const bf16* Tl,
 // O[nb] += X^T . tile  where X = the two 32x32 accumulators x[kb] (rows = tile rows 32kb.., cols = this wave's lanes),
 // fed back as A operands (hi/lo split of the fp32 values); tile rows read k-major in the accumulator's row order.
 __device__ __forceinline__ void acc_times_rows(const f32x16 (&x)[2], const bf16* Th, const bf16* Tl, int nblocks, int lane,
-                                               f32x16 (&O)[5]) {
+                                               f32x16 (&O)[5], int nb0 = 0) {
     const int hh = lane >> 5, q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -127,7 +128,7 @@ __device__ __forceinline__ void acc_times_rows(const f32x16 (&x)[2], const bf16*
             const int ro = (32 * kb + 16 * s + 4 * hh + q4) * LDR + 16 * g1 + 4 * p4;
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
-                if (nb < nblocks) {
+                if (nb >= nb0 && nb < nblocks) {
                     const bf16x8 bh = cat4(tr_read(Th + ro + 32 * nb), tr_read(Th + ro + 32 * nb + 8 * LDR));
                     const bf16x8 bl = cat4(tr_read(Tl + ro + 32 * nb), tr_read(Tl + ro + 32 * nb + 8 * LDR));
                     O[nb] = mfma_bf16(pl, bh, O[nb]);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(128) void k_attn_x3_fwd(AttnX3Args a) {
 
 // out[nb] = tileP rows (this wave's 32 rows, k = 64 columns) . tile rows (k-major read, natural k order), 3 MFMAs per product
 __device__ __forceinline__ void ptile_times_rows(const bf16* Ph, const bf16* Pl, const bf16* Th, const bf16* Tl, int nblocks, int lane,
-                                                 int wave, f32x16 (&O)[5]) {
+                                                 int wave, f32x16 (&O)[5], int nb0 = 0) {
     const int r = lane & 31, hh = lane >> 5, q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ void ptile_times_rows(const bf16* Ph, const bf16* Pl,
         const int ro = (16 * ks + 8 * hh + q4) * LDR + 16 * g1 + 4 * p4;
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb) {
-            if (nb < nblocks) {
+            if (nb >= nb0 && nb < nblocks) {
                 const bf16x8 bh = cat4(tr_read(Th + ro + 32 * nb), tr_read(Th + ro + 32 * nb + 4 * LDR));
                 const bf16x8 bl = cat4(tr_read(Tl + ro + 32 * nb), tr_read(Tl + ro + 32 * nb + 4 * LDR));
                 O[nb] = mfma_bf16(al, bh, O[nb]);
@@ -248,12 +249,13 @@ __device__ __forceinline__ void ptile_times_rows(const bf16* Ph, const bf16* Pl,
     }
 }
 
-__device__ __forceinline__ void store_rows(float* __restrict__ dst, const f32x16 (&O)[5], int wave, int lane, int T, int H, int c0, int dh) {
+__device__ __forceinline__ void store_rows(float* __restrict__ dst, const f32x16 (&O)[5], int wave, int lane, int T, int H, int c0, int dh,
+                                           int nb0 = 0, int nb1 = 5) {
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb) {
         const int c = 32 * nb + r;
-        if (c >= dh) continue;
+        if (c >= dh || nb < nb0 || nb >= nb1) continue;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = 32 * wave + acc_row(j, hh);
@@ -262,7 +264,12 @@ __device__ __forceinline__ void store_rows(float* __restrict__ dst, const f32x16
     }
 }
 
-__global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
+// Four waves: wave (w2 = wave & 1, half = wave >> 1) owns query rows / key rows 32 w2.. as in the two-wave form, and of the three
+// [T, dh] products (dQ, dV, dK) the 32-channel blocks {0, 1, 2} (half 0) or {3, 4} (half 1).  dP^T and the softmax backward of its
+// 32 queries are computed by both halves (60 MFMAs and 32 probabilities: cheaper than an exchange); half 0 writes the P_drop / dS
+// tiles.  With two waves the four operand stagings (V, K, dO, Q: memory -> registers -> LDS, each behind a barrier) ran on 128
+// threads with one wave per SIMD on half of the CU's SIMDs: 62 us for 512 sessions at 6 % matrix-pipe use.
+__global__ __launch_bounds__(256) void k_attn_x3_bwd(AttnX3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Th = (bf16*)smem_raw;
     bf16* Tl = Th + TR * LDR;
@@ -271,21 +278,22 @@ __global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
     bf16* dSh = Pdl + TR * LDP;
     bf16* dSl = dSh + TR * LDP;
     float* km_l = (float*)(dSl + TR * LDP);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 1, half = tid >> 7;
     const int r = lane & 31, hh = lane >> 5;
+    const int nb0 = half ? 3 : 0, nb1 = half ? 5 : 3;        // this wave's channel blocks of dQ / dV / dK
     const int b = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
     const int T = a.T, H = a.H, dh = H / a.heads, c0 = head * dh;
     const size_t base = (size_t)b * T * H;
     const int ksteps = (dh + 15) >> 4, nblocks = (dh + 31) >> 5;
     const int q = 32 * wave + r;
-    for (int i = tid; i < (2 * TR * LDR + 4 * TR * LDP) / 2; i += 128) ((uint32_t*)Th)[i] = 0u;
+    for (int i = tid; i < (2 * TR * LDR + 4 * TR * LDP) / 2; i += 256) ((uint32_t*)Th)[i] = 0u;
     if (tid < TR) km_l[tid] = (tid < T) ? a.kmask[(size_t)b * T + tid] : 0.0f;
     f32x16 X[2];                                            // dP^T, then dS^T (keys on rows, this wave's queries on lanes)
     {
         bf16x8 gh[10], gl[10];
         row_frags(a.res + base + (size_t)(q < T ? q : 0) * H + c0, q < T, dh, hh, gh, gl);      // dO rows
         __syncthreads();
-        stage_split(Th, Tl, a.V + base, T, H, c0, dh, tid);
+        stage_split<256>(Th, Tl, a.V + base, T, H, c0, dh, tid);
         __syncthreads();
         rows_times_frags(Th, Tl, gh, gl, ksteps, r, hh, X);                                      // dP_drop^T = V . dO^T
     }
@@ -320,8 +328,10 @@ __global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
             Pv[kb][j] = p;
             X[kb][j] = dp;
             const bf16 ph = (bf16)pd;
-            Pdh[key * LDP + q] = ph;
-            Pdl[key * LDP + q] = (bf16)(pd - (float)ph);
+            if (half == 0) {
+                Pdh[key * LDP + q] = ph;
+                Pdl[key * LDP + q] = (bf16)(pd - (float)ph);
+            }
         }
     dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
@@ -333,40 +343,42 @@ __global__ __launch_bounds__(128) void k_attn_x3_bwd(AttnX3Args a) {
             if (key < T && q < T && key <= q && km_l[key] != 0.0f) ds = (Pv[kb][j] * (X[kb][j] - dot)) / a.sqrt_dh;
             X[kb][j] = ds;
             const bf16 sh_ = (bf16)ds;
-            dSh[key * LDP + q] = sh_;
-            dSl[key * LDP + q] = (bf16)(ds - (float)sh_);
+            if (half == 0) {
+                dSh[key * LDP + q] = sh_;
+                dSl[key * LDP + q] = (bf16)(ds - (float)sh_);
+            }
         }
     f32x16 O[5];
     // dQ[q][c] = sum_key dS^T[key][q] K[key][c]   (accumulator operand)
     __syncthreads();
-    stage_split(Th, Tl, a.K + base, T, H, c0, dh, tid);
+    stage_split<256>(Th, Tl, a.K + base, T, H, c0, dh, tid);
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
-    acc_times_rows(X, Th, Tl, nblocks, lane, O);
-    store_rows(a.dQ + base, O, wave, lane, T, H, c0, dh);
+    acc_times_rows(X, Th, Tl, min(nblocks, nb1), lane, O, nb0);
+    store_rows(a.dQ + base, O, wave, lane, T, H, c0, dh, nb0, nb1);
     // dV[key][c] = sum_q P_drop^T[key][q] dO[q][c]   (wave = key block)
     __syncthreads();
-    stage_split(Th, Tl, a.res + base, T, H, c0, dh, tid);
+    stage_split<256>(Th, Tl, a.res + base, T, H, c0, dh, tid);
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
-    ptile_times_rows(Pdh, Pdl, Th, Tl, nblocks, lane, wave, O);
-    store_rows(a.dV + base, O, wave, lane, T, H, c0, dh);
+    ptile_times_rows(Pdh, Pdl, Th, Tl, min(nblocks, nb1), lane, wave, O, nb0);
+    store_rows(a.dV + base, O, wave, lane, T, H, c0, dh, nb0, nb1);
     // dK[key][c] = sum_q dS^T[key][q] Q[q][c]
     __syncthreads();
-    stage_split(Th, Tl, a.Q + base, T, H, c0, dh, tid);
+    stage_split<256>(Th, Tl, a.Q + base, T, H, c0, dh, tid);
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
-    ptile_times_rows(dSh, dSl, Th, Tl, nblocks, lane, wave, O);
-    store_rows(a.dK + base, O, wave, lane, T, H, c0, dh);
+    ptile_times_rows(dSh, dSl, Th, Tl, min(nblocks, nb1), lane, wave, O, nb0);
+    store_rows(a.dK + base, O, wave, lane, T, H, c0, dh, nb0, nb1);
 }
 
 // ============================================================================================= C ABI
@@ -418,7 +430,7 @@ int ader_attn_x3_bwd(const float* dO, const float* Q, const float* K, const floa
     }
     a.Q = Q; a.K = K; a.V = V; a.res = dO; a.kmask = kmask; a.qmask = qmask; a.out = nullptr; a.PT = (float*)PT;
     a.dQ = dQ; a.dK = dK; a.dV = dV;
-    hipLaunchKernelGGL(k_attn_x3_bwd, dim3(B * heads), dim3(128), kBwdLds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_attn_x3_bwd, dim3(B * heads), dim3(256), kBwdLds, (hipStream_t)stream, a);
     HIP_LAUNCH_CHECK();
     return 0;
 }

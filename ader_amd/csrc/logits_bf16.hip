@@ -1077,7 +1077,14 @@ int ader_lbf_sum(const float* rowloss, int n, float* loss, void* stream) {
 
 // x3 distilled forward: scratch sizes.  pm / pl / pO use R = ader_lbf_ranges(N, Bp); the teacher readout is a launch of its own with
 // R2 = ader_lx3_readout_ranges(Np, Bp - kd_row0) item ranges: pO2 holds R2 * (Bp - kd_row0) * 160 floats.
-int ader_lx3_readout_ranges(int Np, int Bk) { return ader_lbf_ranges(Np, Bk); }
+int ader_lx3_readout_ranges(int Np, int Bk) {
+    // ... but at least four 32-item blocks per range: on the shipped catalogs (Np ~ 25-43 k) 512 ranges of one or two blocks made the
+    // merge (k_lbf_combine) sum 512 partials per exemplar row for a readout of a few microseconds
+    int r = ader_lbf_ranges(Np, Bk);
+    const int cap = (((Np + FB - 1) / FB + 3) / 4 + 7) / 8 * 8;
+    if (r > cap) r = cap;
+    return r < 8 ? 8 : r;
+}
 
 // ader_lbf_fwd_kd at float32 grade: the distilled step's forward on the x3 kernels (arguments as ader_lbf_fwd_kd, with the fp32
 // table instead of the shadow and the two operand planes rep_hi / rep_lo).
