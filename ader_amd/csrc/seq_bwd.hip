@@ -193,7 +193,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
         float h1[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) h1[j] = bload(oh, boff0 + ROWJ(j) * H4);
-        f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+        f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
         load_bfrags((const bf16*)a.w1 + 2 * WSZ, nb, r, hh, bh, bl);
         bf16* Th = R1 + t0 * LDR + n;
         const float sc1 = a.d_ffn1.scale;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_ffn(AderSeqBwdFfn a) {
     // ---- dy = da . W1^T + g  (in place in Xf)
     {
         PHASE_IDS;
-        f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
+        f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl, skipw);
         float* Xp = Xf + (32 * mh + 4 * hh) * XS + n;
         if (!skipw) {
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
         float res[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) res[j] = bload(ox1, boff0 + ROWJ(j) * H4);
-        f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+        f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
         load_bfrags((const bf16*)a.wk + 2 * WSZ, nb, r, hh, bh, bl);
         float* Xp = Xf + t0 * XS + n;
         if (!skipw) {           // (an all-padding wave: its Xf rows are cleared by the LayerNorm backward below)
@@ -301,9 +301,9 @@ __global__ __launch_bounds__(640) void k_seq_bwd_qkv(AderSeqBwdQkv a) {
     // ---- dx = LN1-backward + dK . Wk^T + dV . Wv^T  [block 0: * (seq != 0) * keep * scale of the embedding prologue]
     {
         PHASE_IDS;
-        f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
+        f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl, skipw);
         load_bfrags((const bf16*)a.wv + 2 * WSZ, nb, r, hh, bh, bl);
-        {
+        if (!skipw) {
             const bf16* Ah = R0 + (32 * mh + r) * LDR + 8 * hh;
             const bf16* Al = Ah + TR * LDR;
 #pragma unroll

@@ -88,12 +88,16 @@ __device__ __forceinline__ void load_bfrags(const bf16* __restrict__ W, int nb, 
     }
 }
 // acc = tile rows 32mh.. (hi/lo in LDS) . W columns 32nb..
-__device__ __forceinline__ f32x16 tile_mma(const bf16* Th, int mh, int r, int hh, const bf16x8 (&bh)[10], const bf16x8 (&bl)[10]) {
+// skip (wave-uniform): the wave's 32 rows are all leading padding -- nobody consumes the product (on the shipped data, mean session
+// length 5 of 50 positions, that is half of the waves of most workgroups: their LDS reads and MFMAs only slowed the other half down)
+__device__ __forceinline__ f32x16 tile_mma(const bf16* Th, int mh, int r, int hh, const bf16x8 (&bh)[10], const bf16x8 (&bl)[10],
+                                           bool skip = false) {
     const bf16* Ah = Th + (32 * mh + r) * LDR + 8 * hh;
     const bf16* Al = Ah + TR * LDR;
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    if (skip) return acc;
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) {
         const bf16x8 ah = *(const bf16x8*)(Ah + 16 * ks);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             PHASE_IDS;
             PRUNE_IDS;
             SFB(1)
-            f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
+            f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl, skipw);
             load_bfrags((const bf16*)k.w[1], nb, r, hh, bh, bl);
             SFB(2)
             const Out o = make_out(k.Q, b, T, H, pruned);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         // ---- K = x.Wk + bk (modules.py:173) -> memory, hi/lo -> R2 (the fp32 tile is dead)
         {
             PHASE_IDS;
-            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
             load_bfrags((const bf16*)k.w[2], nb, r, hh, bh, bl);
             SFB(4)
             const Out o = make_out(k.K, b, T, H, false);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         // ---- V = x.Wv + bv (modules.py:174) -> memory, hi/lo -> R0 (in place)
         {
             PHASE_IDS;
-            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
             const Out o = make_out(k.V, b, T, H, false);
             SFB(6)
             const int t0 = 32 * mh + 4 * hh;
@@ -372,8 +372,10 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
             const int q4 = (lane_p & 15) >> 2, p4 = lane_p & 3, g1_ = (lane_p >> 4) & 1;
             PRUNE_IDS;
             if (act) {
+            const int ks0 = (tv0 >= 32) ? 2 : 0;            // keys 0..31 all leading padding: their probabilities are exact zeros
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (ks < ks0) continue;
                 const bf16x8 ph = *(const bf16x8*)(Ph + (32 * mh + r) * LDP + 16 * ks + 8 * hh);
                 const bf16x8 pl = *(const bf16x8*)(Pl + (32 * mh + r) * LDP + 16 * ks + 8 * hh);
                 const bf16* Vp = R0 + (16 * ks + 8 * hh + q4) * LDR + 16 * g1_ + 4 * p4 + 32 * nb;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         {
             PHASE_IDS;
             PRUNE_IDS;
-            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl);
+            f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
             load_bfrags((const bf16*)k.w[4], nb, r, hh, bh, bl);
             const SDrop d1 = sdrop_of(k.d_ffn1, didx_row0);
             const Out o = make_out(k.h1d, b, T, H, pruned);
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(640) void k_seq_fwd(AderSeqFwd a) {
         {
             PHASE_IDS;
             PRUNE_IDS;
-            f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl);
+            f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl, skipw);
             if (l + 1 < a.L) load_bfrags((const bf16*)kp[1].w[0], nb, r, hh, bh, bl);
             const SDrop d2 = sdrop_of(k.d_ffn2, didx_row0);
             const Out o = make_out(k.x2, b, T, H, pruned);
