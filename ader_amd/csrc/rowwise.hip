@@ -15,6 +15,52 @@ struct __attribute__((packed, aligned(8))) EmbVec { f32x4 v; };      // 16-byte 
 // Four rows per wave, all of their pieces in flight before the first use (16 waves per CU x 4 random rows: the shape that reads
 // whole rows of a table far larger than the caches at 5.5+ TB/s, MI355X_MICROARCH.md "Indexed rows"); lane l owns the 16-byte piece
 // l of a row (H = 150: 37.5 pieces; the half piece and odd H / 4 tails go through the per-element path below).
+// H = 150 (the reference's hidden size): the four rows of a wave as 300 8-byte pieces (75 per row) over five wave-instructions --
+// every lane busy (the 16-byte form leaves 26 of 64 lanes idle on a 600-byte row), naturally aligned (rows of odd ids start at
+// 8 mod 16), and the output streamed with nontemporal stores.  Measured on 409,600 random rows of the 600 MB table (bare gather,
+// tools/gather_probe.hip): 3.87 TB/s in the 16-byte form, 4.44 with nontemporal stores, 4.74 packed, **5.43 TB/s packed + nontemporal**
+// (0.68 of the HBM peak); eight or sixteen rows per wave: slower.
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_embed_fwd150(const int* __restrict__ seq, const float* __restrict__ emb,
+                                                      const float* __restrict__ pos, float* __restrict__ x, int rows, int T, int V,
+                                                      float sqrtH, DropArgs d, int* __restrict__ status) {
+    constexpr int H = 150, PR = 75, NP = 4 * PR, NI = (NP + 63) / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * 4;
+    if (row0 >= rows) return;
+    int myid = 0;
+    if (lane < 4 && row0 + lane < rows) {
+        myid = seq[row0 + lane];
+        if (myid < 0 || myid >= V) { atomicOr(status, ADER_ST_BAD_ID); myid = 0; }
+    }
+    f32x2e e[NI], q[NI];
+    int id[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {          // (row 0 of the table is read for padding ids and ignored: no load under a branch)
+        const int p = min(lane + 64 * k, NP - 1);
+        const int u = p / PR, c = 2 * (p - u * PR);
+        id[k] = __shfl(myid, u, 64);
+        const int row = min(row0 + u, rows - 1);
+        e[k] = *(const f32x2e*)(emb + (size_t)id[k] * H + c);
+        q[k] = *(const f32x2e*)(pos + (size_t)(row % T) * H + c);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int p = lane + 64 * k;
+        const int u = min(p, NP - 1) / PR, c = 2 * (min(p, NP - 1) - u * PR);
+        const int row = row0 + u;
+        if (p >= NP || row >= rows) continue;
+        f32x2e o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v = (id[k] != 0 ? e[k][j] * sqrtH : 0.0f) + q[k][j];
+            v = drop_apply(d, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j), v);
+            o[j] = (id[k] != 0) ? v : 0.0f;
+        }
+        __builtin_nontemporal_store(o, (f32x2e*)(x + (size_t)row * H + c));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ seq, const float* __restrict__ emb,
                                                    const float* __restrict__ pos, float* __restrict__ x,
                                                    int rows, int T, int H, int V, float sqrtH, DropArgs d,
@@ -502,8 +548,10 @@ int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x,
     if (rows <= 0) return 0;
     // 16 rows per workgroup.  (Persistent waves -- 8 workgroups per CU sweeping the rows with the next step's ids requested a step
     // ahead -- measured SLOWER: 175 vs 150-158 us for 409,600 rows; short-lived waves keep more rows in flight.)
-    hipLaunchKernelGGL(k_embed_fwd, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, H, V,
-                       sqrtf((float)H), drop_from(drop), status);
+    if (H == 150) hipLaunchKernelGGL(k_embed_fwd150, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, V,
+                                     sqrtf((float)H), drop_from(drop), status);
+    else hipLaunchKernelGGL(k_embed_fwd, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, seq, emb, pos, x, rows, T, H, V,
+                            sqrtf((float)H), drop_from(drop), status);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -307,7 +307,7 @@ def main():
         gbytes = B * T * (4 + 2 * H * 4) / 1e9                    # ids + one table row read + one row written
         gather = {"kernel": "k_embed_fwd (standalone)", "us": round(us, 2), "bytes": B * T * (4 + 2 * H * 4),
                   "GBps": round(gbytes / (us * 1e-6), 1), "frac_hbm": round(gbytes / (us * 1e-6) / HBM_PEAK_GBS, 4),
-                  "note": "25,600 random 600-B rows of a 600 MB table + 15.4 MB written: latency / launch bound at this size"}
+                  "note": "25,600 random 600-B rows of a 600 MB table + 15.4 MB written (one launch of ~7 us: launch / latency bound at this size); H = 150: rows as packed 8-byte pieces, nontemporal stores"}
         if N >= 100_000:
             # the same kernel on 16 batches' worth of ids (409,600 random rows, 493 MB): what the gather reaches when it is not launch-bound
             Bl = 16 * B
@@ -332,7 +332,7 @@ def main():
             gather["large"] = {"rows": Bl * T, "us": round(usl, 2), "bytes": Bl * T * (4 + 2 * H * 4), "GBps": round(gl / (usl * 1e-6), 1),
                                "frac_hbm": round(gl / (usl * 1e-6) / HBM_PEAK_GBS, 4), "us_no_dropout": round(use, 2),
                                "GBps_no_dropout": round(gl / (use * 1e-6), 1), "frac_hbm_no_dropout": round(gl / (use * 1e-6) / HBM_PEAK_GBS, 4),
-                               "note": "training prologue = gather + counter-hash dropout (two integer multiplies per element: vector-bound)"}
+                               "note": "training prologue = gather + counter-hash dropout; 16 batches of ids back to back"}
             del seql, xl
 
     P, span = eng.P, eng.layout["pos"][0]
