@@ -781,24 +781,12 @@ class Engine:
             Bp = (Bb + 127) // 128 * 128
             lab, ncol = self.buf("ri_lab", (Bp,), torch.int32), self.buf("ri_ncol", (Bp,), torch.int32)
             wrow, trow = self.buf("ri_w", (Bp,)), self.buf("ri_trow", (Bp,), torch.int32)
-            ri_side = bool(defer and self.dp_world == 1 and self.lists_side_stream and self._main is not None)
-            if ri_side:
-                # ... and on the side stream, beside k_seq_fwd (round 4): nothing but the logit forward's prep launch waits for it
-                if getattr(self, "_side", None) is None:
-                    self._side = torch.cuda.Stream(device=self.device, priority=-1)
-                self._side.wait_stream(self._main)       # the previous step's update is done with the descriptors
-                with Engine._OnStream(self, self._side):
-                    call("ader_build_rowinfo", ptr(pos), n_train, None if split_kd else ptr(ex_pos), None, 0 if split_kd else n_ex, N,
-                         0, float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), self._stream())
-            else:
-                call("ader_build_rowinfo", ptr(pos), n_train, None if split_kd else ptr(ex_pos), None, 0 if split_kd else n_ex, N, 0,
-                     float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
-        else:
-            ri_side = False
+            # (tried in round 4: the same launch on the side stream beside k_seq_fwd -- the cross-stream wait that then precedes the logit
+            #  forward costs 12 us against 6 for the launch itself: profiles/r4x_timeline.txt)
+            call("ader_build_rowinfo", ptr(pos), n_train, None if split_kd else ptr(ex_pos), None, 0 if split_kd else n_ex, N, 0,
+                 float(w_train), float(w_ex), Bp, ptr(lab), ptr(ncol), ptr(wrow), ptr(trow), st)
         with self._sec("blocks_fwd"):
             rep = self.forward(seq, training=True, rate=rate, step=step, save=True)
-        if ri_side:
-            self._main.wait_stream(self._side)           # (before the lists are queued on the side stream: only the descriptors)
         if kd_fast or kd_fast_unfused:
             return self._loss_and_grad_kd_fast(seq, pos, rep, n_train, n_ex, N, Np, teacher, ex_trow, w_train, w_ex, fused=kd_fast)
         if defer and self.dp_world == 1:
