@@ -11,6 +11,7 @@ accuracy table of the reference's poster (ADER Recall@20 
 
 Data order follows the reference's RNG streams only until early stopping first differs, so the parity is
 statistical, not bitwise."""
+import json
 import os
 import tempfile
 
@@ -104,6 +105,20 @@ def test_baselines_match_the_published_curves(dataset, method, flags, tol_avg, t
     extra = ["--batch_size", "512", "--test_batch", "64"] if dataset == "YOOCHOOSE" else []
     out = _run(["--dataset", dataset, "--logits_dtype", "x3", "--save_dir", method] + extra + flags)
     _against_figure(out, dataset, method, tol_avg, tol_period)
+    if dataset == "DIGINETICA" and method == "Finetune":
+        # ... and against the ORACLE's own 16-period run of the same configuration (tests/golden/make_oracle_finetune16.py: the CPU
+        # restatement through the whole continual loop, 1.2 CPU-hours; itself asserted against the figure by tests/test_oracle_model.py):
+        # same data, same seeds, same flags -- the two trajectories differ by arithmetic only (and by what early stopping makes of it)
+        orc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_finetune16.json")))
+        assert len(orc["periods"]) == 16
+        for key, tol_a, tol_p in (("recall20", 0.5, 0.7), ("mrr20", 0.35, 0.45)):
+            mine = [100.0 * p_[key] for p_ in out["periods"]]
+            theirs = [100.0 * p_[key] for p_ in orc["periods"]]
+            d_avg = sum(mine) / 16 - sum(theirs) / 16
+            mad = sum(abs(a - b) for a, b in zip(mine, theirs)) / 16
+            print("DIGINETICA Finetune %s: HIP average %.2f, oracle %.2f (delta %+.2f), per-period mean |delta| %.2f"
+                  % (key, sum(mine) / 16, sum(theirs) / 16, d_avg, mad))
+            assert abs(d_avg) <= tol_a and mad <= tol_p, (key, d_avg, mad)
 
 
 def test_diginetica_ader_float32_grade_inside_the_poster_band():

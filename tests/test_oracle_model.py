@@ -166,3 +166,25 @@ def test_oracle_trained_on_period_1_lands_on_the_published_curve(golden_dir):
     assert abs(100.0 * ft["test"]["mrr20"] - sum(m_ft) / 2) <= 0.35, (ft["test"], m_ft)
     # and the oracle reproduces the reference's dropout effect at period 1 (about +3 points of Recall@20)
     assert 2.0 <= r20 - 100.0 * ft["test"]["recall20"] <= 4.0
+
+
+def test_oracle_finetune_16_periods_follow_the_published_curve(golden_dir):
+    """The oracle through the reference's WHOLE continual loop: tests/golden/make_oracle_finetune16.py ran oracle/ader_ref_cpu.py
+    (torch-CPU float32, TF-Adam) as the Finetune baseline (main.py:141-146: dropout 0, no exemplars; previous best state restored per
+    period, early stopping, test on the next period) over the 16 DIGINETICA periods in the build container (66 CPU-minutes) and recorded
+    the per-period test metrics.  Against the Finetune curve of the reference's published figure (results.svg): 16-period averages
+    47.53 / 16.18 against 47.28 / 16.01, per-period mean |delta| 0.43 / 0.23 (largest 1.22 / 0.54) -- the spread between two runs of the
+    reference itself (its period-1 points of one configuration differ by 0.28).  The HIP engine's run of the same configuration is
+    compared with these 16 values in tests/test_gpu_e2e_parity.py."""
+    import json
+    rec = json.load(open(os.path.join(golden_dir, "oracle_finetune16.json")))
+    ref = json.load(open(os.path.join(golden_dir, "results_svg_curves.json")))["curves"]["DIGINETICA"]["Finetune"]
+    per = rec["periods"]
+    assert [p["period"] for p in per] == list(range(1, 17)) and per[-1]["max_item"] == 43105
+    assert all(p["epochs_run"] == p["best_epoch"] + 5 for p in per)          # early stopping ran its patience in every period
+    for key, tol_avg, tol_mad in (("recall20", 0.5, 0.6), ("mrr20", 0.35, 0.35)):
+        mine = [100.0 * p[key] for p in per]
+        avg, avg_ref = sum(mine) / 16, sum(ref[key]) / 16
+        mad = sum(abs(a - b) for a, b in zip(mine, ref[key])) / 16
+        assert abs(avg - avg_ref) <= tol_avg, (key, avg, avg_ref)
+        assert mad <= tol_mad, (key, mad)
