@@ -1,0 +1,142 @@
+"""Third pin of the MODEL-MATH ORACLE against values the reference publishes (build container only; ~3 CPU-hours on 8 threads).
+
+The METHOD ITSELF this time: ADER with its default flags (main.py:76-107: herding exemplars, adaptive distillation, dropout 0.3) over the
+16 DIGINETICA periods, computed by oracle/ader_ref_cpu.py (torch-CPU float32, autograd, TF-Adam; the distillation loss of ADER.py:132-137)
+and oracle/herding_ref.py (the canonical float32 herding loop of util.py:419-432).  The continual-learning loop is the product's own
+host driver, ader_amd/main.py::run -- pinned line by line to the reference's main.py and, for the feeders and the exemplar bookkeeping
+it calls, by the golden fixtures -- with the HIP model swapped for an oracle-backed stand-in of the same call surface (train_step,
+rank_targets, engine.herding_select / teacher_logits / state_dict): no HIP kernel runs.  Output: tests/golden/oracle_ader16.json;
+tests/test_oracle_model.py asserts it against the ADER curve of the reference's published figure (results.svg), and
+tests/test_gpu_e2e_parity.py compares the HIP engine's run with these 16 values.
+
+    python tests/golden/make_oracle_ader16.py [--max_periods N] [--threads N]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import ader_ref_cpu as R  # noqa: E402
+from oracle import herding_ref  # noqa: E402
+import ader_amd.main as M  # noqa: E402  (host driver; importing it loads no HIP library)
+
+T, H, L, HEADS = 50, 150, 2, 1                             # main.py:99-105
+
+
+class OracleEngine:
+    """The part of ader_amd.engine.Engine's surface that main.run and ExemplarGenerator use, on the CPU oracle."""
+
+    def __init__(self, item_num, seed):
+        self.item_num, self.device, self.seed = item_num, torch.device("cpu"), seed
+        self.init_params(seed)
+
+    def init_params(self, seed):
+        self.params = R.init_params(self.item_num, T, H, L, seed=seed)
+        self.opt = R.TFAdam(self.params)
+        self.global_step = 0
+
+    def state_dict(self, to_cpu=False):
+        o = self.opt
+        return {"theta": {k: v.clone() for k, v in self.params.items()}, "m": {k: v.clone() for k, v in o.m.items()},
+                "v": {k: v.clone() for k, v in o.v.items()}, "pow": (o.b1p, o.b2p, o.t), "global_step": self.global_step}
+
+    def load_state_dict(self, st):
+        with torch.no_grad():
+            for k in self.params:
+                self.params[k].copy_(st["theta"][k]); self.opt.m[k].copy_(st["m"][k]); self.opt.v[k].copy_(st["v"][k])
+        self.opt.b1p, self.opt.b2p, self.opt.t = st["pow"]
+        self.global_step = st["global_step"]
+
+    def check_status(self):
+        pass
+
+    def _encode(self, rows):
+        out = []
+        with torch.no_grad():
+            for i in range(0, len(rows), 2048):
+                out.append(R.forward_rep(self.params, np.asarray(rows[i:i + 2048]), L, HEADS))     # eval mode (util.py:449-453)
+        return torch.cat(out) if out else torch.zeros(0, H)
+
+    def herding_select(self, seq_rows, offs, quota, max_item):
+        rep = self._encode(seq_rows).numpy().astype(np.float32)
+        n, G = rep.shape[0], len(quota)
+        sel, cnt = np.zeros(n, dtype=np.int64), np.zeros(G, dtype=np.int32)
+        for g in range(G):
+            if quota[g] > 0:
+                idx, _ = herding_ref.herding_select(rep[offs[g]:offs[g + 1]], int(quota[g]))
+                sel[offs[g]:offs[g] + len(idx)] = idx
+                cnt[g] = len(idx)
+        return sel, cnt
+
+    def teacher_logits(self, seq_rows, max_item):
+        out = []
+        with torch.no_grad():
+            for i in range(0, len(seq_rows), 2048):
+                rep = R.forward_rep(self.params, np.asarray(seq_rows[i:i + 2048]), L, HEADS)
+                out.append(R.logits_from_rep(self.params, rep, max_item).float())
+        return torch.cat(out) if out else torch.zeros(0, max_item)
+
+
+class OracleAder:
+    """Call surface of ader_amd.model.Ader as main.run uses it."""
+
+    def __init__(self, item_num, args, device=None, dp_rank=0, dp_world=1):
+        assert dp_world == 1
+        self.args = args
+        self.engine = OracleEngine(item_num, args.random_seed)
+        self.lambda_ = None
+
+    def set_vanilla_loss(self):
+        self.lambda_ = None
+
+    def update_loss(self, lambda_):
+        self.lambda_ = float(lambda_)
+
+    def train_step(self, seq, pos, max_item, lr, rate, teacher=None, ex_trow=None, ex_pos=None, **kw):
+        e = self.engine
+        extra = {}
+        if teacher is not None:
+            extra = {"ex_logits": teacher[torch.as_tensor(np.asarray(ex_trow), dtype=torch.long)], "lambda_": self.lambda_}
+        elif ex_pos is not None:
+            extra = {"ex_pos": np.asarray(ex_pos), "lambda_": self.lambda_}
+        loss = R.train_step(e.params, e.opt, np.asarray(seq), np.asarray(pos), max_item, L, HEADS, lr, training=True, rate=rate,
+                            seed=e.seed, step=e.global_step, **extra)
+        e.global_step += 1
+        return loss
+
+    def rank_targets(self, seq, pos, max_item):
+        with torch.no_grad():
+            rep = R.forward_rep(self.engine.params, np.asarray(seq), L, HEADS)
+            logits = R.logits_from_rep(self.engine.params, rep, max_item)
+            tgt = torch.as_tensor(np.asarray(pos), dtype=torch.long) - 1
+            t = logits.gather(1, tgt[:, None])
+            idx = torch.arange(max_item)[None, :]
+            return ((logits > t) | ((logits == t) & (idx < tgt[:, None]))).sum(1).numpy()      # ties: lower index first (ADER.py:103)
+
+
+def main():
+    argv = sys.argv[1:]
+    threads = os.cpu_count()
+    if "--threads" in argv:
+        i = argv.index("--threads"); threads = int(argv[i + 1]); del argv[i:i + 2]
+    torch.set_num_threads(threads)
+    M.Ader = OracleAder                                    # the only substitution: everything else is the product's host driver
+    args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--device_feed", "False", "--save_dir", "oracle-ader16",
+                                        "--results_root", "/tmp/oracle_ader16"] + argv)
+    t0 = time.time()
+    out = M.run(args)
+    rec = {"dataset": "DIGINETICA", "config": "ADER, default flags (herding exemplars 30000, lambda_ 0.8 adaptive, dropout 0.3), random_seed 0",
+           "periods": out["periods"], "average": out["average"], "torch": torch.__version__, "threads": threads,
+           "minutes": round((time.time() - t0) / 60.0, 1)}
+    json.dump(rec, open(os.path.join(ROOT, "tests", "golden", "oracle_ader16.json"), "w"), indent=1)
+    print(json.dumps(rec["average"]))
+
+
+if __name__ == "__main__":
+    main()
