@@ -130,6 +130,20 @@ def test_diginetica_ader_float32_grade_inside_the_poster_band():
     assert 49.4 <= r20 <= 50.6, ("Recall@20 outside the poster band", r20)
     assert 16.9 <= m20 <= 17.7, ("MRR@20 outside the poster band", m20)
     _against_figure(out, "DIGINETICA", "ADER", 0.5, 0.8)      # the figure: 50.21 / 17.32
+    # ... and against the ORACLE's own 16-period ADER run (tests/golden/make_oracle_ader16.py: oracle/ader_ref_cpu.py + oracle/herding_ref.py
+    # through the same host loop, ~4 CPU-hours; itself asserted against the figure by tests/test_oracle_model.py): same data, seeds and flags
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_ader16.json")
+    if os.path.exists(path):
+        orc = json.load(open(path))
+        assert len(orc["periods"]) == 16
+        for key, tol_a, tol_p in (("recall20", 0.6, 0.8), ("mrr20", 0.35, 0.45)):
+            mine = [100.0 * p_[key] for p_ in out["periods"]]
+            theirs = [100.0 * p_[key] for p_ in orc["periods"]]
+            d_avg = sum(mine) / 16 - sum(theirs) / 16
+            mad = sum(abs(a - b) for a, b in zip(mine, theirs)) / 16
+            print("DIGINETICA ADER %s: HIP average %.2f, oracle %.2f (delta %+.2f), per-period mean |delta| %.2f"
+                  % (key, sum(mine) / 16, sum(theirs) / 16, d_avg, mad))
+            assert abs(d_avg) <= tol_a and mad <= tol_p, (key, d_avg, mad)
 
 
 # ---- the other columns of the poster's DIGINETICA table (reference flags main.py:83-91, command lines
