@@ -131,12 +131,13 @@ def test_diginetica_ader_float32_grade_inside_the_poster_band():
     assert 16.9 <= m20 <= 17.7, ("MRR@20 outside the poster band", m20)
     _against_figure(out, "DIGINETICA", "ADER", 0.5, 0.8)      # the figure: 50.21 / 17.32
     # ... and against the ORACLE's own 16-period ADER run (tests/golden/make_oracle_ader16.py: oracle/ader_ref_cpu.py + oracle/herding_ref.py
-    # through the same host loop, ~4 CPU-hours; itself asserted against the figure by tests/test_oracle_model.py): same data, seeds and flags
+    # through the same host loop, 239 CPU-minutes; itself asserted against the figure by tests/test_oracle_model.py): same data, seeds and flags
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_ader16.json")
     if os.path.exists(path):
         orc = json.load(open(path))
         assert len(orc["periods"]) == 16
-        for key, tol_a, tol_p in (("recall20", 0.6, 0.8), ("mrr20", 0.35, 0.45)):
+        # (measured at the end of round 4: averages 50.19 / 17.40 against the oracle's 50.28 / 17.42, per-period mean |delta| 0.22 / 0.08)
+        for key, tol_a, tol_p in (("recall20", 0.45, 0.6), ("mrr20", 0.3, 0.35)):
             mine = [100.0 * p_[key] for p_ in out["periods"]]
             theirs = [100.0 * p_[key] for p_ in orc["periods"]]
             d_avg = sum(mine) / 16 - sum(theirs) / 16

@@ -195,17 +195,16 @@ def test_oracle_finetune_16_periods_follow_the_published_curve(golden_dir):
 def test_oracle_ader_16_periods_follow_the_published_curve(golden_dir):
     """The METHOD through the oracle: tests/golden/make_oracle_ader16.py ran ADER with its default flags (herding exemplars, adaptive
     distillation, dropout 0.3) over the 16 DIGINETICA periods on oracle/ader_ref_cpu.py + oracle/herding_ref.py, driven by the product's
-    host loop with the HIP model swapped for an oracle-backed stand-in (no HIP kernel runs; ~3 CPU-hours).  Against the ADER curve of the
-    reference's published figure (16-period averages 50.21 / 17.32)."""
+    host loop with the HIP model swapped for an oracle-backed stand-in (no HIP kernel runs; 239 CPU-minutes).  Against the ADER curve of the
+    reference's published figure: 16-period averages 50.28 / 17.42 against 50.21 / 17.32, per-period mean |delta| 0.20 / 0.12 (largest
+    0.69 / 0.26) -- the oracle, its distillation loss and the herding restatement included, reproduces the published run period by period."""
     import json
     path = os.path.join(golden_dir, "oracle_ader16.json")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/oracle_ader16.json not generated")
     rec = json.load(open(path))
     ref = json.load(open(os.path.join(golden_dir, "results_svg_curves.json")))["curves"]["DIGINETICA"]["ADER"]
     per = rec["periods"]
     assert [p["period"] for p in per] == list(range(1, 17)) and per[-1]["max_item"] == 43105
-    for key, tol_avg, tol_mad in (("recall20", 0.5, 0.7), ("mrr20", 0.35, 0.4)):
+    for key, tol_avg, tol_mad in (("recall20", 0.3, 0.4), ("mrr20", 0.25, 0.25)):
         mine = [100.0 * p[key] for p in per]
         avg, avg_ref = sum(mine) / 16, sum(ref[key]) / 16
         mad = sum(abs(a - b) for a, b in zip(mine, ref[key])) / 16
