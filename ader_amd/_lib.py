@@ -98,6 +98,14 @@ _SIGS = {
     "ader_reduce_slabs": [P, L, I, I, I, I, P, P, P],
     "ader_reduce_slabs_batch": [P, P, P, P, P, P, P, P, I, P],
     "ader_pack_plan": [P, I, I, I, I, I, P, P, P, P, P, P],
+    "ader_seq_pack_plan": [P, I, I, I, I, I, I, I, I, P, P],
+    "ader_seqp_fwd": [P, P, I, P],
+    "ader_seqp_bwd_ffn": [P, P, I, P],
+    "ader_seqp_bwd_qkv": [P, P, I, P],
+    "ader_attnp_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I] + _DROP + [P, I, P],
+    "ader_attnp_last_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I] + _DROP + [P, P],
+    "ader_pos_grad_packed": [P, P, P, I, I, I, P],
+    "ader_gemm_atb_x3_batch_pk": [P, P, P, P, P, P, P, P, I, P, I, P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
     "ader_herding_select_generic": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
@@ -121,6 +129,11 @@ class AderSeqFwd(ctypes.Structure):
     _fields_ = ([(k, c_void_p) for k in ("seq", "emb", "pos", "x0", "status", "lnf_g", "lnf_b", "rep", "meanf", "stdf")] +
                 [(k, c_int) for k in ("B", "T", "H", "V", "L")] + [("sqrtH", c_float), ("sqrt_dh", c_float), ("pad_", c_int),
                                                                   ("d_emb", AderDrop), ("blk", AderSeqBlock * SEQ_MAXL)])
+
+
+class AderSeqPack(ctypes.Structure):
+    """include/ader_hip.h: AderSeqPack (device arrays of the packing plan)"""
+    _fields_ = [(k, c_void_p) for k in ("hdr", "tile_rows", "ids", "lpos", "gpos", "info", "srow0", "slen")]
 
 
 class AderSeqBwdFfn(ctypes.Structure):

@@ -265,6 +265,9 @@ __global__ __launch_bounds__(320) void k_gemm_atb_x3(const float* __restrict__ A
 struct AtbBatch {
     const float* A[ATB_MAX]; const float* G[ATB_MAX]; float* dW[ATB_MAX]; float* db[ATB_MAX];
     int M[ATB_MAX]; int wg0[ATB_MAX + 1]; int n;
+    // packed session tiles (seqp_*.hip): the operands of product y are in tile order -- 64-row tiles of which tile u holds trows[y][u]
+    // rows (the rest was never written) -- and *Mdev[y] = 64 x the number of tiles bounds M[y], the host's upper bound.  NULL: plain rows
+    const int* Mdev[ATB_MAX]; const int* trows[ATB_MAX];
 };
 // dW[y] = sum of product y's slabs (fixed order), row H of the augmented slab -> db[y].  grid (blocks of 64 outputs, n).
 __global__ __launch_bounds__(256) void k_atb_reduce_batch(AtbBatch b, const float* __restrict__ slab, int H) {
@@ -316,7 +319,9 @@ __global__ __launch_bounds__(256, 3) void k_gemm_atb_x3_sm(AtbBatch b, float* __
     while (y + 1 < b.n && (int)blockIdx.x >= b.wg0[y + 1]) ++y;
     const float* __restrict__ A = b.A[y];
     const float* __restrict__ G = b.G[y];
-    const int M = b.M[y];
+    int M = b.M[y];
+    const int* __restrict__ trows = b.trows[y];
+    if (b.Mdev[y]) M = min(M, *b.Mdev[y]);
     const int wg = blockIdx.x - b.wg0[y], nwg = b.wg0[y + 1] - b.wg0[y];
     float* __restrict__ out = slab + (size_t)blockIdx.x * HP * HP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -336,6 +341,11 @@ __global__ __launch_bounds__(256, 3) void k_gemm_atb_x3_sm(AtbBatch b, float* __
     __syncthreads();
     for (int tile = wg; tile < n_tiles; tile += nwg) {
         const int m0 = tile * SM_TM;
+        int mlim = M - m0;                                 // rows of this 32-row tile that exist
+        if (trows) {
+            mlim = min(mlim, trows[m0 >> 6] - (m0 & 63));
+            if (mlim <= 0) continue;                       // (workgroup-uniform: the second half of a session tile with <= 32 rows)
+        }
         // ---- stage: slot s = (row m = s / nkc, k-chunk kc = s % nkc): consecutive lanes read consecutive 32-byte pieces of a row
 #pragma unroll
         for (int op = 0; op < 2; ++op) {               // one operand at a time: 40 staging registers beside the 100 accumulators
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_atb_x3_sm(AtbBatch b, float* __
             for (int r = 0; r < 5; ++r) {
                 const int s = tid + 256 * r;
                 const int m = s / nkc, kc = s - m * nkc;
-                const bool rowok = s < nslot && m0 + m < M;
+                const bool rowok = s < nslot && m < mlim;
                 const float* ps = src + (size_t)(m0 + m) * H + 8 * kc;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[r][j] = make_float2(0.f, 0.f);
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_atb_x3_sm(AtbBatch b, float* __
                     float x[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { x[2 * j] = v[r][j].x; x[2 * j + 1] = v[r][j].y; }
-                    if (op == 0 && kc == (H >> 3) && m0 + m < M) x[H & 7] = 1.0f;          // ones column
+                    if (op == 0 && kc == (H >> 3) && m < mlim) x[H & 7] = 1.0f;          // ones column
                     bf16x8 h_, l_;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { h_[j] = (bf16)x[j]; l_[j] = (bf16)(x[j] - (float)h_[j]); }
@@ -514,6 +524,30 @@ int ader_gemm_atb_batch_slabs(const int* M, int n) {
     return wg0[n];
 }
 
+// ... with operands in the tile order of the packed session kernels (include/ader_hip.h): Mplan[i] = the row count the workgroups
+// are shared out by (the host's estimate of the rows that exist; M[i] stays the bound of the addresses), Mdev[i] / trows[i] device
+// pointers or NULL per product.  Slabs: ader_gemm_atb_batch_slabs(Mplan, n).
+int ader_gemm_atb_x3_batch_pk(const float* const* A, const float* const* G, float* const* dW, float* const* db, const int* M,
+                              const int* Mplan, const int* const* Mdev, const int* const* trows, int n, float* slab, int H, void* stream) {
+    if (n <= 0) return 0;
+    if (n > ATB_MAX) return -2;
+    if (H >= HP || H < 2 || (H & 1) || H > 2 * PFA * 5) return -2;
+    AtbBatch b;
+    for (int i = 0; i < n; ++i) {
+        if (M[i] <= 0 || (Mplan && (Mplan[i] <= 0 || Mplan[i] > M[i]))) return -2;
+        b.A[i] = A[i]; b.G[i] = G[i]; b.dW[i] = dW[i]; b.db[i] = db[i]; b.M[i] = M[i];
+        b.Mdev[i] = Mdev ? Mdev[i] : nullptr; b.trows[i] = trows ? trows[i] : nullptr;
+    }
+    b.n = n;
+    atb_batch_plan(Mplan ? Mplan : M, n, b.wg0);
+    if (H == 150) hipLaunchKernelGGL(k_gemm_atb_x3_sm<150>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
+    else hipLaunchKernelGGL(k_gemm_atb_x3_sm<0>, dim3(b.wg0[n]), dim3(256), SM_LDS, (hipStream_t)stream, b, slab, H);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_atb_reduce_batch, dim3(((H + 1) * H + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, b, slab, H);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* const* dW, float* const* db, const int* M, int n,
                            float* slab, int H, void* stream) {
     if (n <= 0) return 0;
@@ -523,6 +557,7 @@ int ader_gemm_atb_x3_batch(const float* const* A, const float* const* G, float* 
     for (int i = 0; i < n; ++i) {
         if (M[i] <= 0) return -2;
         b.A[i] = A[i]; b.G[i] = G[i]; b.dW[i] = dW[i]; b.db[i] = db[i]; b.M[i] = M[i];
+        b.Mdev[i] = nullptr; b.trows[i] = nullptr;
     }
     b.n = n;
     atb_batch_plan(M, n, b.wg0);

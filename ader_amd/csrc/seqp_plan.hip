@@ -1,0 +1,159 @@
+// Packing plan of the packed session kernels (seqp_fwd.hip, seqp_bwd.hip): one launch, one workgroup.
+//
+// The reference left-pads every session to maxlen (util.py:161-169); on the shipped splits ~90 % of the positions are padding.
+// A padded position influences no real one -- its key is masked (modules.py:188-193), its outputs are re-zeroed (ADER.py:80),
+// its gradient is exactly zero -- so the session kernels may drop those rows altogether.  This kernel lays the REAL positions
+// of a batch out in 64-row tiles: several short sessions share a tile (attention becomes block-diagonal inside it), a tile never
+// splits a session, sessions keep their batch order inside a tile.  The activations of the packed kernels live in this layout
+// ([tile*64 + row, H]); only the representations [B,H], the compact tensors of a pruned last block [B,..] and the gradient rows
+// of the input embeddings [B*T,H] stay session-indexed.
+//
+// Packing rule (no sequential dependency between sessions, so it is two scans): sessions fall into three classes by length --
+// short (<= 16), medium (<= 32), long; inside a class the sessions' rows form one stream in batch order and a session goes to the
+// tile floor(start / w) of the stream offset it starts at; because a session is shorter than 64 - w + 1 the rows that land in a
+// tile never exceed 64 (w <= 49 for short, 33 for medium; long sessions get a tile each).  w of the short class shrinks when the
+// batch would otherwise fill fewer tiles than the chip has CUs (`target`): the session kernels are latency-bound per tile, a
+// half-filled tile is faster than a full one, and an idle CU is worth nothing.
+//
+// Outputs (AderSeqPack): hdr = {tiles, 64 tiles, real positions, w}; per tile its row count; per packed row the local position
+// b*T + t (ids, positional row), the GLOBAL position (dropout counters: a data-parallel rank draws the masks of its global
+// rows, include/ader_hip.h AderDrop) and info = first row of its session in the tile | last-row flag << 6 | t << 8 | b << 16;
+// per session its first packed row and its length.  An all-padding session keeps position T-1 (one row of id 0), so that every
+// session has a last row.  gfx950 only.
+#include "common.h"
+#include "../../include/ader_hip.h"
+
+#define PLAN_MAXB 4096
+#define PLAN_THREADS 1024
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// exclusive scan of one int per thread over the workgroup; returns the exclusive prefix, *total = sum.  tmp: 16 ints of LDS
+__device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PLAN_THREADS / 64; ++w) {
+        const int x = tmp[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __restrict__ seq, int B, int T, int row0, int split_rows,
+                                                                int row0_ex, int w1_min, int w1_max, int target, AderSeqPack o) {
+    __shared__ unsigned char len_l[PLAN_MAXB];
+    __shared__ int first_l[PLAN_MAXB], end_l[PLAN_MAXB];
+    __shared__ unsigned short tile_l[PLAN_MAXB];
+    __shared__ int off_l[PLAN_MAXB];
+    __shared__ int tmp[16];
+    __shared__ int tot_l;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- lengths: one wave-load per session
+    for (int s = wave; s < B; s += PLAN_THREADS / 64) {
+        const int id = (lane < T) ? seq[(size_t)s * T + lane] : 0;
+        const unsigned long long nz = __ballot(id != 0);
+        const int tv0 = nz ? (int)__ffsll((long long)nz) - 1 : T - 1;
+        if (lane == 0) len_l[s] = (unsigned char)(T - tv0);
+    }
+    if (tid == 0) tot_l = 0;
+    for (int i = tid; i < PLAN_MAXB; i += PLAN_THREADS) { first_l[i] = 0x7fffffff; end_l[i] = 0; }
+    __syncthreads();
+    // ---- stream offsets per class (thread t owns sessions [t spt, (t+1) spt))
+    const int spt = (B + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int s0 = tid * spt, s1 = min(B, s0 + spt);
+    int a1 = 0, a2 = 0, a3 = 0;
+    for (int s = s0; s < s1; ++s) {
+        const int ln = len_l[s];
+        if (ln <= 16) a1 += ln; else if (ln <= 32) a2 += ln; else a3 += 1;
+    }
+    int P1, P2, C3;
+    int e1 = block_excl_scan(a1, tmp, &P1);
+    int e2 = block_excl_scan(a2, tmp, &P2);
+    int e3 = block_excl_scan(a3, tmp, &C3);
+    int w1 = w1_max;
+    if (target > 0) w1 = max(w1_min, min(w1_max, (P1 + target - 1) / target));
+    w1 = max(1, min(49, w1));
+    const int w2 = 33;
+    const int n1 = P1 > 0 ? (P1 - 1) / w1 + 1 : 0;       // upper bound of the short tiles (tiles beyond the last start stay empty: none, see below)
+    const int n2 = P2 > 0 ? (P2 - 1) / w2 + 1 : 0;
+    // (every window [k w, (k+1) w) below the stream's end holds at least one session start, because a session is shorter than w or, when it is
+    //  not (w1 < 16), the tile index is compacted below by counting the windows that do hold a start)
+    for (int s = s0; s < s1; ++s) {
+        const int ln = len_l[s];
+        int tile, st;
+        if (ln <= 16) { st = e1; tile = e1 / w1; e1 += ln; }
+        else if (ln <= 32) { st = e2; tile = n1 + e2 / w2; e2 += ln; }
+        else { st = 0; tile = n1 + n2 + e3; e3 += 1; }
+        tile_l[s] = (unsigned short)tile; off_l[s] = st;
+        atomicMin(&first_l[tile], st);
+        atomicMax(&end_l[tile], st + ln);
+    }
+    __syncthreads();
+    // ---- compact the tile numbering (a window without a session start is no tile: possible only for w1 < 16)
+    const int nt_raw = n1 + n2 + C3;
+    int cnt = 0;
+    const int tpt = (nt_raw + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int t0 = tid * tpt, t1 = min(nt_raw, t0 + tpt);
+    for (int t = t0; t < t1; ++t) cnt += (end_l[t] > 0) ? 1 : 0;
+    int ntiles;
+    int tb = block_excl_scan(cnt, tmp, &ntiles);
+    __syncthreads();
+    // end_l[raw tile] becomes its compact index
+    for (int t = t0; t < t1; ++t) {
+        const int e = end_l[t];
+        if (e > 0) {
+            o.tile_rows[tb] = e - first_l[t];
+            end_l[t] = tb++;                    // raw -> compact index
+        } else end_l[t] = -1;
+    }
+    __syncthreads();
+    int tot = 0;
+    // ---- per session / per row outputs: one wave per session, lane k = its k-th real position
+    for (int s = wave; s < B; s += PLAN_THREADS / 64) {
+        const int ln = len_l[s], raw = tile_l[s];
+        const int tile = end_l[raw];
+        const int r0 = off_l[s] - first_l[raw];               // first row of the session inside its tile
+        const int p0 = tile * 64 + r0;
+        if (lane == 0) { o.srow0[s] = p0; o.slen[s] = ln; }
+        if (lane < ln) {
+            const int t = T - ln + lane;
+            o.ids[p0 + lane] = seq[(size_t)s * T + t];
+            const int gb = (split_rows >= 0 && s >= split_rows) ? s - split_rows + row0_ex : s + row0;
+            o.lpos[p0 + lane] = s * T + t;
+            o.gpos[p0 + lane] = (unsigned)gb * (unsigned)T + (unsigned)t;
+            o.info[p0 + lane] = r0 | ((lane == ln - 1) ? 64 : 0) | (t << 8) | (s << 16);
+        }
+        tot += ln;
+    }
+    if (lane == 0) atomicAdd(&tot_l, tot);
+    __syncthreads();
+    if (tid == 0) { o.hdr[0] = ntiles; o.hdr[1] = ntiles * 64; o.hdr[2] = tot_l; o.hdr[3] = w1; }
+}
+
+extern "C" {
+
+int ader_seq_pack_plan(const int* seq, int B, int T, int row0, int split_rows, int row0_ex, int w1_min, int w1_max, int target,
+                       const AderSeqPack* out, void* stream) {
+    if (B <= 0) return 0;
+    if (B > PLAN_MAXB || T < 1 || T > 64 || !out) return -2;
+    hipLaunchKernelGGL(k_seq_pack_plan, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, seq, B, T, row0, split_rows, row0_ex,
+                       w1_min, w1_max, target, *out);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

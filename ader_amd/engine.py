@@ -221,6 +221,14 @@ class Engine:
         self.gemm_x3 = gemm == "x3" and hidden_units % 2 == 0 and hidden_units <= 150
         # whole forward stack in one launch (seq_fwd.hip); the per-op kernels remain for the shapes it does not cover
         self.seq_fused = (self.gemm_x3 and num_heads == 1 and maxlen <= 64 and num_blocks <= _lib.SEQ_MAXL)
+        # packed session tiles (csrc/seqp_*.hip): the session kernels run on the REAL positions only, several short sessions per
+        # 64-row tile.  True / False, or "auto": packed when the batch is sparse enough to pay for it -- decided from the host copy of
+        # the batch when the caller passes one (numpy input_seq), else from Engine.pack_density, the fraction of real positions the
+        # feeder announces (Sampler.to_device / main.py set it from the dataset; None = unknown = not packed)
+        self.pack_sessions = "auto"
+        self.pack_density = None
+        self.pack_window = (17, 49, 224)   # stream window of the short class: at least / at most / tile count aimed at (seqp_plan.hip)
+        self._pack_now = False
         self.lists_side_stream = True      # build the sparse lists under the block kernels
         self.late_side_stream = True       # small-parameter gradients / Adam run beside the (HBM-bound) fused table update
         self._late, self._late_on, self._late_force = [], False, False
@@ -488,11 +496,12 @@ class Engine:
             call("ader_gemm_rows", ptr(A), self._pp[wname], bias, ptr(C), ptr(aux), ptr(seq), M, self.H, epi, trans, rmap[0],
                  rmap[1], *d, self._stream())
 
-    def _atb(self, A, G, wname, bname, slab, M):
+    def _atb(self, A, G, wname, bname, slab, M, pack=None):
         """dW = A^T.G, db = colsum(G).  In x3 mode the products are queued (A and G stay untouched until the end of the
-        backward pass) and issued as one batched launch by _atb_flush."""
+        backward pass) and issued as one batched launch by _atb_flush.  pack: the operands are in tile order (packed session
+        kernels): the plan tells the product which rows exist."""
         if self.gemm_x3 and self.atb_batch:
-            self._atb_q.append((A, G, self._gp[wname], self._gp[bname], M))
+            self._atb_q.append((A, G, self._gp[wname], self._gp[bname], M, pack))
             if len(self._atb_q) == 16:
                 self._atb_flush()
             return
@@ -530,6 +539,17 @@ class Engine:
         n = len(q)
         VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
         Ms = IA(*[it[4] for it in q])
+        if any(it[5] is not None for it in q):
+            # tile-ordered operands: bound the rows on the device, mask the unwritten rows of every tile, and share the workgroups
+            # out by the rows expected to exist (the compact tensors of a pruned block are plain: every row exists)
+            Mp = IA(*[(min(it[4], it[5]["est"]) if it[5] is not None else it[4]) for it in q])
+            Md = VP(*[(it[5]["hdr"].data_ptr() + 4 if it[5] is not None else None) for it in q])
+            Tr = VP(*[(it[5]["trows"].data_ptr() if it[5] is not None else None) for it in q])
+            slabs = call("ader_gemm_atb_batch_slabs", Mp, n)
+            slab = self.buf("atb_slab", (slabs * 160 * 160,))
+            call("ader_gemm_atb_x3_batch_pk", VP(*[it[0].data_ptr() for it in q]), VP(*[it[1].data_ptr() for it in q]),
+                 VP(*[it[2] for it in q]), VP(*[it[3] for it in q]), Ms, Mp, Md, Tr, n, ptr(slab), self.H, self._stream())
+            return
         slabs = call("ader_gemm_atb_batch_slabs", Ms, n)
         slab = self.buf("atb_slab", (slabs * 160 * 160,))
         call("ader_gemm_atb_x3_batch", VP(*[it[0].data_ptr() for it in q]), VP(*[it[1].data_ptr() for it in q]),
@@ -541,6 +561,8 @@ class Engine:
         x[:, -1, :] (ADER.py:85) and rows interact only through K/V, so the other T-1 rows of that block are dead work."""
         self._refresh_stream()
         if self.seq_fused:
+            if self._use_pack(seq):
+                return self._forward_packed(seq, training, rate, step, save)
             return self._forward_fused(seq, training, rate, step, save)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
         rows = B * T
@@ -681,6 +703,128 @@ class Engine:
             self._act = A
         return rep
 
+    # ---------------------------------------------------------------------------------------- packed session tiles
+    PACK_DENSITY_MAX = 0.45      # "auto": pack when at most this fraction of the [B,T] positions is real
+
+    def _seq_in(self, seq):
+        """input_seq of a public entry point -> int32 device tensor.  A batch that arrives from the host (the reference-style feed
+        dict) shows "auto" packing its density: the fraction of real positions."""
+        if isinstance(seq, torch.Tensor):
+            self._density_now = None
+        else:
+            a = np.asarray(seq)
+            self._density_now = float(np.count_nonzero(a)) / max(a.size, 1)
+        return self._dev_i32(seq)
+
+    def _use_pack(self, seq):
+        if not (self.seq_fused and self.prune_last and self.H <= 150 and self.H % 2 == 0 and seq.shape[0] <= 4096):
+            return False
+        ps = self.pack_sessions
+        if ps == "auto":
+            d = getattr(self, "_density_now", None)
+            if d is None:
+                d = self.pack_density
+            return d is not None and d <= self.PACK_DENSITY_MAX
+        return bool(ps)
+
+    def _pack_plan(self, seq, tag):
+        """ader_seq_pack_plan for this batch: the tile layout of its real positions (device arrays; nothing comes back to the host --
+        the launches that follow are sized by the bound max_tiles = B and read the true counts on the device)."""
+        B, T = seq.shape[0], self.T
+        i32 = torch.int32
+        n = B * 64
+        hdr = self.buf(tag + "pq_hdr", (8,), i32, zero=True)
+        trows = self.buf(tag + "pq_trows", (B,), i32, zero=True)
+        ids, lpos = self.buf(tag + "pq_ids", (n,), i32, zero=True), self.buf(tag + "pq_lpos", (n,), i32, zero=True)
+        gpos, info = self.buf(tag + "pq_gpos", (n,), i32, zero=True), self.buf(tag + "pq_info", (n,), i32, zero=True)
+        srow0, slen = self.buf(tag + "pq_srow0", (B,), i32, zero=True), self.buf(tag + "pq_slen", (B,), i32, zero=True)
+        c = _lib.AderSeqPack()
+        c.hdr, c.tile_rows, c.ids, c.lpos, c.gpos, c.info, c.srow0, c.slen = (ptr(hdr), ptr(trows), ptr(ids), ptr(lpos), ptr(gpos),
+                                                                              ptr(info), ptr(srow0), ptr(slen))
+        split = -1 if self.split_rows is None else int(self.split_rows)
+        w1_min, w1_max, target = self.pack_window
+        call("ader_seq_pack_plan", ptr(seq), B, T, int(self.row0), split, int(self.row0_ex), w1_min, w1_max, target, ctypes.byref(c),
+             self._stream())
+        d = self.pack_density if self.pack_density is not None else 0.15
+        est = int(min(n, max(64, 1.25 * d * B * T + 64)))          # rows expected to exist: how the weight-gradient workgroups are shared out
+        return dict(c=c, ref=ctypes.byref(c), hdr=hdr, trows=trows, ids=ids, lpos=lpos, gpos=gpos, info=info, srow0=srow0, slen=slen,
+                    B=B, rows=n, max_tiles=B, est=est)
+
+    def unpack_rows(self, t, pack=None, pruned=False):
+        """Tile-ordered activation [B*64, ...] of the last packed forward -> the session-indexed [B*T, ...] layout of the unpacked
+        kernels, zeros at the padding positions (tests and diagnostics; a host synchronisation)."""
+        pk = pack if pack is not None else self._act["pack"]
+        if pruned:
+            return t
+        B, T = pk["B"], self.T
+        nt = int(pk["hdr"][0].item())
+        tr = pk["trows"][:nt].long()
+        r = torch.arange(64, device=self.device)
+        ok = (r[None, :] < tr[:, None]).reshape(-1)
+        rows = torch.nonzero(ok).reshape(-1)
+        lp = pk["lpos"][:nt * 64][ok].long()
+        out = torch.zeros((B * T,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        out[lp] = t[rows]
+        return out
+
+    def _forward_packed(self, seq, training, rate, step, save):
+        """forward() on packed tiles (ader_seq_pack_plan + ader_seqp_fwd): the saved-activation dict has the keys of the unpacked
+        path, the tensors of the K / V side and of unpruned blocks in tile order ([B*64, ..], see include/ader_hip.h)."""
+        B, T, H, L = seq.shape[0], self.T, self.H, self.L
+        tag = "pt" if save else "pe"
+        pk = self._pack_plan(seq, tag)
+        rows = pk["rows"]
+        A = {"B": B, "seq": seq, "rate": rate, "training": training, "step": step, "pack": pk}
+        per_row = T * H
+        pp = self._pp
+        d = _lib.AderSeqFwd()
+        d0 = self._drop(step, SITE_EMB, rate, training, per_row)
+        A["d_emb"] = d0
+        x = self.buf(tag + "x0", (rows, H), zero=True)
+        rep = self.buf(tag + "rep", (B, H))
+        meanf, stdf = self.buf(tag + "mf", (B,)), self.buf(tag + "sf", (B,))
+        d.seq, d.emb, d.pos, d.x0, d.status = ptr(seq), pp["emb"], pp["pos"], ptr(x), ptr(self.status)
+        d.lnf_g, d.lnf_b, d.rep, d.meanf, d.stdf = pp["lnf_g"], pp["lnf_b"], ptr(rep), ptr(meanf), ptr(stdf)
+        d.B, d.T, d.H, d.V, d.L = B, T, H, self.V, L
+        d.sqrtH = float(np.sqrt(np.float32(H)))
+        d.sqrt_dh = float(np.sqrt(np.float32(H // self.heads)))
+        d.d_emb = d0.c
+        for l in range(L):
+            p = "b%d." % l
+            n = lambda s: "%s%d%s" % (tag, l, s)   # noqa: E731
+            pruned = self.prune_last and l == L - 1
+            da = self._drop(step, site_attn(l), rate, training, self.heads * T * T)
+            d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
+            d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
+            M, sfx = (B, "L") if pruned else (rows, "")
+            kmask = self.buf(n("km"), (rows,), zero=True)
+            K, Vv = self.buf(n("K"), (rows, H), zero=True), self.buf(n("V"), (rows, H), zero=True)
+            q_in = self.buf(n("qin" + sfx), (M, H), zero=True)
+            mean1, std1, qmask = self.buf(n("m1" + sfx), (M,), zero=True), self.buf(n("s1" + sfx), (M,), zero=True), self.buf(n("qm" + sfx), (M,), zero=True)
+            Q, x1, y = self.buf(n("Q" + sfx), (M, H), zero=True), self.buf(n("x1" + sfx), (M, H), zero=True), self.buf(n("y" + sfx), (M, H), zero=True)
+            Pm = self.buf(n("P" + sfx), (B * T if pruned else rows * 64,), zero=True)
+            mean2, std2 = self.buf(n("m2" + sfx), (M,), zero=True), self.buf(n("s2" + sfx), (M,), zero=True)
+            h1d, x2 = self.buf(n("h1" + sfx), (M, H), zero=True), self.buf(n("x2" + sfx), (M, H), zero=True)
+            k = d.blk[l]
+            for i, w in enumerate(("wq", "wk", "wv", "w1", "w2")):
+                k.w[i] = self.wbf.data_ptr() + self._widx[p + w] * self._wplane
+            for i, bn in enumerate(("bq", "bk", "bv", "b1", "b2")):
+                k.bias[i] = pp[p + bn]
+            k.ln1_g, k.ln1_b, k.ln2_g, k.ln2_b = pp[p + "ln1_g"], pp[p + "ln1_b"], pp[p + "ln2_g"], pp[p + "ln2_b"]
+            k.q_in, k.mean1, k.std1, k.kmask, k.qmask = ptr(q_in), ptr(mean1), ptr(std1), ptr(kmask), ptr(qmask)
+            k.Q, k.K, k.V, k.P, k.x1, k.y = ptr(Q), ptr(K), ptr(Vv), ptr(Pm), ptr(x1), ptr(y)
+            k.mean2, k.std2, k.h1d, k.x2 = ptr(mean2), ptr(std2), ptr(h1d), ptr(x2)
+            k.d_attn, k.d_ffn1, k.d_ffn2 = da.c, d1.c, d2.c
+            k.pruned = 1 if pruned else 0
+            A[l] = dict(pruned=pruned, x=x, q_in=q_in, mean1=mean1, std1=std1, kmask=kmask, qmask=qmask, Q=Q, K=K, V=Vv, P=Pm,
+                        x1=x1, y=y, mean2=mean2, std2=std2, h1d=h1d, da=da, d1=d1, d2=d2)
+            x = x2
+        call("ader_seqp_fwd", ctypes.byref(d), pk["ref"], pk["max_tiles"], self._stream())
+        A.update(xL=x, rep=rep, meanf=meanf, stdf=stdf)
+        if save:
+            self._act = A
+        return rep
+
     # ---------------------------------------------------------------------------------------- loss rows
     def _rowinfo(self, B, pos, n_train, ex_pos, ex_trow, N, Np, w_train, w_ex, teacher, tag="ri_"):
         Bp = (B + 63) // 64 * 64
@@ -729,7 +873,7 @@ class Engine:
             # used on its own): its loss sum is still owed -- settle it before the row losses are overwritten
             call("ader_lbf_sum", ptr(self._pending_loss[0]), self._pending_loss[1], ptr(self.loss), self._stream())
             self._pending_loss = None
-        seq = self._dev_i32(seq)
+        seq = self._seq_in(seq)
         pos = self._dev_i32(pos)
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
         cap = self.MAX_ROWS_FAST if self.lfast else self.MAX_ROWS
@@ -937,8 +1081,15 @@ class Engine:
         wslab = self.buf("w_slab", (max(call("ader_gemm_atb_slabs", rows) * 160 * 160, call("ader_ln_bwd_slabs", rows) * 2 * H),))
         pp, gp = self._pp, self._gp
         xL = A["xL"]
-        dx = self.buf("dx_a", (rows, H), zero=True)
-        dxn = self.buf("dx_b", (rows, H), zero=True)
+        pk = A.get("pack")
+        if pk is not None:
+            # packed tiles: block-to-block gradients in tile order; the rows of the input embeddings leave by position (dx_emb)
+            dx = self.buf("pdx_a", (pk["rows"], H), zero=True)
+            dxn = self.buf("pdx_b", (pk["rows"], H), zero=True)
+            dx_emb = self.buf("dx_emb", (rows, H), zero=True)
+        else:
+            dx = self.buf("dx_a", (rows, H), zero=True)
+            dxn = self.buf("dx_b", (rows, H), zero=True)
         self._late_on = bool(defer and (self.dp_world == 1 or self._late_force) and self.seq_fused and self.late_side_stream)
         if self.prune_last:
             dxl = self.buf("dx_L", (B, H))        # gradient of the final block's output row T-1 (compact)
@@ -966,6 +1117,12 @@ class Engine:
                 M, rmap, dxo = B, last_map, dxl
             else:
                 M, rmap, dxo = rows, (1, 0), dx
+            if pk is not None:
+                emb_bwd = l == 0
+                self._bwd_block_packed(l, S, pk, dxo, dx_emb if emb_bwd else dxn, B, emb_bwd, A["d_emb"])
+                fused_emb = fused_emb or emb_bwd
+                dx, dxn = (dx_emb, dx) if emb_bwd else (dxn, dx)
+                continue
             if self.seq_fused:
                 emb_bwd = l == 0        # (block 0's chain applies the prologue mask / dropout to the rows it writes)
                 self._bwd_block_fused(l, S, seq, dxo, dxn, M, B, emb_bwd, A["d_emb"])
@@ -1016,7 +1173,16 @@ class Engine:
         if not self._late_on:
             self._atb_flush()
         self._last_g = dx       # per-position gradient rows of the input embeddings (tests: column-sum checks)
-        if defer:
+        if pk is not None:
+            # (the packed chain wrote the REAL positions of dx only: the positional gradient sums those; every other consumer
+            #  addresses dx through the id lists, which leave the padding out)
+            self._late_call("ader_pos_grad_packed", ptr(dx), ptr(pk["slen"]), gp["pos"], B, T, H)
+            if not defer and self._early is None:
+                lab0 = self.buf("dp_lab0", (1,), torch.int32, zero=True)
+                ids_s, order, sp_start, _, _, _, _ = self._sparse_lists(seq, lab0, self.item_num)
+                call("ader_scatter_rows_ordered", ptr(ids_s), ptr(order), ptr(sp_start), sp_start.numel() - 1, ptr(dx), H, self.V,
+                     float(np.sqrt(np.float32(H))), ptr(demb), st)
+        elif defer:
             # (block 0's ader_seq_bwd_qkv has already applied the prologue mask / dropout to the rows: seq = NULL)
             if fused_emb:
                 self._late_call("ader_embed_bwd_rows", None, ptr(dx), gp["pos"], B, T, H, self.V, *A["d_emb"].args())
@@ -1083,6 +1249,53 @@ class Engine:
         self._atb(S["q_in"], dQ, p + "wq", p + "bq", wslab, M)
         self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows)
         self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows)
+
+    def _bwd_block_packed(self, l, S, pk, dxo, dxn, B, emb_bwd, d_emb):
+        """_bwd_block_fused on packed tiles (seqp_bwd.hip): dxo = gradient of the block output (tile order, or compact [B,H] for the
+        pruned last block); dxn receives the gradient of the block input (tile order; block 0: the session-indexed [B*T,H] rows)."""
+        T, H = self.T, self.H
+        rows, mt = pk["rows"], pk["max_tiles"]
+        st = self._stream()
+        p = "b%d." % l
+        pp, gp = self._pp, self._gp
+        pruned = 1 if S["pruned"] else 0
+        M = B if pruned else rows
+        mpk = None if pruned else pk           # the compact tensors of a pruned block are plain [B, H]
+        wp = lambda w: self.wbf.data_ptr() + self._widx[p + w] * self._wplane     # noqa: E731
+        sfx = "L" if pruned else ""
+        dh2, da_ = self.buf("pbw_dh2%d%s" % (l, sfx), (M, H), zero=True), self.buf("pbw_da%d%s" % (l, sfx), (M, H), zero=True)
+        dx1, dQ = self.buf("pbw_dx1%d%s" % (l, sfx), (M, H), zero=True), self.buf("pbw_dQ%d%s" % (l, sfx), (M, H), zero=True)
+        dK, dV = self.buf("pbw_dK%d" % l, (rows, H), zero=True), self.buf("pbw_dV%d" % l, (rows, H), zero=True)
+        slab2, slab1 = self.buf("pln_slab%d_2" % l, (mt * 2 * H,)), self.buf("pln_slab%d_1" % l, (mt * 2 * H,))
+        f = _lib.AderSeqBwdFfn()
+        f.seq, f.dx2, f.h1d, f.x1, f.mean2, f.std2 = None, ptr(dxo), ptr(S["h1d"]), ptr(S["x1"]), ptr(S["mean2"]), ptr(S["std2"])
+        f.ln2_g, f.w2, f.w1 = pp[p + "ln2_g"], wp("w2"), wp("w1")
+        f.dh2, f.da, f.dx1, f.slab = ptr(dh2), ptr(da_), ptr(dx1), ptr(slab2)
+        f.d_ffn1, f.d_ffn2 = S["d1"].c, S["d2"].c
+        f.B, f.T, f.H, f.pruned = B, T, H, pruned
+        call("ader_seqp_bwd_ffn", ctypes.byref(f), pk["ref"], mt, st)
+        self._late_call("ader_reduce_slabs", ptr(slab2), 2 * H, mt, H, 1, H, gp[p + "ln2_g"], gp[p + "ln2_b"])
+        wslab = self._ws["w_slab"]
+        self._atb(S["h1d"], dh2, p + "w2", p + "b2", wslab, M, mpk)
+        self._atb(S["y"], da_, p + "w1", p + "b1", wslab, M, mpk)
+        if pruned:
+            call("ader_attnp_last_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
+                 ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, *S["da"].args(), pk["ref"], st)
+        else:
+            call("ader_attnp_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]),
+                 ptr(dQ), ptr(dK), ptr(dV), B, T, H, *S["da"].args(), pk["ref"], mt, st)
+        q = _lib.AderSeqBwdQkv()
+        q.seq, q.dQ, q.dx1, q.dK, q.dV, q.x = None, ptr(dQ), ptr(dx1), ptr(dK), ptr(dV), ptr(S["x"])
+        q.mean1, q.std1, q.ln1_g = ptr(S["mean1"]), ptr(S["std1"]), pp[p + "ln1_g"]
+        q.wq, q.wk, q.wv = wp("wq"), wp("wk"), wp("wv")
+        q.dx, q.slab = ptr(dxn), ptr(slab1)
+        q.d_emb = d_emb.c
+        q.B, q.T, q.H, q.pruned, q.emb_bwd = B, T, H, pruned, 1 if emb_bwd else 0
+        call("ader_seqp_bwd_qkv", ctypes.byref(q), pk["ref"], mt, st)
+        self._late_call("ader_reduce_slabs", ptr(slab1), 2 * H, mt, H, 1, H, gp[p + "ln1_g"], gp[p + "ln1_b"])
+        self._atb(S["q_in"], dQ, p + "wq", p + "bq", wslab, M, mpk)
+        self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows, pk)
+        self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows, pk)
 
     def _lr_t(self, lr):
         return float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
@@ -1342,7 +1555,7 @@ class Engine:
         import torch.distributed as dist
         self._refresh_stream()
         W, r, grp = self.dp_world, self.dp_rank, self.dp_group
-        seq, pos = self._dev_i32(seq), self._dev_i32(pos)
+        seq, pos = self._seq_in(seq), self._dev_i32(pos)
         B_all, T, H, S = seq.shape[0], self.T, self.H, self.shard_items
         B = pos.shape[0]                                                   # train rows (the exemplar rows follow them in seq)
         n_ex = B_all - B
@@ -1639,7 +1852,7 @@ class Engine:
         """Eval-mode representation (is_training=False): rep [n,H] for any n (chunks of MAX_ROWS)."""
         self._refresh_stream()
         self.sync_table()
-        seq = self._dev_i32(seq)
+        seq = self._seq_in(seq)
         n = seq.shape[0]
         out = torch.empty((n, self.H), dtype=torch.float32, device=self.device)
         for s in range(0, n, self.MAX_ROWS):
@@ -1680,7 +1893,7 @@ class Engine:
         """0-based rank of pos[b] among items 1..N for every row (Evaluator path, util.py:323-325) -> int32 numpy [n]."""
         self._refresh_stream()
         self.sync_table()
-        seq = self._dev_i32(seq)
+        seq = self._seq_in(seq)
         pos = self._dev_i32(pos)
         n, N = seq.shape[0], int(max_item)
         out = torch.empty(n, dtype=torch.int32, device=self.device)
@@ -1719,7 +1932,7 @@ class Engine:
         self.sync_table()
         if self.ewc is None:
             self.ewc_snapshot()
-        seq, pos = self._dev_i32(seq), self._dev_i32(pos)
+        seq, pos = self._seq_in(seq), self._dev_i32(pos)
         n = seq.shape[0]
         F = self.ewc["F"]
         F.zero_()
@@ -1742,7 +1955,7 @@ class Engine:
         device tensor.  Exact-f32 logit kernels, chunks of MAX_ROWS rows."""
         self._refresh_stream()
         self.sync_table()
-        seq, pos = self._dev_i32(seq), self._dev_i32(pos)
+        seq, pos = self._seq_in(seq), self._dev_i32(pos)
         n, N = seq.shape[0], int(max_item)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         st = self._stream()

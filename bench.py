@@ -132,6 +132,10 @@ def main():
                          "(SURVEY 8a): cfgD = DIGINETICA ADER last period (N 43,105, 256 train + 143 distilled rows), cfgY = YOOCHOOSE "
                          "ADER last period (N 25,750, 512 + 102 rows), cfgF = DIGINETICA finetune baseline (BASELINE configs[0]: N 43,105, "
                          "batch 128, no exemplars, dropout 0); synthetic ids of those shapes")
+    ap.add_argument("--pack", choices=["auto", "on", "off"], default="auto",
+                    help="packed session tiles (csrc/seqp_*.hip: the session kernels on the real positions only).  auto: the engine's "
+                         "rule on the density of the synthetic batches (packed in the realistic regime, not in the dense one)")
+    ap.add_argument("--pack-window", default=None, help="w1_min,w1_max,target of the packing plan (tuning; default: the engine's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32grade", "--no-companion", dest="no_companion", action="store_true",
                     help="skip the companion run of the other logits type (bf16 beside the x3 headline)")
@@ -204,6 +208,11 @@ def main():
         if world > 1 and (logits == "x3" or (logits == "bf16" and not E)):     # (distilled rows on the sharded table: float32 grade)
             eng_.dp_mode = args.dp_mode
         dp_.set_rows(rank * B, N)
+        # the feeder's announcement: fraction of real positions of the batches (what Sampler.to_device tells the engine in main.py)
+        eng_.pack_density = float(np.mean([float((sq != 0).float().mean()) for sq, _ in batches]))
+        eng_.pack_sessions = {"auto": "auto", "on": True, "off": False}[args.pack]
+        if args.pack_window:
+            eng_.pack_window = tuple(int(v) for v in args.pack_window.split(","))
         return eng_
 
     # packed catalog exchange (the default from 8 ranks on): its all-to-all split sizes come from the ids of the GLOBAL batch, which
@@ -522,6 +531,7 @@ def main():
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam", "exchange": exchange, "precision": prec[args.logits],
                        "parallelism": "dp%d" % world, "final_loss": loss,
+                       "session_tiles": ("packed" if eng._act.get("pack") is not None else "one session per workgroup"),
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1)},
             "sustained": sustained,
             "comm": comm,

@@ -116,6 +116,31 @@ typedef struct {
 } AderSeqFwd;
 int ader_seq_fwd(const AderSeqFwd* desc, void* stream);
 
+/* ---- the same stack on PACKED session tiles (seqp_plan.hip, seqp_fwd.hip, seqp_bwd.hip) ---------------------------------
+ * The reference pads every session to maxlen (util.py:161-169) and computes the padding too; a padded position influences no real
+ * one (key masked modules.py:188-193, output re-zeroed ADER.py:80, zero gradient), so these kernels drop it: ader_seq_pack_plan
+ * lays the REAL positions of a batch out in 64-row tiles (several short sessions per tile, a session never split, batch order kept
+ * inside a tile) and ader_seqp_fwd / ader_seqp_bwd_* run the unchanged arithmetic of ader_seq_fwd / ader_seq_bwd_* per tile,
+ * attention block-diagonal over the sessions of a tile.  Activation tensors of these kernels are in TILE order ([tile*64 + row, ..],
+ * probabilities [tile][key][query]); rep / meanf / stdf [B,..], the compact tensors of a pruned block [B,..] and the gradient rows of
+ * the input embeddings [B*T,H] (only real positions written) stay session-indexed.
+ * Plan arrays (device, written by ader_seq_pack_plan): hdr [4] = {tiles, 64*tiles, real positions, window}; tile_rows [<= B]; per
+ * packed row (<= 64 B entries): ids (item id), lpos (b*T + t), gpos (GLOBAL position (b + row offset)*T + t: the dropout counters
+ * of a data-parallel rank, see AderDrop), info = first tile row of the row's session | last-position flag << 6 | t << 8 | b << 16;
+ * per session: srow0 (first packed row), slen (real positions, >= 1: an all-padding session keeps position T-1).
+ * row0 / split_rows / row0_ex: global row of local session 0, first local exemplar session (-1: none) and its global row.
+ * w1_min / w1_max / target: stream window of the short (<= 16 positions) class, at most 49 -- shrunk towards w1_min so that the
+ * batch fills about `target` tiles (0: always w1_max). */
+typedef struct {
+    int *hdr, *tile_rows, *ids, *lpos;
+    unsigned* gpos;
+    int *info, *srow0, *slen;
+} AderSeqPack;
+int ader_seq_pack_plan(const int* seq, int B, int T, int row0, int split_rows, int row0_ex, int w1_min, int w1_max, int target,
+                       const AderSeqPack* out, void* stream);
+/* max_tiles: host-side upper bound of the tile count = grid size (<= 0 or > B: B); workgroups beyond hdr[0] exit at once */
+int ader_seqp_fwd(const AderSeqFwd* desc, const AderSeqPack* pack, int max_tiles, void* stream);
+
 /* ---- session-tiled backward chains of one block (seq_bwd.hip) --------------------------------------------------------
  * The row-local kernels on either side of the attention backward, one launch of B workgroups each (tf.gradients of
  * ADER.py:62-81).  Tensors and layouts as written by the per-op kernels they replace; pruned != 0: the block kept only
@@ -140,6 +165,26 @@ typedef struct {      /* replaces ader_gemm_x3<ADD,trans> x3, ader_ln_bwd, ader_
 } AderSeqBwdQkv;
 int ader_seq_bwd_ffn(const AderSeqBwdFfn* desc, void* stream);
 int ader_seq_bwd_qkv(const AderSeqBwdQkv* desc, void* stream);
+/* ---- packed session tiles, backward (seqp_bwd.hip) */
+/* backward chains of one block on the tiles (descriptors of ader_seq_bwd_ffn / _qkv below; `seq` unused -- the ids come from the
+ * plan; slab: [max_tiles][2][H] per-TILE partial sums; emb_bwd: dx is the session-indexed [B*T,H] tensor, real positions only) */
+int ader_seqp_bwd_ffn(const AderSeqBwdFfn* desc, const AderSeqPack* pack, int max_tiles, void* stream);
+int ader_seqp_bwd_qkv(const AderSeqBwdQkv* desc, const AderSeqPack* pack, int max_tiles, void* stream);
+/* attention backward on a tile (ader_attn_x3_bwd; heads == 1; PT [tile][key][query] as ader_seqp_fwd stored it) and of a pruned
+ * block (ader_attn_last_bwd: Q_last / dO_last / dQ_last / P_last / qmask_last compact [B,..], K / V / dK / dV / kmask tile order) */
+int ader_attnp_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* PT, const float* kmask,
+                   const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, const AderDrop* drop,
+                   const AderSeqPack* pack, int max_tiles, void* stream);
+int ader_attnp_last_bwd(const float* dO_last, const float* Q_last, const float* K, const float* V, const float* P_last,
+                        const float* kmask, const float* qmask_last, float* dQ_last, float* dK, float* dV, int B, int T, int H,
+                        const AderDrop* drop, const AderSeqPack* pack, void* stream);
+/* dpos [T,H] = sum over the sessions that have position t of dx[b*T + t] (gradient of the positional table, modules.py:118-130
+ * differentiated) from session-indexed rows whose padding rows were never written */
+int ader_pos_grad_packed(const float* dx, const int* slen, float* dpos, int B, int T, int H, void* stream);
+/* ader_gemm_atb_x3_batch with operands in tile order: Mplan (host, or NULL = M) shares the workgroups out by the rows expected to
+ * exist, Mdev[i] (device: 64 x tiles) bounds M[i], trows[i] (device: rows per tile) masks the unwritten rows; NULL entries: plain */
+int ader_gemm_atb_x3_batch_pk(const float* const* A, const float* const* G, float* const* dW, float* const* db, const int* M,
+                              const int* Mplan, const int* const* Mdev, const int* const* trows, int n, float* slab, int H, void* stream);
 /* g = dx2*(seq!=0); dh2 = g*keep*scale : backward entry of modules.py:262-266 + ADER.py:80 */
 int ader_mask_dropgrad(const float* dx2, const int* seq, float* g, float* dh2, int rows, int H, int row_mul, int row_add,
                        const AderDrop* drop, void* stream);
