@@ -726,8 +726,18 @@ __global__ __launch_bounds__(256) void k_pos_grad_pk(const float* __restrict__ g
         const int t = i / H;
         const int per = (B + 7) / 8;
         const int b0 = sl * per, b1 = min(B, b0 + per);
-#pragma unroll 4
-        for (int b = b0; b < b1; ++b) acc += (t >= T - slen[b]) ? g[(size_t)b * TH + i] : 0.0f;
+        // (unconditional loads -- the rows exist, stale or not -- and a select: a load under the branch is waited for inside it,
+        //  one memory round trip per session)
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            float v[4];
+            int ln[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[u] = g[(size_t)(b + u) * TH + i]; ln[u] = slen[b + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (t >= T - ln[u]) ? v[u] : 0.0f;
+        }
+        for (; b < b1; ++b) { const float v = g[(size_t)b * TH + i]; acc += (t >= T - slen[b]) ? v : 0.0f; }
     }
     red[sl][o] = acc;
     __syncthreads();

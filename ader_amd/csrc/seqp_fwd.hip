@@ -17,6 +17,24 @@
 // heads == 1, T <= 64, H even and <= 150.  gfx950 only.
 #include "seqp_common.h"
 
+#ifdef SFP_STAMP     // diagnostic build only (tools/build_variant.sh ... -DSFP_STAMP): clocks per phase of waves 0 and 4 of each workgroup
+__device__ unsigned long long sfp_dbg[2 * 40 * 1024];
+#define SFS_INIT unsigned long long seg[40], tprev; for (int i_ = 0; i_ < 40; ++i_) seg[i_] = 0; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#define SFS(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0); seg[k_] += t_ - tprev; tprev = t_; }
+#define SFB(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0); if (l == 0) seg[1 + k_] += t_ - tprev; else seg[17 + k_] += t_ - tprev; tprev = t_; }
+#define SFS_DUMP { if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 1024) for (int k_ = 0; k_ < 40; ++k_) \
+                       sfp_dbg[(blockIdx.x * 2 + (wave == 4)) * 40 + k_] = seg[k_]; }
+extern "C" int ader_dbg_read_sfp(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sfp_dbg), (size_t)n * 8); }
+#else
+#define SFS_INIT
+#define SFS(k_)
+#define SFB(k_)
+#define SFS_DUMP {}
+#endif
+
 __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R0 = (bf16*)smem_raw;
@@ -40,6 +58,7 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
     const int T = a.T, H = a.H;
     const uint32_t H4 = (uint32_t)H * 4u;
     bf16x8 bh[10], bl[10];
+    SFS_INIT
     typedef const AderSeqBlock __attribute__((address_space(4))) * BlkPtr;
     const BlkPtr blks = (BlkPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
                                  offsetof(AderSeqFwd, blk));
@@ -104,6 +123,7 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
         load_bfrags((const bf16*)blks[0].w[0], nb, r, hh, bh, bl);       // Wq of block 0 (in flight across the barrier)
     }
     lds_barrier();
+    SFS(0)
     const bool skipw = mh == 1 && nrows <= 32;        // this wave's 32 rows hold no position
     const int npass = nrows > 40 ? 2 : 1;             // row-layout phases: rows 40 pass + 4 wave + rsub
 
@@ -177,12 +197,15 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
             }
             if (npass == 1 && tid < TR - 40) { km_l[40 + tid] = 0.0f; qm_l[40 + tid] = 0.0f; }
         }
+        SFB(0)
         lds_barrier();
+        SFB(1)
         // ---- Q = LN(x).Wq + bq (modules.py:172) -> memory, hi/lo -> R1 (in place)
         {
             PHASE_IDS;
             f32x16 acc = tile_mma(R1, mh, r, hh, bh, bl, skipw);
             load_bfrags((const bf16*)k.w[1], nb, r, hh, bh, bl);
+            SFB(2)
             const Out o = make_rows(k.Q, mrow0, mrows, H);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t n4 = (n < H) ? (uint32_t)n * 4u : OOBH;
@@ -197,11 +220,13 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
                 }
             }
         }
+        SFB(3)
         // ---- K = x.Wk + bk (modules.py:173) -> memory, hi/lo -> R2 (the fp32 tile is dead)
         {
             PHASE_IDS;
             f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
             load_bfrags((const bf16*)k.w[2], nb, r, hh, bh, bl);
+            SFB(4)
             const Out o = make_rows(k.K, prow0, nrows, H);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
@@ -215,10 +240,12 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
                 }
             }
         }
+        SFB(5)
         // ---- V = x.Wv + bv (modules.py:174) -> memory, hi/lo -> R0 (in place)
         {
             PHASE_IDS;
             f32x16 acc = tile_mma(R0, mh, r, hh, bh, bl, skipw);
+            SFB(6)
             const Out o = make_rows(k.V, prow0, nrows, H);
             const int t0 = 32 * mh + 4 * hh;
             const uint32_t boff0 = (n < H) ? (uint32_t)(t0 * H + n) * 4u : OOB;
@@ -233,7 +260,9 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
                 }
             }
         }
+        SFB(7)
         __syncthreads();        // full barrier: LN(x) rows written to memory by other waves are re-read after the attention
+        SFB(8)
         // ---- attention (modules.py:177-223), block-diagonal over the sessions of the tile.  Wave (mq, kb) of the first four owns
         //      the 32x32 block S^T[keys 32kb..][queries 32mq..]; block (0, 1) is above the diagonal: nothing to do.
         float qres[16], g2[10], be2[10];
@@ -246,6 +275,7 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
 #pragma unroll
             for (int j = 0; j < 16; ++j) qres[j] = bload(oq, row_base(pruned, t0 + ROWJ(j), H4, info_l) + n4);    // residual rows, added after P.V
         }
+        SFB(9)
         bf16* Ph = R1;                                   // [64 queries][LDP] hi, then lo: overlays the Q tile once S is done
         bf16* Pl = R1 + TR * LDP;
         {
@@ -331,10 +361,12 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
                 }
             }
         }
+        SFB(10)
         lds_barrier();
         {
             PHASE_IDS;
             f32x16 O;
+            SFB(11)
 #pragma unroll
             for (int j = 0; j < 16; ++j) O[j] = 0.0f;
             const int q4 = (lane_p & 15) >> 2, p4 = lane_p & 3, g1_ = (lane_p >> 4) & 1;
@@ -368,6 +400,7 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
                 }
             }
         }
+        SFB(12)
         lds_barrier();
         // ---- LN2 (ADER.py:75): y -> memory, Xf (fp32, the FFN residual) and hi/lo -> R0
         {
@@ -412,6 +445,7 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
                 }
             }
         }
+        SFB(13)
         lds_barrier();
         // ---- h1 = dropout(relu(y.W1 + b1)) (modules.py:254-257) -> memory, hi/lo -> R1
         {
@@ -436,6 +470,7 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
             } else if (thr) { F1_EPI(true) } else { F1_EPI(false) }
 #undef F1_EPI
         }
+        SFB(14)
         lds_barrier();
         // ---- x2 = (dropout(h1.W2 + b2) + y) * (id != 0) (modules.py:258-266, ADER.py:80)
         {
@@ -462,9 +497,11 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
             } else if (thr) { F2_EPI(true) } else { F2_EPI(false) }
 #undef F2_EPI
         }
+        SFB(15)
         lds_barrier();
 #undef k
     }
+    SFS(33)
     // ---- final LayerNorm of every session's last position (ADER.py:83-85) -> rep[b]
     {
         float gf[3], bf_[3];
@@ -485,6 +522,8 @@ __global__ __launch_bounds__(640) void k_seqp_fwd(AderSeqFwd a, AderSeqPack pk) 
             if (lane == 0) { a.meanf[b] = mean; a.stdf[b] = sd; }
         }
     }
+    SFS(34)
+    SFS_DUMP
 }
 
 static const size_t kSeqpFwdLds = (size_t)3 * RSZ * sizeof(bf16) + (size_t)11 * TR * sizeof(float);

@@ -11,7 +11,7 @@
 // Packing rule (no sequential dependency between sessions, so it is two scans): sessions fall into three classes by length --
 // short (<= 16), medium (<= 32), long; inside a class the sessions' rows form one stream in batch order and a session goes to the
 // tile floor(start / w) of the stream offset it starts at; because a session is shorter than 64 - w + 1 the rows that land in a
-// tile never exceed 64 (w <= 49 for short, 33 for medium; long sessions get a tile each).  w of the short class shrinks when the
+// tile never exceed 64 (16 <= w <= 49 for short, 33 for medium; long sessions get a tile each).  w of the short class shrinks when the
 // batch would otherwise fill fewer tiles than the chip has CUs (`target`): the session kernels are latency-bound per tile, a
 // half-filled tile is faster than a full one, and an idle CU is worth nothing.
 //
@@ -25,6 +25,17 @@
 
 #define PLAN_MAXB 4096
 #define PLAN_THREADS 1024
+
+#ifdef PLAN_STAMP     // diagnostic build only (tools/build_variant.sh ... -DPLAN_STAMP): clocks per phase of thread 0
+__device__ unsigned long long plan_dbg[16];
+#define PST_INIT unsigned long long tprev_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_) :: "memory");
+#define PST(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                  if (threadIdx.x == 0) plan_dbg[k_] = t_ - tprev_; tprev_ = t_; }
+extern "C" int ader_dbg_read_plan(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(plan_dbg), (size_t)n * 8); }
+#else
+#define PST_INIT
+#define PST(k_)
+#endif
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -53,6 +64,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total) {
     return base + inc - v;
 }
 
+// NV > 0: the batch's ids stay in registers between the two element passes (n <= NV * 1024): one memory round trip per launch.
+template <int NV>
 __global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __restrict__ seq, int B, int T, int row0, int split_rows,
                                                                 int row0_ex, int w1_min, int w1_max, int target, AderSeqPack o) {
     __shared__ unsigned char len_l[PLAN_MAXB];
@@ -61,15 +74,45 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __res
     __shared__ int off_l[PLAN_MAXB];
     __shared__ int tmp[16];
     __shared__ int tot_l;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- lengths: one wave-load per session
-    for (int s = wave; s < B; s += PLAN_THREADS / 64) {
-        const int id = (lane < T) ? seq[(size_t)s * T + lane] : 0;
-        const unsigned long long nz = __ballot(id != 0);
-        const int tv0 = nz ? (int)__ffsll((long long)nz) - 1 : T - 1;
-        if (lane == 0) len_l[s] = (unsigned char)(T - tv0);
-    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = B * T;
+    PST_INIT
+    // ---- lengths.  Element-parallel: every thread reads ids tid, tid + 1024, ... (coalesced, eight loads in flight) and the
+    //      first item of a session is an LDS atomicMin over its positions.  (One wave-load per session, the first form of this
+    //      kernel, paid a memory round trip per session and wave: 25-32 us for 400-600 sessions.)
+    int* fz_l = off_l;                                   // first real position of the session (T-1 for an all-padding one)
+    for (int i = tid; i < B; i += PLAN_THREADS) fz_l[i] = T - 1;
     if (tid == 0) tot_l = 0;
+    __syncthreads();
+    const int ds = PLAN_THREADS / T, dt = PLAN_THREADS - ds * T;         // (s, t) of index i + 1024 from (s, t) of i
+    int vr[NV > 0 ? NV : 1];
+    if (NV > 0) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) { const int i = tid + u * PLAN_THREADS; vr[u] = (i < n) ? seq[i] : 0; }
+        int sI = tid / T, tI = tid - sI * T;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (vr[u] != 0) atomicMin(&fz_l[sI], tI);
+            sI += ds; tI += dt;
+            if (tI >= T) { tI -= T; ++sI; }
+        }
+    } else {
+        int sI = tid / T, tI = tid - sI * T;
+        for (int i0 = tid; i0 < n; i0 += 8 * PLAN_THREADS) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * PLAN_THREADS; v[u] = (i < n) ? seq[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (v[u] != 0) atomicMin(&fz_l[sI], tI);
+                sI += ds; tI += dt;
+                if (tI >= T) { tI -= T; ++sI; }
+            }
+        }
+    }
+    __syncthreads();
+    PST(0)
+    for (int i = tid; i < B; i += PLAN_THREADS) len_l[i] = (unsigned char)(T - fz_l[i]);
     for (int i = tid; i < PLAN_MAXB; i += PLAN_THREADS) { first_l[i] = 0x7fffffff; end_l[i] = 0; }
     __syncthreads();
     // ---- stream offsets per class (thread t owns sessions [t spt, (t+1) spt))
@@ -80,18 +123,20 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __res
         const int ln = len_l[s];
         if (ln <= 16) a1 += ln; else if (ln <= 32) a2 += ln; else a3 += 1;
     }
+    PST(1)
     int P1, P2, C3;
     int e1 = block_excl_scan(a1, tmp, &P1);
     int e2 = block_excl_scan(a2, tmp, &P2);
     int e3 = block_excl_scan(a3, tmp, &C3);
     int w1 = w1_max;
     if (target > 0) w1 = max(w1_min, min(w1_max, (P1 + target - 1) / target));
-    w1 = max(1, min(49, w1));
+    w1 = max(16, min(49, w1));          // (>= 16: every window then holds a session start, so the raw tile count never exceeds B)
+    PST(2)
     const int w2 = 33;
     const int n1 = P1 > 0 ? (P1 - 1) / w1 + 1 : 0;       // upper bound of the short tiles (tiles beyond the last start stay empty: none, see below)
     const int n2 = P2 > 0 ? (P2 - 1) / w2 + 1 : 0;
-    // (every window [k w, (k+1) w) below the stream's end holds at least one session start, because a session is shorter than w or, when it is
-    //  not (w1 < 16), the tile index is compacted below by counting the windows that do hold a start)
+    // (every window [k w, (k+1) w) below the stream's last start holds at least one session start, because no session is longer than w;
+    //  the window that holds the stream's end may hold none: the tile numbering is compacted below)
     for (int s = s0; s < s1; ++s) {
         const int ln = len_l[s];
         int tile, st;
@@ -103,7 +148,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __res
         atomicMax(&end_l[tile], st + ln);
     }
     __syncthreads();
-    // ---- compact the tile numbering (a window without a session start is no tile: possible only for w1 < 16)
+    PST(3)
+    // ---- compact the tile numbering (a window without a session start is no tile)
     const int nt_raw = n1 + n2 + C3;
     int cnt = 0;
     const int tpt = (nt_raw + PLAN_THREADS - 1) / PLAN_THREADS;
@@ -121,26 +167,58 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __res
         } else end_l[t] = -1;
     }
     __syncthreads();
+    PST(4)
+    // ---- per session: first packed row (kept in off_l for the row pass below)
     int tot = 0;
-    // ---- per session / per row outputs: one wave per session, lane k = its k-th real position
-    for (int s = wave; s < B; s += PLAN_THREADS / 64) {
-        const int ln = len_l[s], raw = tile_l[s];
-        const int tile = end_l[raw];
-        const int r0 = off_l[s] - first_l[raw];               // first row of the session inside its tile
-        const int p0 = tile * 64 + r0;
-        if (lane == 0) { o.srow0[s] = p0; o.slen[s] = ln; }
-        if (lane < ln) {
-            const int t = T - ln + lane;
-            o.ids[p0 + lane] = seq[(size_t)s * T + t];
-            const int gb = (split_rows >= 0 && s >= split_rows) ? s - split_rows + row0_ex : s + row0;
-            o.lpos[p0 + lane] = s * T + t;
-            o.gpos[p0 + lane] = (unsigned)gb * (unsigned)T + (unsigned)t;
-            o.info[p0 + lane] = r0 | ((lane == ln - 1) ? 64 : 0) | (t << 8) | (s << 16);
-        }
+    for (int sx = s0; sx < s1; ++sx) {
+        const int ln = len_l[sx], raw = tile_l[sx];
+        const int p0 = end_l[raw] * 64 + off_l[sx] - first_l[raw];
+        o.srow0[sx] = p0; o.slen[sx] = ln;
         tot += ln;
+        off_l[sx] = p0;
     }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) tot += __shfl_xor(tot, o_, 64);
+    __syncthreads();
+    PST(5)
+    // ---- per row: element-parallel again; position t of session s is row p0 + t - (T - len)
+#define PLAN_ROW(i_, id_)                                                                                                  \
+    {                                                                                                                      \
+        const int ln = len_l[sI], k = tI - (T - ln);                                                                       \
+        if ((i_) < n && k >= 0) {                                                                                          \
+            const int p0 = off_l[sI], pr = p0 + k;                                                                         \
+            const int gb = (split_rows >= 0 && sI >= split_rows) ? sI - split_rows + row0_ex : sI + row0;                  \
+            o.ids[pr] = (id_);                                                                                             \
+            o.lpos[pr] = (i_);                                                                                             \
+            o.gpos[pr] = (unsigned)gb * (unsigned)T + (unsigned)tI;                                                        \
+            o.info[pr] = (p0 & 63) | ((k == ln - 1) ? 64 : 0) | (tI << 8) | (sI << 16);                                    \
+        }                                                                                                                  \
+        sI += ds; tI += dt;                                                                                                \
+        if (tI >= T) { tI -= T; ++sI; }                                                                                    \
+    }
+    {
+        int sI = tid / T, tI = tid - sI * T;
+        if (NV > 0) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                if (u * PLAN_THREADS >= n) break;
+                PLAN_ROW(tid + u * PLAN_THREADS, vr[u])
+            }
+        } else {
+            for (int i0 = tid; i0 < n; i0 += 8 * PLAN_THREADS) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * PLAN_THREADS; v[u] = (i < n) ? seq[i] : 0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) PLAN_ROW(i0 + u * PLAN_THREADS, v[u])
+            }
+        }
+    }
+#undef PLAN_ROW
+    PST(6)
     if (lane == 0) atomicAdd(&tot_l, tot);
     __syncthreads();
+    PST(7)
     if (tid == 0) { o.hdr[0] = ntiles; o.hdr[1] = ntiles * 64; o.hdr[2] = tot_l; o.hdr[3] = w1; }
 }
 
@@ -150,8 +228,11 @@ int ader_seq_pack_plan(const int* seq, int B, int T, int row0, int split_rows, i
                        const AderSeqPack* out, void* stream) {
     if (B <= 0) return 0;
     if (B > PLAN_MAXB || T < 1 || T > 64 || !out) return -2;
-    hipLaunchKernelGGL(k_seq_pack_plan, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, seq, B, T, row0, split_rows, row0_ex,
-                       w1_min, w1_max, target, *out);
+    const int n = B * T;
+#define PLAN_LAUNCH(NV_) hipLaunchKernelGGL(k_seq_pack_plan<NV_>, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, seq, B, T, row0,    \
+                                            split_rows, row0_ex, w1_min, w1_max, target, *out)
+    PLAN_LAUNCH(0);
+#undef PLAN_LAUNCH
     HIP_LAUNCH_CHECK();
     return 0;
 }

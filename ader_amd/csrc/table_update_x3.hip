@@ -879,6 +879,7 @@ static bool tab_pairs() {                 // (ADER_DIAG, ADER_X3_TILE=64: k_tab1
 
 // table_update_x3p.hip: the pipelined kernel (large catalogs); 1 = launched, 0 = shape not covered, otherwise an error
 int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st);
+static int g_x3_pair_min_tiles = 0;       // ader_x3_update_pair_min_tiles(): 0 = pairs always (measured: no difference on the shipped catalogs)
 static int g_x3_pipelined = 0;            // ader_x3_update_pipelined(): off by default -- see the measurements at the setter
 
 template <bool EXTRA, bool KD>
@@ -918,7 +919,9 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
         if (rc == 1) return 0;
         if (rc != 0) return rc;
     }
-    if (tab_pairs() && (a.tile_off & 1) == 0 && !(a.ko & 0xff)) {
+    // (A/B knob: below g_x3_pair_min_tiles tiles, one tile per workgroup.  Measured on the shipped catalogs, 400-700 tiles, distilled step:
+    //  k_tab16x3 107.6 us against k_tab32x3 112.1 us, step 0.4594 against 0.4575 ms -- no difference, the default stays pairs)
+    if (tab_pairs() && tiles > g_x3_pair_min_tiles && (a.tile_off & 1) == 0 && !(a.ko & 0xff)) {
         if (kd) return tab32x3_launch_t<false, true>(a, fa, tiles, lds, st);
         if (extra) return tab32x3_launch_t<true, false>(a, fa, tiles, lds, st);
         return tab32x3_launch_t<false, false>(a, fa, tiles, lds, st);
@@ -936,6 +939,13 @@ extern "C" {
 // update in 0.93 ms against 1.00 ms, but its persistent 512-thread workgroups own every register of every CU, so the weight-gradient
 // products, reductions and the small Adam of the side stream can no longer run INSIDE the update (0.14 ms when they follow it): the
 // step is 2.26 ms against 2.20.  DESIGN.md section 6 has the stamps.
+// tiles (64 table rows each) above which the update takes a PAIR of tiles per workgroup (k_tab32x3) instead of one (k_tab16x3):
+// tuning / A-B knob, bit-identical results either way; negative: query.  Returns the previous setting.
+int ader_x3_update_pair_min_tiles(int tiles) {
+    const int prev = g_x3_pair_min_tiles;
+    if (tiles >= 0) g_x3_pair_min_tiles = tiles;
+    return prev;
+}
 int ader_x3_update_pipelined(int mode) {
     const int prev = g_x3_pipelined;
     if (mode >= 0) g_x3_pipelined = mode ? 1 : 0;

@@ -368,6 +368,9 @@ int ader_x3_rep_image_bytes(int Bp);
  * (csrc/table_update_x3p.hip: >= 4 tile pairs per CU, no EXTRA / KD term), 0 (default) = always k_tab32x3; negative: query only.
  * Returns the previous setting.  Bit-identical results either way (same op sites: ADER.py:91-96). */
 int ader_x3_update_pipelined(int mode);
+/* ... and between its two plain kernels: catalogs of more than `tiles` 64-row tiles take a pair of tiles per workgroup (k_tab32x3),
+ * smaller ones a single tile (k_tab16x3); default 0 = pairs always; negative: query only.  Returns the previous value. */
+int ader_x3_update_pair_min_tiles(int tiles);
 int ader_x3_rep_image(const void* rep_hi, const void* rep_lo, int Bp, void* img, void* stream);
 int ader_tab_update_x3(const void* rep_hi, const void* rep_lo, const void* rep_img, int item_num, int B, int Bp, int H, int N,
                        const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,

@@ -2,11 +2,12 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_seq_fwd')]
+first = 'k_seq_pack_plan' if any(r['Kernel_Name'].startswith('k_seq_pack_plan') for r in rows) else 'k_seq_fwd'
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(first)]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
     s = int(r['Start_Timestamp']) - t0
     e = int(r['End_Timestamp']) - t0
     print("%8.1f %8.1f %7.1f  q%s %s" % (s / 1000, e / 1000, (e - s) / 1000, r.get('Queue_Id', ''), r['Kernel_Name'][:70]))
-print("# step period (start of this k_seq_fwd to the next one): %.1f us" % ((int(rows[b]['Start_Timestamp']) - t0) / 1000))
+print("# step period (start of the step's first session kernel to the next one): %.1f us" % ((int(rows[b]['Start_Timestamp']) - t0) / 1000))
