@@ -187,6 +187,9 @@ class Sampler:
         Call again after split_data / add_exemplar (they repack)."""
         import torch
         self._rows_dev = torch.from_numpy(self._rows).to(device)
+        # fraction of real positions (sessions are left-padded to maxlen, util.py:161-169): what the engine's packed session
+        # kernels go by when the batches no longer pass through the host (Engine.pack_density)
+        self.density = float(np.count_nonzero(self._rows[:, :self.maxlen])) / max(self._rows[:, :self.maxlen].size, 1)
         return self
 
     def _rows_of(self, idx):

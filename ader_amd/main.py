@@ -56,6 +56,7 @@ _BUILD_FLAGS = (
     ("dist_backend", "nccl", str, "torch.distributed backend when WORLD_SIZE > 1"),
     ("device_feed", True, bool, "keep the packed training rows on the GPU and gather batches there"),
     ("eval_batch", 1024, int, "rows per evaluation launch (results do not depend on it)"),
+    ("pack_sessions", "auto", str, ("auto", "on", "off")),
 )
 
 
@@ -140,6 +141,7 @@ def run(args, log=print):
         valid_subseq, train_subseq = train_sampler.split_data(valid_portion=0.1, return_train=True)
         if args.device_feed:
             train_sampler.to_device(model.engine.device)
+            model.engine.pack_density = train_sampler.density        # device batches: the feeder announces how sparse they are
         batch_num = train_sampler.batch_num()
         test_sess, info = dataloader.evaluate_loader(period)
         logs.write(info + '\n')

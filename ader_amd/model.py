@@ -32,6 +32,8 @@ class Ader:
         self.engine = Engine(item_num, maxlen=args.maxlen, hidden_units=args.hidden_units, num_blocks=args.num_blocks,
                              num_heads=args.num_heads, seed=args.random_seed, device=device, logits_dtype=ld,
                              dp_rank=dp_rank, dp_world=dp_world)
+        # session kernels on the real positions only (packed tiles): "auto" goes by the density of the batches (engine.py)
+        self.engine.pack_sessions = {"auto": "auto", "on": True, "off": False}[getattr(args, "pack_sessions", "auto")]
         for n in ("is_training", "input_seq", "pos", "exemplar_logits", "exemplar_pos", "max_item", "lr", "dropout_rate",
                   "test_item", "rep", "logits", "loss", "train_op", "pred_last", "exemp_loss"):
             setattr(self, n, _Handle(n))
