@@ -1,8 +1,8 @@
-// Packing plan of the packed session kernels (seqp_fwd.hip, seqp_bwd.hip): one launch, one workgroup.
+// Packing plan of the packed session kernels (seqp_fwd.hip, seqp_bwd.hip): two small launches.
 //
 // The reference left-pads every session to maxlen (util.py:161-169); on the shipped splits ~90 % of the positions are padding.
 // A padded position influences no real one -- its key is masked (modules.py:188-193), its outputs are re-zeroed (ADER.py:80),
-// its gradient is exactly zero -- so the session kernels may drop those rows altogether.  This kernel lays the REAL positions
+// its gradient is exactly zero -- so the session kernels may drop those rows altogether.  This file lays the REAL positions
 // of a batch out in 64-row tiles: several short sessions share a tile (attention becomes block-diagonal inside it), a tile never
 // splits a session, sessions keep their batch order inside a tile.  The activations of the packed kernels live in this layout
 // ([tile*64 + row, H]); only the representations [B,H], the compact tensors of a pruned last block [B,..] and the gradient rows
@@ -11,12 +11,19 @@
 // Packing rule (no sequential dependency between sessions, so it is two scans): sessions fall into three classes by length --
 // short (<= 16), medium (<= 32), long; inside a class the sessions' rows form one stream in batch order and a session goes to the
 // tile floor(start / w) of the stream offset it starts at; because a session is shorter than 64 - w + 1 the rows that land in a
-// tile never exceed 64 (16 <= w <= 49 for short, 33 for medium; long sessions get a tile each).  w of the short class shrinks when the
-// batch would otherwise fill fewer tiles than the chip has CUs (`target`): the session kernels are latency-bound per tile, a
+// tile never exceed 64 (16 <= w <= 49 for short, 33 for medium; long sessions get a tile each).  w of the short class shrinks when
+// the batch would otherwise fill fewer tiles than the chip has CUs (`target`): the session kernels are latency-bound per tile, a
 // half-filled tile is faster than a full one, and an idle CU is worth nothing.
 //
-// Outputs (AderSeqPack): hdr = {tiles, 64 tiles, real positions, w}; per tile its row count; per packed row the local position
-// b*T + t (ids, positional row), the GLOBAL position (dropout counters: a data-parallel rank draws the masks of its global
+// Launch 1 (k_plan_len, one workgroup per 64 sessions): the first item of every session (its ids read once, coalesced; an LDS
+// atomicMin over the positions) -> slen; the workgroup whose ticket is last then runs the scans for the whole batch (slen read
+// back with L1-bypassing loads: the lengths were stored write-through and drained before the ticket, MI355X_MICROARCH.md
+// "Valid forms") -> srow0, tile_rows, hdr.  Launch 2 (k_plan_rows, one thread per position): the per-row records.
+// (The first form of this file was ONE 1,024-thread workgroup: 22-32 us for 400-600 sessions -- a single CU reads the batch's
+// 120 KB of ids at ~10 B/clock, twice.)
+//
+// Outputs (AderSeqPack): hdr = {tiles, 64 tiles, real positions, w, -, -, -, ticket}; per tile its row count; per packed row the
+// item id, the local position b*T + t, the GLOBAL position (dropout counters: a data-parallel rank draws the masks of its global
 // rows, include/ader_hip.h AderDrop) and info = first row of its session in the tile | last-row flag << 6 | t << 8 | b << 16;
 // per session its first packed row and its length.  An all-padding session keeps position T-1 (one row of id 0), so that every
 // session has a last row.  gfx950 only.
@@ -24,9 +31,10 @@
 #include "../../include/ader_hip.h"
 
 #define PLAN_MAXB 4096
-#define PLAN_THREADS 1024
+#define PLAN_THREADS 256
+#define PLAN_SPW 64                 // sessions per workgroup of the length pass
 
-#ifdef PLAN_STAMP     // diagnostic build only (tools/build_variant.sh ... -DPLAN_STAMP): clocks per phase of thread 0
+#ifdef PLAN_STAMP     // diagnostic build only (tools/build_variant.sh ... -DPLAN_STAMP): clocks per phase of thread 0 of the last workgroup
 __device__ unsigned long long plan_dbg[16];
 #define PST_INIT unsigned long long tprev_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_) :: "memory");
 #define PST(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
@@ -46,7 +54,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// exclusive scan of one int per thread over the workgroup; returns the exclusive prefix, *total = sum.  tmp: 16 ints of LDS
+// exclusive scan of one int per thread over the workgroup; returns the exclusive prefix, *total = sum.  tmp: PLAN_THREADS / 64 ints of LDS
 __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int inc = wave_incl_scan(v, lane);
@@ -64,76 +72,70 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total) {
     return base + inc - v;
 }
 
-// NV > 0: the batch's ids stay in registers between the two element passes (n <= NV * 1024): one memory round trip per launch.
-template <int NV>
-__global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __restrict__ seq, int B, int T, int row0, int split_rows,
-                                                                int row0_ex, int w1_min, int w1_max, int target, AderSeqPack o) {
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan_len(const int* __restrict__ seq, int B, int T, int w1_min, int w1_max, int target,
+                                                          AderSeqPack o) {
+    __shared__ int fz_l[PLAN_SPW];
+    __shared__ int last_l;
     __shared__ unsigned char len_l[PLAN_MAXB];
     __shared__ int first_l[PLAN_MAXB], end_l[PLAN_MAXB];
     __shared__ unsigned short tile_l[PLAN_MAXB];
     __shared__ int off_l[PLAN_MAXB];
-    __shared__ int tmp[16];
-    __shared__ int tot_l;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int n = B * T;
+    __shared__ int tmp[PLAN_THREADS / 64];
+    const int tid = threadIdx.x;
     PST_INIT
-    // ---- lengths.  Element-parallel: every thread reads ids tid, tid + 1024, ... (coalesced, eight loads in flight) and the
-    //      first item of a session is an LDS atomicMin over its positions.  (One wave-load per session, the first form of this
-    //      kernel, paid a memory round trip per session and wave: 25-32 us for 400-600 sessions.)
-    int* fz_l = off_l;                                   // first real position of the session (T-1 for an all-padding one)
-    for (int i = tid; i < B; i += PLAN_THREADS) fz_l[i] = T - 1;
-    if (tid == 0) tot_l = 0;
+    // ---- lengths of this workgroup's sessions
+    const int sb = blockIdx.x * PLAN_SPW, ns = min(PLAN_SPW, B - sb);
+    const int n = ns * T;                                        // <= 4096 ids: sixteen loads per thread, all in flight
+    if (tid < PLAN_SPW) fz_l[tid] = T - 1;                       // first real position (T-1 for an all-padding session)
     __syncthreads();
-    const int ds = PLAN_THREADS / T, dt = PLAN_THREADS - ds * T;         // (s, t) of index i + 1024 from (s, t) of i
-    int vr[NV > 0 ? NV : 1];
-    if (NV > 0) {
+    {
+        const int* __restrict__ p = seq + (size_t)sb * T;
+        int v[16];
 #pragma unroll
-        for (int u = 0; u < NV; ++u) { const int i = tid + u * PLAN_THREADS; vr[u] = (i < n) ? seq[i] : 0; }
+        for (int u = 0; u < 16; ++u) { const int i = tid + u * PLAN_THREADS; v[u] = (i < n) ? p[i] : 0; }
+        const int ds = PLAN_THREADS / T, dt = PLAN_THREADS - ds * T;
         int sI = tid / T, tI = tid - sI * T;
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            if (vr[u] != 0) atomicMin(&fz_l[sI], tI);
+        for (int u = 0; u < 16; ++u) {
+            if (v[u] != 0) atomicMin(&fz_l[sI], tI);
             sI += ds; tI += dt;
             if (tI >= T) { tI -= T; ++sI; }
         }
-    } else {
-        int sI = tid / T, tI = tid - sI * T;
-        for (int i0 = tid; i0 < n; i0 += 8 * PLAN_THREADS) {
-            int v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * PLAN_THREADS; v[u] = (i < n) ? seq[i] : 0; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (v[u] != 0) atomicMin(&fz_l[sI], tI);
-                sI += ds; tI += dt;
-                if (tI >= T) { tI -= T; ++sI; }
-            }
-        }
     }
     __syncthreads();
+    // write-through (L2-visible) stores, drained by every storing wave, then the workgroup's ticket
+    if (tid < ns) __hip_atomic_store(o.slen + sb + tid, T - fz_l[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) last_l = (__hip_atomic_fetch_add(o.hdr + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_l) return;
     PST(0)
-    for (int i = tid; i < B; i += PLAN_THREADS) len_l[i] = (unsigned char)(T - fz_l[i]);
-    for (int i = tid; i < PLAN_MAXB; i += PLAN_THREADS) { first_l[i] = 0x7fffffff; end_l[i] = 0; }
+    // ================= the last workgroup: scans over all sessions
+    for (int i = tid; i < B; i += PLAN_THREADS) len_l[i] = (unsigned char)__hip_atomic_load(o.slen + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < B; i += PLAN_THREADS) { first_l[i] = 0x7fffffff; end_l[i] = 0; }
     __syncthreads();
     // ---- stream offsets per class (thread t owns sessions [t spt, (t+1) spt))
     const int spt = (B + PLAN_THREADS - 1) / PLAN_THREADS;
     const int s0 = tid * spt, s1 = min(B, s0 + spt);
-    int a1 = 0, a2 = 0, a3 = 0;
+    int a1 = 0, a2 = 0, a3 = 0, tot = 0;
     for (int s = s0; s < s1; ++s) {
         const int ln = len_l[s];
+        tot += ln;
         if (ln <= 16) a1 += ln; else if (ln <= 32) a2 += ln; else a3 += 1;
     }
     PST(1)
-    int P1, P2, C3;
+    int P1, P2, C3, TOT;
     int e1 = block_excl_scan(a1, tmp, &P1);
     int e2 = block_excl_scan(a2, tmp, &P2);
     int e3 = block_excl_scan(a3, tmp, &C3);
+    block_excl_scan(tot, tmp, &TOT);
     int w1 = w1_max;
     if (target > 0) w1 = max(w1_min, min(w1_max, (P1 + target - 1) / target));
     w1 = max(16, min(49, w1));          // (>= 16: every window then holds a session start, so the raw tile count never exceeds B)
     PST(2)
     const int w2 = 33;
-    const int n1 = P1 > 0 ? (P1 - 1) / w1 + 1 : 0;       // upper bound of the short tiles (tiles beyond the last start stay empty: none, see below)
+    const int n1 = P1 > 0 ? (P1 - 1) / w1 + 1 : 0;
     const int n2 = P2 > 0 ? (P2 - 1) / w2 + 1 : 0;
     // (every window [k w, (k+1) w) below the stream's last start holds at least one session start, because no session is longer than w;
     //  the window that holds the stream's end may hold none: the tile numbering is compacted below)
@@ -158,68 +160,39 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_seq_pack_plan(const int* __res
     int ntiles;
     int tb = block_excl_scan(cnt, tmp, &ntiles);
     __syncthreads();
-    // end_l[raw tile] becomes its compact index
-    for (int t = t0; t < t1; ++t) {
+    for (int t = t0; t < t1; ++t) {             // end_l[raw tile] becomes its compact index
         const int e = end_l[t];
         if (e > 0) {
             o.tile_rows[tb] = e - first_l[t];
-            end_l[t] = tb++;                    // raw -> compact index
+            end_l[t] = tb++;
         } else end_l[t] = -1;
     }
     __syncthreads();
     PST(4)
-    // ---- per session: first packed row (kept in off_l for the row pass below)
-    int tot = 0;
+    // ---- per session: first packed row
     for (int sx = s0; sx < s1; ++sx) {
-        const int ln = len_l[sx], raw = tile_l[sx];
-        const int p0 = end_l[raw] * 64 + off_l[sx] - first_l[raw];
-        o.srow0[sx] = p0; o.slen[sx] = ln;
-        tot += ln;
-        off_l[sx] = p0;
+        const int raw = tile_l[sx];
+        o.srow0[sx] = end_l[raw] * 64 + off_l[sx] - first_l[raw];
     }
-#pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) tot += __shfl_xor(tot, o_, 64);
-    __syncthreads();
+    if (tid == 0) { o.hdr[0] = ntiles; o.hdr[1] = ntiles * 64; o.hdr[2] = TOT; o.hdr[3] = w1; o.hdr[7] = 0; }     // (ticket re-armed for the next launch)
     PST(5)
-    // ---- per row: element-parallel again; position t of session s is row p0 + t - (T - len)
-#define PLAN_ROW(i_, id_)                                                                                                  \
-    {                                                                                                                      \
-        const int ln = len_l[sI], k = tI - (T - ln);                                                                       \
-        if ((i_) < n && k >= 0) {                                                                                          \
-            const int p0 = off_l[sI], pr = p0 + k;                                                                         \
-            const int gb = (split_rows >= 0 && sI >= split_rows) ? sI - split_rows + row0_ex : sI + row0;                  \
-            o.ids[pr] = (id_);                                                                                             \
-            o.lpos[pr] = (i_);                                                                                             \
-            o.gpos[pr] = (unsigned)gb * (unsigned)T + (unsigned)tI;                                                        \
-            o.info[pr] = (p0 & 63) | ((k == ln - 1) ? 64 : 0) | (tI << 8) | (sI << 16);                                    \
-        }                                                                                                                  \
-        sI += ds; tI += dt;                                                                                                \
-        if (tI >= T) { tI -= T; ++sI; }                                                                                    \
-    }
-    {
-        int sI = tid / T, tI = tid - sI * T;
-        if (NV > 0) {
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                if (u * PLAN_THREADS >= n) break;
-                PLAN_ROW(tid + u * PLAN_THREADS, vr[u])
-            }
-        } else {
-            for (int i0 = tid; i0 < n; i0 += 8 * PLAN_THREADS) {
-                int v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = i0 + u * PLAN_THREADS; v[u] = (i < n) ? seq[i] : 0; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) PLAN_ROW(i0 + u * PLAN_THREADS, v[u])
-            }
-        }
-    }
-#undef PLAN_ROW
-    PST(6)
-    if (lane == 0) atomicAdd(&tot_l, tot);
-    __syncthreads();
-    PST(7)
-    if (tid == 0) { o.hdr[0] = ntiles; o.hdr[1] = ntiles * 64; o.hdr[2] = tot_l; o.hdr[3] = w1; }
+}
+
+// position t of session s is packed row srow0[s] + t - (T - slen[s]) when t >= T - slen[s]
+__global__ __launch_bounds__(256) void k_plan_rows(const int* __restrict__ seq, int B, int T, int row0, int split_rows, int row0_ex,
+                                                   AderSeqPack o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T) return;
+    const int s = i / T, t = i - s * T;
+    const int id = seq[i], ln = o.slen[s], p0 = o.srow0[s];
+    const int k = t - (T - ln);
+    if (k < 0) return;
+    const int pr = p0 + k;
+    const int gb = (split_rows >= 0 && s >= split_rows) ? s - split_rows + row0_ex : s + row0;
+    o.ids[pr] = id;
+    o.lpos[pr] = i;
+    o.gpos[pr] = (unsigned)gb * (unsigned)T + (unsigned)t;
+    o.info[pr] = (p0 & 63) | ((k == ln - 1) ? 64 : 0) | (t << 8) | (s << 16);
 }
 
 extern "C" {
@@ -228,11 +201,10 @@ int ader_seq_pack_plan(const int* seq, int B, int T, int row0, int split_rows, i
                        const AderSeqPack* out, void* stream) {
     if (B <= 0) return 0;
     if (B > PLAN_MAXB || T < 1 || T > 64 || !out) return -2;
-    const int n = B * T;
-#define PLAN_LAUNCH(NV_) hipLaunchKernelGGL(k_seq_pack_plan<NV_>, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, seq, B, T, row0,    \
-                                            split_rows, row0_ex, w1_min, w1_max, target, *out)
-    PLAN_LAUNCH(0);
-#undef PLAN_LAUNCH
+    hipLaunchKernelGGL(k_plan_len, dim3((B + PLAN_SPW - 1) / PLAN_SPW), dim3(PLAN_THREADS), 0, (hipStream_t)stream, seq, B, T, w1_min, w1_max,
+                       target, *out);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_plan_rows, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream, seq, B, T, row0, split_rows, row0_ex, *out);
     HIP_LAUNCH_CHECK();
     return 0;
 }

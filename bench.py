@@ -62,6 +62,65 @@ def synth_batch(B, T, N, seed, device, regime="dense"):
     return torch.from_numpy(seq).to(device), torch.from_numpy(pos).to(device)
 
 
+REAL_SHAPES = {  # step shapes of the real-data configurations: items, train rows, distilled exemplar rows
+    "cfgD": ("DIGINETICA ADER, last period (BASELINE.json configs[1])", 43105, 256, 143),
+    "cfgY": ("YOOCHOOSE ADER, last period (configs[2])", 25750, 512, 102),
+}
+
+
+def real_shape_line(name, dev, seconds=1.2):
+    """One real-data step shape on its own engine, as main.py runs it: synthetic ids of the realistic law (session length
+    1 + Geometric(0.2): the shipped splits' ~90 % padding), the exemplar rows distilled against resident teacher logits over
+    0.9 N items, dropout 0.3, float32 grade, packed session tiles by the engine's own rule.  Same protocol as the headline
+    (warm-up, then K steps bracketed by synchronize; median of 5), sized to ~`seconds` of GPU time."""
+    from ader_amd.engine import Engine, SectionTimer
+    label, N, B, E = REAL_SHAPES[name]
+    T, lr, rate = 50, 5e-4, 0.3
+    batches = [synth_batch(B + E, T, N, 1000 * s + 77, dev, "realistic") for s in range(4)]
+    eng = Engine(N, maxlen=T, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device=dev)
+    eng.pack_density = float(np.mean([float((sq != 0).float().mean()) for sq, _ in batches]))
+    teacher = torch.randn(E, int(0.9 * N), generator=torch.Generator().manual_seed(7)).to(dev)
+    kw = dict(rate=rate, teacher=teacher, ex_trow=torch.arange(E, dtype=torch.int32, device=dev), lambda_=0.8)
+
+    def step(i):
+        sq, ps = batches[i % 4]
+        eng.train_step(sq, ps[:B], N, lr, **kw)
+    for i in range(8):
+        step(i)
+    eng.timer = SectionTimer()
+    for i in range(4):
+        step(i)
+    sections = eng.timer.collect()
+    eng.timer = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(40):
+        step(i)
+    torch.cuda.synchronize()
+    K = max(40, int(seconds / 5 / max((time.perf_counter() - t0) / 40, 1e-5)))
+    dts = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i)
+        torch.cuda.synchronize()
+        dts.append((time.perf_counter() - t0) / K * 1e3)
+    eng.check_status()
+    ms = float(np.median(dts))
+    pk = eng._act.get("pack")
+    out = {"workload": "step shape of %s: N=%d items, %d train + %d distilled rows, synthetic ids, realistic length law" % (label, N, B, E),
+           "ms_per_step": ms, "sessions_per_s": B / ms * 1e3, "rows_per_s": (B + E) / ms * 1e3, "steps": K, "reps_ms": [round(x, 4) for x in dts],
+           "sections_ms": {k: round(v, 4) for k, v in sections.items()}, "real_positions_fraction": round(eng.pack_density, 4),
+           "session_tiles": "packed" if pk is not None else "one session per workgroup", "final_loss": float(eng.loss.item())}
+    if pk is not None:
+        out["tiles"] = int(pk["hdr"][0].item())
+        out["positions"] = int(pk["hdr"][2].item())
+    del eng, teacher
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(N, B, T, H, L, heads, rate, lr, E=0, Np=0):
     """Reference-equivalent CPU step (oracle/ader_ref_cpu.py: materialised [B,N] logits, one-hot CE [+ distillation against E
     teacher rows], autograd, dense TF-style Adam) timed on this host's cores.  Bounded sample: full steps of the same workload
@@ -136,6 +195,8 @@ def main():
                     help="packed session tiles (csrc/seqp_*.hip: the session kernels on the real positions only).  auto: the engine's "
                          "rule on the density of the synthetic batches (packed in the realistic regime, not in the dense one)")
     ap.add_argument("--pack-window", default=None, help="w1_min,w1_max,target of the packing plan (tuning; default: the engine's)")
+    ap.add_argument("--no-real-shapes", action="store_true",
+                    help="skip the real_shapes block (cfgD / cfgY step shapes with the realistic length law and ADER rows, ~2 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32grade", "--no-companion", dest="no_companion", action="store_true",
                     help="skip the companion run of the other logits type (bf16 beside the x3 headline)")
@@ -507,6 +568,15 @@ def main():
                 herd = {"failed": repr(e)}
         if roof is not None:
             roof["herding"] = herd
+        real = None
+        if world == 1 and not args.no_real_shapes and args.workload == "cfgS" and not E and args.regime == "dense":
+            # the workloads the reference trains on (BASELINE.json configs[1], [2]) on the driver-run line, after everything else
+            real = {}
+            for nm in REAL_SHAPES:
+                try:
+                    real[nm] = real_shape_line(nm, dev)
+                except Exception as e:
+                    real[nm] = {"failed": repr(e)}
         prec = {"bf16": "logit GEMMs: bf16 operands, fp32 accumulate + softmax; block GEMMs and attention: bf16x3 (three bf16 MFMAs "
                         "per product on hi/lo splits, ~2^-16 relative, fp32 accumulate); LayerNorm, softmax, optimizer, master "
                         "weights: fp32",
@@ -540,6 +610,7 @@ def main():
             ("ms_per_step_" + (comp_name or "companion")): comp["ms_per_step"] if comp else None,
             "companion": comp,
             "roofline": roof, "cpu_baseline": cpu,
+            "real_shapes": real,
         }
         print(json.dumps(out))
     if world > 1:

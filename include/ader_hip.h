@@ -124,7 +124,8 @@ int ader_seq_fwd(const AderSeqFwd* desc, void* stream);
  * attention block-diagonal over the sessions of a tile.  Activation tensors of these kernels are in TILE order ([tile*64 + row, ..],
  * probabilities [tile][key][query]); rep / meanf / stdf [B,..], the compact tensors of a pruned block [B,..] and the gradient rows of
  * the input embeddings [B*T,H] (only real positions written) stay session-indexed.
- * Plan arrays (device, written by ader_seq_pack_plan): hdr [4] = {tiles, 64*tiles, real positions, window}; tile_rows [<= B]; per
+ * Plan arrays (device, written by ader_seq_pack_plan): hdr [8] = {tiles, 64*tiles, real positions, window, -, -, -, ticket of the
+ * length pass: zero before the first call}; tile_rows [<= B]; per
  * packed row (<= 64 B entries): ids (item id), lpos (b*T + t), gpos (GLOBAL position (b + row offset)*T + t: the dropout counters
  * of a data-parallel rank, see AderDrop), info = first tile row of the row's session | last-position flag << 6 | t << 8 | b << 16;
  * per session: srow0 (first packed row), slen (real positions, >= 1: an all-padding session keeps position T-1).

@@ -143,19 +143,25 @@ def main():
         json.dump(rec, open(os.path.join(ROOT, "tests", "golden", "oracle_ader16.json"), "w"), indent=1)
         print(len(per), json.dumps(rec["average"]))
         return
-    threads = os.cpu_count()
+    threads = 8                    # pinned: the record is a function of the thread count (threaded float32 sums), see "reproducibility"
     if "--threads" in argv:
         i = argv.index("--threads"); threads = int(argv[i + 1]); del argv[i:i + 2]
+    out_name, label = "oracle_ader16.json", "ADER, default flags (herding exemplars 30000, lambda_ 0.8 adaptive, dropout 0.3), random_seed 0"
+    if "--out" in argv:            # another configuration of the same driver (e.g. --disable_distillation True: the poster's ER-herding column)
+        i = argv.index("--out"); out_name = argv[i + 1]; del argv[i:i + 2]
+        label = "flags beyond the defaults: " + " ".join(argv)
     torch.set_num_threads(threads)
     M.Ader = OracleAder                                    # the only substitution: everything else is the product's host driver
     args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--device_feed", "False", "--save_dir", "oracle-ader16",
                                         "--results_root", "/tmp/oracle_ader16"] + argv)
     t0 = time.time()
     out = M.run(args)
-    rec = {"dataset": "DIGINETICA", "config": "ADER, default flags (herding exemplars 30000, lambda_ 0.8 adaptive, dropout 0.3), random_seed 0",
+    rec = {"dataset": "DIGINETICA", "config": label,
            "periods": out["periods"], "average": out["average"], "torch": torch.__version__, "threads": threads,
-           "minutes": round((time.time() - t0) / 60.0, 1)}
-    json.dump(rec, open(os.path.join(ROOT, "tests", "golden", "oracle_ader16.json"), "w"), indent=1)
+           "minutes": round((time.time() - t0) / 60.0, 1),
+           "reproducibility": "not bitwise reproducible: threaded CPU float32 sums move the early-stopping epoch; re-runs of a period "
+                              "land within +-0.25 Recall@20 of each other (VERDICT r4: 48.98 against 49.21 for period 1)"}
+    json.dump(rec, open(os.path.join(ROOT, "tests", "golden", out_name), "w"), indent=1)
     print(json.dumps(rec["average"]))
 
 

@@ -15,9 +15,9 @@ lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 lib.ader_dbg_read_plan.argtypes = [ctypes.c_void_p, ctypes.c_int]
 print("rc", lib.ader_dbg_read_plan(buf, 16))
-names = ["lengths pass (loads + LDS atomicMin)", "len/first/end init + class sums", "three block scans", "assignment loop (atomics)",
-         "compaction scan + tile rows", "per-session p0", "row pass (stores)", "total reduce"]
-a = np.array(buf[:8], dtype=np.float64)
+names = ["lengths of 64 sessions + ticket (last workgroup)", "slen read-back + init + class sums", "four block scans", "assignment loop (atomics)",
+         "compaction scan + tile rows", "per-session first row + hdr"]
+a = np.array(buf[:6], dtype=np.float64)
 for n_, v in zip(names, a):
     print("%-45s %8.0f clocks %5.1f %%" % (n_, v, 100 * v / a.sum()))
 print("sum %.0f clocks; hdr" % a.sum(), pk["hdr"].cpu().numpy()[:4])

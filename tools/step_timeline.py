@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-first = 'k_seq_pack_plan' if any(r['Kernel_Name'].startswith('k_seq_pack_plan') for r in rows) else 'k_seq_fwd'
+first = 'k_plan_len' if any(r['Kernel_Name'].startswith('k_plan_len') for r in rows) else 'k_seq_fwd'
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(first)]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
