@@ -19,9 +19,9 @@ __device__ __forceinline__ int key_of(int id, int gran, int nkeys) {
 //   count   : cnt[list][key] += 1 per entry (integer atomics)
 //   scan    : one workgroup per list: exclusive prefix over the keys -> first[key]; writes the bucket offsets start[j] = first[j+1]
 //   scatter : slot = first[key] + ticket (atomic) -> tmp[slot] = position            (order inside a bucket: arbitrary)
-//   rank    : one thread per slot: rank = #entries of its bucket with a smaller position -> final slot first[key] + rank
-// The result is independent of the atomics' arrival order: inside a bucket the entries are in position order (so every table
-// row receives its contributions in position order: bit-reproducible), buckets are in id order.
+//   rank    : one thread per slot: rank = #entries of its bucket with a smaller (id, position) -> final slot first[key] + rank
+// The result is independent of the atomics' arrival order: inside a bucket the entries are in (id, position) order (so every table
+// row receives its contributions in position order: bit-reproducible -- and as one run), buckets are in id order.
 __global__ __launch_bounds__(256) void k_ip_count(const int* __restrict__ ids0, int n0, const int* __restrict__ ids1, int n1, int gran,
                                                   int nkeys, int* __restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,9 +101,14 @@ __global__ __launch_bounds__(256) void k_ip_rank(const int* __restrict__ ids0, i
     const int id = ids[my];
     const int k = key_of(id, gran, nkeys);
     const int k0 = f[k], k1 = f[k + 1];
+    // order inside a bucket: by id, then by position (a table row's entries are consecutive and in position order: the update
+    // kernels sum a row's run in a register).  Quadratic in the bucket's size: buckets hold a handful of entries, a hot item's
+    // a few hundred.
     int rank = 0;
-    for (int u = k0; u < k1; ++u) rank += tp[u] < my;  // (quadratic in the bucket's size: buckets hold a handful of entries, a hot
-                                                       //  item's a few hundred)
+    for (int u = k0; u < k1; ++u) {
+        const int pu = tp[u], iu = ids[pu];
+        rank += (iu < id) || (iu == id && pu < my);
+    }
     (lst ? sid1 : sid0)[k0 + rank] = id;
     (lst ? srow1 : srow0)[k0 + rank] = my;
 }
@@ -117,8 +122,8 @@ int ader_sparse_lists_scratch_n(int n_sp, int n_tg, int N) { return 2 * ip_nkeys
 int ader_sparse_lists_starts(int N) { return ip_nkeys(N); }
 
 // Bucketed lists of the two sparse table-gradient terms (input positions seq [n_sp], labels lab [n_tg]; id 0 = none) for
-// ader_tab_update / ader_tab_update_sh: entries grouped by 64-id bucket in id order, inside a bucket in POSITION order (so the
-// contributions to a table row are added in position order: bit-reproducible), their ids and positions, and the bucket offsets
+// ader_tab_update / ader_tab_update_sh: entries grouped by 64-id bucket in id order, inside a bucket by (id, POSITION) (so the
+// contributions to a table row are consecutive and added in position order: bit-reproducible), their ids and positions, and the bucket offsets
 // start[j] (first entry of bucket j = ids [64 j + 1, 64 j + 65)), j = 0 .. ceil(N/64).  Padding entries (id 0) are left out:
 // the lists hold start[ceil(N/64)] entries.
 int ader_sparse_lists(const int* seq, int n_sp, const int* lab, int n_tg, int N, int* scratch, int* sp_ids, int* sp_rows,

@@ -366,10 +366,12 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
     }
     red[tid] = l;
     __syncthreads();
-    if (tid == 0) {                                  // fixed order
-        float v = 0.0f;
-        for (int k = 0; k < 640; ++k) v += red[k];
-        sL = v;
+    if (tid < 64) {                                  // fixed order: ten strided terms per lane, then the wave butterfly (a single thread
+        float v = 0.0f;                              // walking the 640 partials was a quarter of this kernel on the shipped catalogs)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v += red[tid + 64 * k];
+        v = wave_sum(v);
+        if (tid == 0) sL = v;
     }
     __syncthreads();
     const float L = sL;
@@ -407,11 +409,12 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
         drep[(size_t)bc_ * H + tid] = w * (oh / L - et);
     }
     __syncthreads();
-    red[tid] = part;
+    red[tid] = (tid < H) ? part : 0.0f;
     __syncthreads();
-    if (tid == 0) {
-        float s_lab = 0.0f;
-        for (int k = 0; k < H; ++k) s_lab += red[k];
+    if (tid < 64) {
+        float s_lab = (red[tid] + red[tid + 64]) + red[tid + 128];      // (H <= 160: three terms per lane, fixed order)
+        s_lab = wave_sum(s_lab);
+        if (tid != 0) return;
         const float z = lse2 / LOG2E;
         lse[b] = z;
         rowloss[b] = (t >= 0 || kd) ? w * (z - s_lab) : 0.0f;
@@ -1118,7 +1121,7 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        emb + H, rep);
-    hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
+    if (loss) hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);     // NULL: ader_lbf_sum(rowloss, Bp) later
     HIP_LAUNCH_CHECK();
     return 0;
 }

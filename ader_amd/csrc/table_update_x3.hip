@@ -33,7 +33,8 @@
 
 #define SPV 3                      // input-embedding gradient rows prefetched under the GEMM phase
 #define HEAVY_N 32                 // a bucket with more entries than this in either list takes the heavy path
-#define HVB 16                     // gradient rows in flight per thread on the heavy path
+#define HVB 32                     // gradient rows in flight per thread on the heavy path (k_tab32x3)
+#define HVB1 16                    // ... of k_tab16x3 (168 registers: three workgroups per CU)
 #define SPB 4                      // sparse-list entries per batch of the optimiser phase (loads of a batch are independent)
 #ifndef AV
 #define AV 6                       // 16-byte vectors per thread and load round of the optimiser phase (x theta, m, v)
@@ -367,20 +368,32 @@ __global__ __launch_bounds__(256, 3) void k_tab16x3(TabArgs a, FuseArgs f) {
                 const int n_ = min(256, (K1_) - base_);                                                    \
                 if (tid < n_) { hv_l[tid] = (IDS_)[base_ + tid]; hv_l[256 + tid] = (ROWS_)[base_ + tid]; } \
                 __syncthreads();                                                                           \
-                if (tid < H && id_lo < id_hi) {                                                            \
-                    for (int e0_ = 0; e0_ < n_; e0_ += HVB) {                                              \
-                        int idv[HVB];                                                                      \
-                        float val[HVB];                                                                    \
-                        _Pragma("unroll") for (int u = 0; u < HVB; ++u) {                                  \
-                            const bool in_ = e0_ + u < n_;                                                 \
-                            idv[u] = in_ ? hv_l[e0_ + u] : 0x7fffffff;                                     \
-                            const int rw = in_ ? hv_l[256 + e0_ + u] : 0;                                  \
-                            val[u] = (VAL_) * ((idv[u] < id_hi) ? 1.0f : 0.0f);                            \
-                        }                                                                                  \
-                        _Pragma("unroll") for (int u = 0; u < HVB; ++u)                                    \
-                            if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] OP_ val[u];                \
-                    }                                                                                      \
-                }                                                                                          \
+                if (tid < H && id_lo < id_hi) {                                                                \
+                    /* the list is in (id, position) order: a table row's entries are consecutive -- its sum runs in a register, */ \
+                    /* F + r1 + r2 + ... in position order exactly as one LDS update per entry gave it, without the chain of dependent */ \
+                    /* LDS read-modify-writes (a hot item of the shipped data has hundreds of entries: +50 us on that tile's workgroup) */ \
+                    int cur_ = -1;                                                                             \
+                    float acc_ = 0.0f;                                                                         \
+                    for (int e0_ = 0; e0_ < n_; e0_ += HVB1) {                                                  \
+                        float val[HVB1];                                                                        \
+                        _Pragma("unroll") for (int u = 0; u < HVB1; ++u) {                                      \
+                            const int rw = (e0_ + u < n_) ? hv_l[256 + e0_ + u] : 0;                           \
+                            val[u] = (VAL_);                                                                   \
+                        }                                                                                      \
+                        _Pragma("unroll") for (int u = 0; u < HVB1; ++u) {                                      \
+                            const int id_ = (e0_ + u < n_) ? hv_l[e0_ + u] : 0x7fffffff;                       \
+                            if (id_ < id_hi) {                                                                 \
+                                if (id_ != cur_) {                                                             \
+                                    if (cur_ >= 0) F_l[(cur_ - id_lo) * H + tid] = acc_;                       \
+                                    cur_ = id_;                                                                \
+                                    acc_ = F_l[(id_ - id_lo) * H + tid];                                       \
+                                }                                                                              \
+                                acc_ OP_ val[u];                                                               \
+                            }                                                                                  \
+                        }                                                                                      \
+                    }                                                                                          \
+                    if (cur_ >= 0) F_l[(cur_ - id_lo) * H + tid] = acc_;                                       \
+                }                                                                                              \
                 __syncthreads();                                                                           \
             }
             HEAVY_LIST(meta_l[0], meta_l[1], f.sp_ids, f.sp_rows, f.sp_src[(size_t)rw * H + tid] * f.sp_scale, +=)
@@ -742,20 +755,32 @@ __global__ __launch_bounds__(256, 2) void k_tab32x3(TabArgs a, FuseArgs f) {
                     const int n_ = min(256, (K1_) - base_);                                                \
                     if (tid < n_) { hv_l[tid] = (IDS_)[base_ + tid]; hv_l[256 + tid] = (ROWS_)[base_ + tid]; } \
                     __syncthreads();                                                                       \
-                    if (tid < H && id_lo < id_hi) {                                                        \
-                        for (int e0_ = 0; e0_ < n_; e0_ += HVB) {                                          \
-                            int idv[HVB];                                                                  \
-                            float val[HVB];                                                                \
-                            _Pragma("unroll") for (int u = 0; u < HVB; ++u) {                              \
-                                const bool in_ = e0_ + u < n_;                                             \
-                                idv[u] = in_ ? hv_l[e0_ + u] : 0x7fffffff;                                 \
-                                const int rw = in_ ? hv_l[256 + e0_ + u] : 0;                              \
-                                val[u] = (VAL_) * ((idv[u] < id_hi) ? 1.0f : 0.0f);                        \
-                            }                                                                              \
-                            _Pragma("unroll") for (int u = 0; u < HVB; ++u)                                \
-                                if (idv[u] < id_hi) F_l[(idv[u] - id_lo) * H + tid] OP_ val[u];            \
-                        }                                                                                  \
-                    }                                                                                      \
+                    if (tid < H && id_lo < id_hi) {                                                                \
+                        /* the list is in (id, position) order: a table row's entries are consecutive -- its sum runs in a register, */ \
+                        /* F + r1 + r2 + ... in position order exactly as one LDS update per entry gave it, without the chain of dependent */ \
+                        /* LDS read-modify-writes (a hot item of the shipped data has hundreds of entries: +50 us on that tile's workgroup) */ \
+                        int cur_ = -1;                                                                             \
+                        float acc_ = 0.0f;                                                                         \
+                        for (int e0_ = 0; e0_ < n_; e0_ += HVB) {                                                  \
+                            float val[HVB];                                                                        \
+                            _Pragma("unroll") for (int u = 0; u < HVB; ++u) {                                      \
+                                const int rw = (e0_ + u < n_) ? hv_l[256 + e0_ + u] : 0;                           \
+                                val[u] = (VAL_);                                                                   \
+                            }                                                                                      \
+                            _Pragma("unroll") for (int u = 0; u < HVB; ++u) {                                      \
+                                const int id_ = (e0_ + u < n_) ? hv_l[e0_ + u] : 0x7fffffff;                       \
+                                if (id_ < id_hi) {                                                                 \
+                                    if (id_ != cur_) {                                                             \
+                                        if (cur_ >= 0) F_l[(cur_ - id_lo) * H + tid] = acc_;                       \
+                                        cur_ = id_;                                                                \
+                                        acc_ = F_l[(id_ - id_lo) * H + tid];                                       \
+                                    }                                                                              \
+                                    acc_ OP_ val[u];                                                               \
+                                }                                                                                  \
+                            }                                                                                      \
+                        }                                                                                          \
+                        if (cur_ >= 0) F_l[(cur_ - id_lo) * H + tid] = acc_;                                       \
+                    }                                                                                              \
                     __syncthreads();                                                                       \
                 }
                 HEAVY_LIST(ms[0], ms[1], f.sp_ids, f.sp_rows, f.sp_src[(size_t)rw * H + tid] * f.sp_scale, +=)

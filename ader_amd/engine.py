@@ -1040,10 +1040,13 @@ class Engine:
         drep = self.buf("drep", (B, H))
         with self._sec("logits_fwd"):
             if self.lx3:
+                # (as in the vanilla step: the loss scalar feeds nothing in the backward pass -- summed beside the table update)
+                late_loss = bool(fused and self.dp_world == 1 and self.late_side_stream and self.seq_fused)
                 call("ader_lx3_fwd_kd", ptr(rep), self._pp["emb"], self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
                      ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
                      ptr(trow), ptr(tlse2), ptr(rep_bf), ptr(rep_lo), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off),
-                     ptr(rowloss), ptr(self.loss), ptr(drep), st)
+                     ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), st)
+                self._pending_loss = (rowloss, Bp) if late_loss else None
             else:
                 call("ader_lbf_fwd_kd", ptr(rep), ptr(self.shadow), self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
                      ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
@@ -1391,12 +1394,14 @@ class Engine:
         overlap = bool(self._late or self._atb_q) and self.late_side_stream
         if overlap:
             # weight-gradient products, LayerNorm / positional reductions, small Adam and the bf16 weight planes are compute /
-            # latency bound and independent of the table: a side stream runs them under the HBM-bound table update
+            # latency bound and independent of the table: a side stream runs them under the HBM-bound table update.  The side
+            # stream's wait is placed HERE (behind the backward chain), the update is ENQUEUED FIRST and the small launches after
+            # it: on the small catalogs of the shipped datasets the host is only a launch or two ahead of the GPU, and with the eight
+            # small launches enqueued first the update reached the queue 100 us after the backward chain had finished
+            # (profiles/r5_packed/timeline_cfgY_update_late.txt)
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=self.device, priority=-1)
             self._side.wait_stream(main)
-            with Engine._OnStream(self, self._side):
-                small_update()
         with self._sec("logits_bwd_adam"):
             if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
                 img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", D["Bp"]),), torch.uint8, zero=True)
@@ -1433,6 +1438,8 @@ class Engine:
                      ptr(tids), ptr(torder), ptr(tg_start), tids.numel(), ptr(D["wrow"]), ptr(self.theta), ptr(self.adam_m),
                      ptr(self.adam_v), lr_t, self.beta1, self.beta2, self.eps, 0, -1, ptr(D.get("extra")), st)
         if overlap:
+            with Engine._OnStream(self, self._side):
+                small_update()
             main.wait_stream(self._side)
         else:
             small_update()

@@ -415,8 +415,8 @@ int ader_tab_tile_meta(const int* sp_ids, const int* sp_rows, const int* sp_star
 /* tile_begin/tile_count: restrict the update to 128-item tiles [tile_begin, tile_begin+tile_count) (row-sharded table
  * update under data parallelism; tile_count < 0 = all tiles).  B/Bp then describe the GLOBAL batch. */
 /* The lists themselves (index work, bit-exact): the input positions seq [n_sp] and the labels lab [n_tg] grouped by bucket
- * [g j + id0, g (j+1) + id0) in id order, inside a bucket in POSITION order (every table row receives its contributions in
- * position order: bit-reproducible; padding entries, id 0, come first), their ids and positions, and the bucket offsets
+ * [g j + id0, g (j+1) + id0) in id order, inside a bucket by (id, POSITION) (every table row receives its contributions as one
+ * run in position order: bit-reproducible; padding entries, id 0, are left out), their ids and positions, and the bucket offsets
  * start[j], j = 0 .. ceil(N/g) (ader_sparse_lists_starts(N) ints per list).  A counting sort (integer atomics) whose arrival
  * order is replaced by position ranks.  scratch: ader_sparse_lists_scratch_n(n_sp, n_tg, N) ints.  Replaces, for the gradient
  * of tf.nn.embedding_lookup (modules.py:127) and of the one-hot labels (ADER.py:89), TF's unsorted_segment_sum by a

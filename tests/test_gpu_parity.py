@@ -903,8 +903,8 @@ def test_rank_is_exact_wrt_device_logits_and_matches_oracle(cfg):
 @pytest.mark.parametrize("n_sp,n_tg,N", [(25600, 512, 1_000_000), (19950, 399, 43105), (7, 1, 5), (51200, 1024, 777), (1, 1, 64),
                                          (3000, 0, 65), (204800, 4096, 1_000_000)])
 def test_sparse_lists_are_bucketed_in_position_order(n_sp, n_tg, N):
-    """ader_sparse_lists (index work, bit-exact): entries grouped by 64-id bucket in id order and, inside a bucket, in position
-    order -- i.e. a stable sort by bucket -- with the bucket offsets, against numpy.  Pads (id 0), heavy duplicates, ids in the
+    """ader_sparse_lists (index work, bit-exact): entries in id order and, for one id, in position order -- i.e. a stable sort
+    by id (hence grouped by 64-id bucket) -- with the bucket offsets, against numpy.  Pads (id 0), heavy duplicates, ids in the
     last bucket, and the gathered list sizes of an 8-rank data-parallel step."""
     from ader_amd._lib import call, ptr
     rs = np.random.RandomState(n_sp + N)
@@ -930,7 +930,7 @@ def test_sparse_lists_are_bucketed_in_position_order(n_sp, n_tg, N):
         assert len(bounds) == nb1
         for src, got_ids, got_rows, got_st, n in ((seq, ids, rows, st, n_sp), (lab, tids, trows, tst, n_tg)):
             real = np.flatnonzero(src > 0)               # padding entries (id 0) are left out of the lists
-            o = real[np.argsort((src[real] - 1) // 64, kind="stable")]
+            o = real[np.argsort(src[real], kind="stable")]
             nr = len(real)
             assert np.array_equal(got_rows.cpu().numpy()[:nr], o.astype(np.int32))
             assert np.array_equal(got_ids.cpu().numpy()[:nr], src[o])
