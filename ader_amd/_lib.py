@@ -14,10 +14,8 @@ _DROP = [P]          # const AderDrop* (NULL: no dropout)
 
 _SIGS = {
     "ader_embed_fwd": [P, P, P, P, I, I, I, I] + _DROP + [P, P],
-    "ader_embed_bwd": [P, P, P, P, I, I, I, I] + _DROP + [P],
     "ader_sq_accum": [P, P, Z, F, P],
     "ader_ewc_penalty": [P, P, P, P, Z, F, P, P, P],
-    "ader_scatter_rows": [P, P, I, I, I, F, P, P],
     "ader_scatter_rows_ordered": [P, P, P, I, P, I, I, F, P, P],
     "ader_ln_fwd": [P, L, P, L, P, P, P, P, P, P, I, I, P],
     "ader_ln_bwd_slabs": [I],

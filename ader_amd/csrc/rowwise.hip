@@ -134,33 +134,9 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ seq, 
     }
 }
 
-// Backward of the prologue.  g = dx0 * mask * keep * scale is written back in place (it is the
-// gradient w.r.t. the positional rows before the batch sum); sqrt(H)*g is scatter-added into dE[id].
-// dE rows hit by several (b,t) use float atomics (order-dependent last bits; the fused single-GPU table update
-// of logits_bf16.hip adds these rows from an id-sorted list instead: deterministic).
-__global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ seq, float* __restrict__ dx,
-                                                   float* __restrict__ demb, int rows, int H, int V, float sqrtH,
-                                                   DropArgs d) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    int id = seq[row];
-    if (id < 0 || id >= V) id = 0;
-    float* g = dx + (size_t)row * H;
-    float* de = demb + (size_t)id * H;
-    for (int c = lane; c < H; c += 64) {
-        float v = 0.0f;
-        if (id != 0) {
-            v = g[c];
-            if (d.thr != 0) v = drop_keep(d, (uint32_t)row * (uint32_t)H + (uint32_t)c) ? v * d.scale : 0.0f;
-            atomicAdd(de + c, v * sqrtH);
-        }
-        g[c] = v;
-    }
-}
-
-// Same as k_embed_bwd without the scatter: leaves g = dx0 * mask * keep * scale in place (consumed by the fused
-// table update of logits_bf16.hip through an id-sorted list) -- no atomics.
+// Backward of the prologue: leaves g = dx0 * mask * keep * scale in place (the gradient w.r.t. the positional rows before the batch
+// sum; consumed by the fused table update through an id-sorted list, or by ader_scatter_rows_ordered) -- no atomics.  (The float-atomic
+// scatter forms of rounds 1-3, ader_embed_bwd / ader_scatter_rows, are gone: their sums depended on the arrival order.)
 __global__ __launch_bounds__(256) void k_embed_bwd_rows(const int* __restrict__ seq, float* __restrict__ dx, int rows, int H, int V,
                                                         DropArgs d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -214,22 +190,7 @@ __global__ __launch_bounds__(256) void k_sum_add(const float* __restrict__ part,
     if (threadIdx.x == 0) out[0] += scale * red[0];
 }
 
-// demb[ids[p]] += rows[p] * scale for p < n (ids 0 / out of range skipped): the scatter half of k_embed_bwd on its own, for rows
-// whose mask / dropout factors are already applied -- the data-parallel dense path adds the input-embedding gradient rows of
-// ALL ranks after the table gradient's all-reduce (float atomics, as k_embed_bwd).
-__global__ __launch_bounds__(256) void k_scatter_rows(const int* __restrict__ ids, const float* __restrict__ rows,
-                                                      float* __restrict__ demb, int n, int H, int V, float scale) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= n) return;
-    const int id = ids[row];
-    if (id <= 0 || id >= V) return;
-    const float* g = rows + (size_t)row * H;
-    float* de = demb + (size_t)id * H;
-    for (int c = lane; c < H; c += 64) atomicAdd(de + c, g[c] * scale);
-}
-
-// The same without atomics: entries bucketed by id (ader_sparse_lists: buckets of `gran` ids in id order, inside a bucket in POSITION
+// demb[id] += rows * scale without atomics: entries bucketed by id (ader_sparse_lists: buckets of `gran` ids in id order, inside a bucket in POSITION
 // order).  One workgroup per bucket, thread c owns column c and adds the bucket's rows one after the other: the sum of a table row is
 // formed in position order -- bit-reproducible, and bit-IDENTICAL on every rank that holds the same gathered rows (the float
 // atomics of k_scatter_rows arrive in a run- and rank-dependent order, which let data-parallel replicas drift apart).
@@ -556,17 +517,6 @@ int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x,
     return 0;
 }
 
-int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
-                   const AderDrop* drop, void* stream) {
-    const int rows = B * T;
-    if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_embed_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, seq, dx, demb, rows, H, V,
-                       sqrtf((float)H), drop_from(drop));
-    hipLaunchKernelGGL(k_pos_grad, dim3((T * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, T, H);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
 int ader_sq_accum(const float* g, float* F, size_t n, float scale, void* stream) {
     if (n == 0) return 0;
     size_t blocks = (n + 255) / 256;
@@ -588,15 +538,8 @@ int ader_ewc_penalty(const float* theta, const float* prev, const float* F, floa
     return 0;
 }
 
-int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, float scale, float* demb, void* stream) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, rows, demb, n, H, V, scale);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
 // demb[ids[k]] += rows[rws[k]] * scale in list order, bucket by bucket (lists from ader_sparse_lists over the gathered ids; nb =
-// number of buckets): deterministic counterpart of ader_scatter_rows.
+// number of buckets): deterministic -- every table row is summed in position order.
 int ader_scatter_rows_ordered(const int* ids, const int* rws, const int* start, int nb, const float* rows, int H, int V, float scale,
                               float* demb, void* stream) {
     if (nb <= 0) return 0;

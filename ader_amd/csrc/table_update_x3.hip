@@ -903,7 +903,7 @@ static bool tab_pairs() {                 // (ADER_DIAG, ADER_X3_TILE=64: k_tab1
 }
 
 // table_update_x3p.hip: the pipelined kernel (large catalogs); 1 = launched, 0 = shape not covered, otherwise an error
-int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st);
+int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, int wg_per_cu, hipStream_t st);
 static int g_x3_pair_min_tiles = 0;       // ader_x3_update_pair_min_tiles(): 0 = pairs always (measured: no difference on the shipped catalogs)
 static int g_x3_pipelined = 0;            // ader_x3_update_pipelined(): off by default -- see the measurements at the setter
 
@@ -940,7 +940,7 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
     hipStream_t st = (hipStream_t)stream;
     a.tile_end = a.tile_off + tiles;
     if (g_x3_pipelined && !kd && !extra && !(a.ko & 0xff)) {
-        const int rc = tabp_try_launch(a, fa, tiles, st);
+        const int rc = tabp_try_launch(a, fa, tiles, g_x3_pipelined, st);
         if (rc == 1) return 0;
         if (rc != 0) return rc;
     }
@@ -958,8 +958,10 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
 
 extern "C" {
 
-// Kernel choice of ader_tab_update_x3 for large catalogs: 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
-// (table_update_x3p.hip), 0 (default) = always k_tab32x3; a negative argument only queries.  Returns the previous setting.  Both
+// Kernel choice of ader_tab_update_x3 for large catalogs: k >= 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
+// (table_update_x3p.hip) with k workgroups per CU in the grid -- 1: fully persistent, one workgroup per CU walks its share of the tile
+// pairs; k > 1: SEMI-persistent, k x CUs workgroups that own 1/k of that share and retire, so that the side stream's small launches
+// find free CUs again --, 0 (default) = always k_tab32x3; a negative argument only queries.  Returns the previous setting.  Both
 // kernels give bit-identical results (tests/test_gpu_fullsize.py).  Why 0 is the default (round 4, cfg-S, same box): k_tabp runs the
 // update in 0.93 ms against 1.00 ms, but its persistent 512-thread workgroups own every register of every CU, so the weight-gradient
 // products, reductions and the small Adam of the side stream can no longer run INSIDE the update (0.14 ms when they follow it): the
@@ -973,7 +975,7 @@ int ader_x3_update_pair_min_tiles(int tiles) {
 }
 int ader_x3_update_pipelined(int mode) {
     const int prev = g_x3_pipelined;
-    if (mode >= 0) g_x3_pipelined = mode ? 1 : 0;
+    if (mode >= 0) g_x3_pipelined = mode > 64 ? 64 : mode;
     return prev;
 }
 

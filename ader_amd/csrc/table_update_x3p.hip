@@ -592,7 +592,7 @@ static size_t tabp_lds(int Bp) {
 
 // Launch the pipelined kernel over tiles [a.tile_off, a.tile_off + tiles) if the shape is one it is built for; returns 1 if it
 // was launched, 0 if the caller should use k_tab32x3 / k_tab16x3, < 0 / a hipError_t on failure.
-int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st) {
+int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, int wg_per_cu, hipStream_t st) {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
@@ -605,7 +605,8 @@ int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st) {
     const int R2 = (2 * TI * a.H + 4 * TP_AT - 1) / (4 * TP_AT);      // Adam rounds per pair
     // every CU gets >= 4 pairs (persistent workgroups: a short list would leave the pipeline mostly filling and draining); the
     // Adam rounds of a pair fit the chunk slots at TP_MR per slot; even first tile
-    if (npairs < 4 * cus || (a.tile_off & 1) || nch < 2 * TP_D || (nch % TP_D) || R2 > TP_MR * (nch - 1) || a.H > 150 || a.Bp > 4096) return 0;
+    const int G = cus * (wg_per_cu < 1 ? 1 : wg_per_cu);
+    if (npairs < 4 * G || (a.tile_off & 1) || nch < 2 * TP_D || (nch % TP_D) || R2 > TP_MR * (nch - 1) || a.H > 150 || a.Bp > 4096) return 0;
     a.tile_end = a.tile_off + tiles;
     a.ko = 0;
 #ifdef ADER_DIAG
@@ -618,6 +619,6 @@ int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         lds_set = (int)lds;
     }
-    hipLaunchKernelGGL(k_tabp, dim3(cus), dim3(512), lds, st, a, fa);
+    hipLaunchKernelGGL(k_tabp, dim3(G), dim3(512), lds, st, a, fa);
     return 1;
 }

@@ -45,6 +45,56 @@ def init(backend="nccl"):
     return rank, world, local
 
 
+class CollectiveGuard:
+    """First-contact insurance for a multi-rank run (the 8-GPU node is the driver's: nothing in the build container can execute
+    RCCL with more than one rank).  While `on`, every collective of the engine / the exchange hooks first announces itself --
+    (call site, kind, shape, dtype[, split sizes]) -- through an all_gather_object and every rank compares: a rank that reaches
+    another call site, or the same one with another shape or with split sizes that do not mirror its peers', raises RuntimeError
+    naming the rank and the call site BEFORE the data collective is issued (where a mismatch would hang or corrupt).  The log of
+    one guarded step is what bench.py prints per rank ahead of its timed region.  Off (the default), a check costs one attribute
+    test."""
+
+    def __init__(self):
+        self.on, self.log, self.group = False, [], None
+
+    def start(self, group=None):
+        self.on, self.log, self.group = True, [], group
+
+    def stop(self):
+        self.on = False
+        return self.log
+
+    def check(self, site, kind, shape, dtype, splits=None):
+        if not self.on:
+            return
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        rec = (site, kind, tuple(int(d) for d in shape), str(dtype).replace("torch.", ""),
+               None if splits is None else (tuple(int(x) for x in splits[0]), tuple(int(x) for x in splits[1])))
+        k = len(self.log)
+        self.log.append(rec)
+        peers = [None] * world
+        dist.all_gather_object(peers, rec, group=self.group)
+        for j, o in enumerate(peers):
+            if o[:2] != rec[:2]:
+                raise RuntimeError("collective #%d of the step: rank %d is at %s (%s), rank %d at %s (%s) -- the ranks diverged"
+                                   % (k, rank, rec[0], rec[1], j, o[0], o[1]))
+            if splits is None and o[2:4] != rec[2:4]:
+                raise RuntimeError("collective #%d (%s at %s): rank %d passes %s %s, rank %d %s %s" % (k, kind, site, rank, rec[3],
+                                                                                                          rec[2], j, o[3], o[2]))
+            if splits is not None and (o[4][0][rank] != rec[4][1][j] or rec[4][0][j] != o[4][1][rank]):
+                raise RuntimeError("collective #%d (%s at %s): rank %d sends %d rows to rank %d, which expects %d; it expects %d from "
+                                   "rank %d, which sends %d" % (k, kind, site, rank, rec[4][0][j], j, o[4][1][rank], rec[4][1][j], j,
+                                                                 o[4][0][rank]))
+
+    def describe(self, rank):
+        return ["[rank %d] collective %2d: %-22s %-28s %s %s%s" % (rank, i, kind, site, dt, list(shape),
+                                                                    "" if sp is None else "  send %s recv %s" % (list(sp[0]), list(sp[1])))
+                for i, (site, kind, shape, dt, sp) in enumerate(self.log)]
+
+
+guard = CollectiveGuard()
+
+
 def shard_bounds(n, world, rank):
     """Contiguous, near-equal split of n rows: rank r gets [lo, hi)."""
     base, rem = divmod(n, world)
@@ -96,8 +146,10 @@ def allreduce_flat(grad, used_table_elems, table_span, bucket_elems=64 << 20, gr
     """SUM-reduce grad[0:used_table_elems] (table rows that can be non-zero) and grad[table_span:] (all other
     parameters) in place.  Rows above max_item are zero on every rank and are skipped."""
     for lo, hi in bucket_ranges(grad.numel(), used_table_elems, bucket_elems):
+        guard.check("dist.allreduce_flat:table", "all_reduce", (hi - lo,), grad.dtype)
         dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, group=group)
     if table_span < grad.numel():
+        guard.check("dist.allreduce_flat:small", "all_reduce", (grad.numel() - table_span,), grad.dtype)
         dist.all_reduce(grad[table_span:], op=dist.ReduceOp.SUM, group=group)
 
 
@@ -166,13 +218,17 @@ class DataParallel:
         per-position rows and _exchange adds the rows of ALL ranks after the reduction (they are 15 MB per rank against 600 MB)."""
         H = eng.H
         self.max_item = int(max_item)
-        return [dist.all_reduce(eng.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                for lo, hi in bucket_ranges(eng.grad.numel(), (self.max_item + 1) * H, self.bucket_elems)]
+        works = []
+        for lo, hi in bucket_ranges(eng.grad.numel(), (self.max_item + 1) * H, self.bucket_elems):
+            guard.check("DataParallel._early:table", "all_reduce(async)", (hi - lo,), eng.grad.dtype)
+            works.append(dist.all_reduce(eng.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
 
     bucket_elems = 64 << 20          # 256 MB buckets: xGMI rings are per-link bound -- few, large collectives
 
     def _exchange(self, eng):
         from ._lib import call, ptr
+        guard.check("DataParallel._exchange:loss", "all_reduce", eng.loss.shape, eng.loss.dtype)
         dist.all_reduce(eng.loss, group=self.group)
         H = eng.H
         table_span = eng.layout["pos"][0]
@@ -185,9 +241,12 @@ class DataParallel:
         W = self.world
         ids_g = torch.empty(W * seq.numel(), dtype=seq.dtype, device=seq.device)
         rows_g = torch.empty(W * dx.numel(), dtype=dx.dtype, device=dx.device)
+        guard.check("DataParallel._exchange:ids", "all_gather", (seq.numel(),), seq.dtype)
         dist.all_gather_into_tensor(ids_g, seq.contiguous().view(-1), group=self.group)      # small bucket: ids + per-position rows ...
+        guard.check("DataParallel._exchange:rows", "all_gather", (dx.numel(),), dx.dtype)
         dist.all_gather_into_tensor(rows_g, dx.contiguous().view(-1), group=self.group)
         if table_span < eng.grad.numel():
+            guard.check("DataParallel._exchange:small", "all_reduce", (eng.grad.numel() - table_span,), eng.grad.dtype)
             dist.all_reduce(eng.grad[table_span:], op=dist.ReduceOp.SUM, group=self.group)   # ... and every non-table parameter
         for w in works:
             w.wait()                                                                  # table buckets (started before the blocks backward)

@@ -277,6 +277,9 @@ class Engine:
         _p = os.environ.get("ADER_DP_PACK")
         self.dp_pack = (self.dp_world >= 8) if _p is None else (_p == "1")
         self.comm_syncs = None   # catalog packed exchange: host synchronisations of the last step (0 with ids_host, else 1)
+        # ... with host-side split sizes (ids_host / pack_counts): compare them with the device plan every n-th step (0 = never; a
+        # host synchronisation each time -- tests and the first steps of a new data pipeline)
+        self.check_pack_counts = int(os.environ.get("ADER_CHECK_PACK_COUNTS", "0"))
         self.kd_split = True     # distilled steps: train rows on the bf16 / fused path, exemplar rows on the exact-f32 kernels
         self.kd_fast = True      # ... exemplar rows on the flash path too (teacher readout + fused KD update)
         # bf16 mode, fused table update: "sh" = k_tab16 (operand from the shadow rows, three workgroups per CU: the faster form),
@@ -1463,6 +1466,7 @@ class Engine:
         def ag(t):                      # [W, *t.shape]; moved as raw bytes (any dtype, any backend)
             t = t.contiguous()
             out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            self._guard("sharded-update:inputs", "all_gather", t.shape, t.dtype)
             dist.all_gather_into_tensor(out.view(torch.uint8).view(-1), t.view(torch.uint8).view(-1), group=grp)
             return out
 
@@ -1471,7 +1475,9 @@ class Engine:
             lab_g, w_g = ag(D["lab"]), ag(D["wrow"])
             seq_g, g_g = ag(D["seq"]), ag(D["g"])
             span = self.layout["pos"][0]
+            self._guard("sharded-update:small-gradients", "all_reduce", (self.P - span,), self.grad.dtype)
             dist.all_reduce(self.grad[span:], group=grp)
+            self._guard("sharded-update:loss", "all_reduce", self.loss.shape, self.loss.dtype)
             dist.all_reduce(self.loss, group=grp)
         tiles = self.shard_items // 128
         ids, order, sp_start, tids, torder, tg_start, tmeta = self._sparse_lists(seq_g, lab_g, N)
@@ -1485,6 +1491,7 @@ class Engine:
             S = self.shard_items * H
             table = self.theta[H:H + W * S]                       # rows 1 .. W*shard_items
             own = table[r * S:(r + 1) * S].clone()
+            self._guard("sharded-update:table-rows", "all_gather", own.shape, own.dtype)
             dist.all_gather_into_tensor(table, own, group=grp)
             if self.shadow is not None:                           # bf16 shadow rows of the other shards
                 call("ader_lbf_shadow_refresh", self._pp["emb"], ptr(self.shadow), self.V, H, st)
@@ -1497,23 +1504,49 @@ class Engine:
         self._advance_adam()
 
     # ---------------------------------------------------------------------------------------- catalog-sharded data parallelism
-    def _ag(self, t):
+    def _ag(self, t, site=None):
         """all-gather -> [W, *t.shape]; moved as raw bytes (any dtype, any backend)."""
         import torch.distributed as dist
         t = t.contiguous()
+        self._guard(site or "Engine._ag", "all_gather", t.shape, t.dtype)
         out = torch.empty((self.dp_world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out.view(torch.uint8).view(-1), t.view(torch.uint8).view(-1), group=self.dp_group)
         return out
+
+    def _guard(self, site, kind, shape, dtype, splits=None):
+        """dist.CollectiveGuard hook: announce the collective about to be issued (a no-op unless the guard is on)."""
+        from . import dist as adist
+        if adist.guard.on:
+            import sys
+            f = sys._getframe(1)
+            while f.f_back is not None and f.f_code.co_name in ("_guard", "_ag", "_a2a", "_a2a_rows"):
+                f = f.f_back
+            adist.guard.check("%s@%s:%d" % (site, os.path.basename(f.f_code.co_filename), f.f_lineno), kind, shape, dtype, splits)
 
     def _a2a(self, t):
         """t [W, ...]: slice j goes to rank j; returns [W, ...] with slice i received from rank i."""
         import torch.distributed as dist
         t = t.contiguous()
+        self._guard("Engine._a2a", "all_to_all", t.shape, t.dtype)
         if dist.get_backend(self.dp_group) == "nccl":
             out = torch.empty_like(t)
             dist.all_to_all_single(out.view(torch.uint8).view(-1), t.view(torch.uint8).view(-1), group=self.dp_group)
             return out
-        return self._ag(t)[:, self.dp_rank].contiguous()        # backends without all-to-all on device tensors (tests)
+        adist_on = self._guard_off()
+        try:
+            return self._ag(t)[:, self.dp_rank].contiguous()    # backends without all-to-all on device tensors (tests)
+        finally:
+            self._guard_on(adist_on)
+
+    def _guard_off(self):
+        """the gloo stand-ins of the all-to-alls are built from an all-gather: announced once, as the all-to-all they stand for"""
+        from . import dist as adist
+        was, adist.guard.on = adist.guard.on, False
+        return was
+
+    def _guard_on(self, was):
+        from . import dist as adist
+        adist.guard.on = was
 
     def _a2a_rows(self, rows, counts):
         """Uneven all-to-all of rows [K, H]: counts [W, W] (host ints), counts[i][j] = rows rank i sends to rank j; the local
@@ -1522,6 +1555,7 @@ class Engine:
         W, r = self.dp_world, self.dp_rank
         ins = [int(c) for c in counts[r]]
         outs = [int(counts[i][r]) for i in range(W)]
+        self._guard("Engine._a2a_rows", "all_to_all(uneven)", rows.shape[1:], rows.dtype, (ins, outs))
         out = torch.empty((sum(outs),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         if dist.get_backend(self.dp_group) == "nccl":
             dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=outs, input_split_sizes=ins, group=self.dp_group)
@@ -1530,7 +1564,11 @@ class Engine:
         kmax = max(int(sum(counts[i])) for i in range(W))
         pad = torch.zeros((kmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         pad[:rows.shape[0]] = rows
-        allr = self._ag(pad)
+        adist_on = self._guard_off()
+        try:
+            allr = self._ag(pad)
+        finally:
+            self._guard_on(adist_on)
         segs = []
         for i in range(W):
             o = int(sum(counts[i][:r]))
@@ -1598,7 +1636,8 @@ class Engine:
                 # packed exchange: only owned rows travel.  ONE launch (csrc/pack_plan.hip) derives, from the gathered ids, the
                 # [owner, destination] row counts -- the same matrix on every rank -- and every index list of the exchange.  The
                 # counts are the split sizes of the uneven all-to-alls, which torch wants as host integers: when the caller knows
-                # the global batch on the host (`ids_host`, [W, n_all]: main.py and bench.py do -- every rank builds the same
+                # the global batch on the host (`ids_host`, [W, n_all], or `pack_counts`: bench.py precomputes the counts outside its
+                # timed region, tests/test_gpu_dp.py passes ids_host; main.py runs the replicated scheme -- every rank builds the same
                 # batches), they are computed there and the step has NO host synchronisation; otherwise they are read back (one sync).
                 i64 = torch.int64
                 cnt = self.buf("pk_cnt", (2, W, W), torch.int32)
@@ -1607,14 +1646,28 @@ class Engine:
                 call("ader_pack_plan", ptr(ids_g), W, n_all, n_pos, r, S, ptr(cnt), ptr(send_id), ptr(ids_bk), ptr(perm), ptr(bsrc), st)
                 if pack_counts is not None:                                     # (C_all, C_pos) prepared by the caller
                     C_all, C_pos = pack_counts
+                    _check(all(len(C) == W and all(len(row) == W for row in C) for C in (C_all, C_pos)),
+                           "pack_counts must be two %d x %d [owner][destination] count matrices" % (W, W))
                     self.comm_syncs = 0
                 elif ids_host is not None:
+                    # (the layout dist.global_ids_host gives: per rank its input positions, then its labels.  A distilled step's rows
+                    #  are [train | exemplar] x T positions followed by the TRAIN labels only: n_all as computed above)
+                    _check(tuple(np.asarray(ids_host).shape) == (W, n_all),
+                           "ids_host must be [world = %d, %d] (rows * T input positions, then the labels, per rank); got %s"
+                           % (W, n_all, tuple(np.asarray(ids_host).shape)))
                     C_all, C_pos = pack_counts_host(ids_host, n_pos, S)
                     self.comm_syncs = 0
                 else:
                     C = cnt.cpu().tolist()
                     C_all, C_pos = C[0], C[1]
                     self.comm_syncs = 1
+                if self.check_pack_counts and self.comm_syncs == 0 and self.global_step % self.check_pack_counts == 0:
+                    # opt-in cross-check of the caller's host-side counts against the device plan (one host synchronisation): a
+                    # mismatch would misplace rows in the exchange below or hang the uneven all-to-all
+                    Cd = cnt.cpu().tolist()
+                    _check(Cd[0] == [list(r_) for r_ in C_all] and Cd[1] == [list(r_) for r_ in C_pos],
+                           "packed catalog exchange: the host-side split sizes (ids_host / pack_counts) differ from the device plan "
+                           "-- the ranks did not build the same global batch")
                 table = self.theta[:self.V_alloc * H].view(self.V_alloc, H)
                 K = sum(C_all[r])                                               # rows I send, ordered by (destination, position)
                 rows = table.index_select(0, send_id[:K])
@@ -1754,7 +1807,9 @@ class Engine:
                 trow_g = torch.cat([zt - 1, mk_g[:, 2].contiguous().view(-1)])
                 tlse2_g = torch.cat([zt.view(torch.float32), mk_g[:, 3].contiguous().view(torch.float32).view(-1)])
             main.wait_stream(self._side) if getattr(self, "_side", None) is not None else None   # small gradients complete
+            self._guard("catalog:small-gradients", "all_reduce", (self.P - span,), self.grad.dtype)
             dist.all_reduce(self.grad[span:], group=grp)
+            self._guard("catalog:loss", "all_reduce", self.loss.shape, self.loss.dtype)
             dist.all_reduce(self.loss, group=grp)
         ids, order, sp_start, tids, torder, tg_start, tmeta = self._lists_wait()
         tiles = S // 128
@@ -1795,6 +1850,7 @@ class Engine:
         H, S = self.H, self.shard_items * self.H
         tab = self.theta[H:H + self.dp_world * S]
         own = tab[self.dp_rank * S:(self.dp_rank + 1) * S].clone()
+        self._guard("sync_table", "all_gather", own.shape, own.dtype)
         dist.all_gather_into_tensor(tab, own, group=self.dp_group)
         self._table_stale = False
         self.refresh_shadow()
@@ -1808,6 +1864,7 @@ class Engine:
             for buf in (self.adam_m, self.adam_v):
                 table = buf[H:H + self.dp_world * S]
                 own = table[self.dp_rank * S:(self.dp_rank + 1) * S].clone()
+                self._guard("gather_table_state", "all_gather", own.shape, own.dtype)
                 dist.all_gather_into_tensor(table, own, group=self.dp_group)
 
     def train_step(self, seq, pos, max_item, lr, **kw):
@@ -1879,7 +1936,9 @@ class Engine:
         self.sync_table()
         n, N = rep.shape[0], int(max_item)
         if out is None:
-            out = torch.empty((n, N), dtype=torch.float32, device=self.device)
+            # row stride padded to 16 bytes: the teacher readout of a distilled step streams these rows 16 bytes at a time (k_lx3r);
+            # with an odd stride -- max_item is whatever the previous period's catalog was -- it falls back to the slower kernel
+            out = torch.empty((n, (N + 3) // 4 * 4), dtype=torch.float32, device=self.device)[:, :N]
         for s in range(0, n, self.MAX_ROWS):
             e = min(n, s + self.MAX_ROWS)
             B = e - s

@@ -55,7 +55,7 @@ class ExemplarStore:
     # the period's checkpoint and read back (rows + teacher logits + the catalog size they were computed for).
     def save(self, path):
         import torch
-        lg = self.logits.detach().cpu() if hasattr(self.logits, "detach") else torch.as_tensor(np.asarray(self.logits))
+        lg = self.logits.detach().cpu().contiguous() if hasattr(self.logits, "detach") else torch.as_tensor(np.asarray(self.logits))
         rows = torch.as_tensor(np.ascontiguousarray(np.asarray(self.rows), dtype=np.int32))
         torch.save({"rows": rows, "logits": lg, "max_item": int(self.max_item)}, path)
         return path
@@ -64,7 +64,11 @@ class ExemplarStore:
     def load(cls, path, device=None):
         import torch
         d = torch.load(path, weights_only=True)        # tensors and plain numbers only: nothing is unpickled
-        lg = d["logits"].to(device) if device is not None else d["logits"]
+        lg = d["logits"]
+        if device is not None:          # on the device the rows keep the 16-byte aligned stride Engine.teacher_logits gives them
+            pad = torch.empty((lg.shape[0], (lg.shape[1] + 3) // 4 * 4), dtype=lg.dtype, device=device)[:, :lg.shape[1]]
+            pad.copy_(lg)
+            lg = pad
         return cls(d["rows"].numpy(), lg, int(d["max_item"]))
 
     def by_label(self):

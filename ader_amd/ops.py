@@ -209,7 +209,7 @@ def embed_bwd(seq: torch.Tensor, dx: torch.Tensor, V: int, key: int, thr: int, s
     dev = dx.device
     demb, dpos = torch.zeros(V, H, device=dev), torch.zeros(T, H, device=dev)
     # rows first (mask, dropout, positional gradient), then a bucketed, position-ordered accumulation into the table gradient: no
-    # float atomics, bitwise reproducible (ader_embed_bwd is the same arithmetic with an atomic scatter)
+    # float atomics, bitwise reproducible
     call("ader_embed_bwd_rows", ptr(seq), ptr(g), ptr(dpos), B, T, H, V, _drop(key, thr, scale), _st())
     N = V - 1
     i32 = dict(dtype=torch.int32, device=dev)
@@ -511,12 +511,27 @@ def _sqrt_f32(H):
     return float(np.sqrt(np.float32(H)))        # the engine's float32 sqrt(H) (ADER.py:38 scale), not the double one
 
 
-def _check_labels(t, name, N, lo=1):
-    """ids the kernels match by equality: an out-of-range label would silently drop its target term (the loss degrades to lse)"""
+_STATUS = {}        # device -> int32[1]: ids outside their range seen by an op since the last check_status()
+
+
+def _check_labels(t, name, N, lo=0):
+    """ids the kernels match by equality: an out-of-range label would silently drop its target term (the loss degrades to lse).
+    Flagged ON THE DEVICE (no host synchronisation: the ops stay stream-ordered and capturable) into a status word that
+    ader_amd.ops.check_status() reads -- as Engine.check_status does for item ids.  0 is legal: "no target" (a weight-0 padding
+    row of an equal-size data-parallel shard)."""
     if t.numel():
-        mn, mx = int(t.min().item()), int(t.max().item())
-        if mn < lo or mx > N:
-            raise RuntimeError("ader::%s: ids must lie in [%d, %d] (got %d .. %d)" % (name, lo, N, mn, mx))
+        st = _STATUS.get(t.device)
+        if st is None:
+            st = _STATUS[t.device] = torch.zeros(1, dtype=torch.int32, device=t.device)
+        st.bitwise_or_(((t < lo) | (t > N)).any().to(torch.int32))
+
+
+def check_status():
+    """Raise if an op of this module has seen an id outside its range since the last call (one host synchronisation)."""
+    for dev, st in _STATUS.items():
+        if int(st.item()):
+            st.zero_()
+            raise RuntimeError("ader::ops: a label / row id outside its valid range was passed to a logits_ce op on %s" % (dev,))
 
 
 def _x3_fwd_scratch(N, Bp, dev):
@@ -604,7 +619,7 @@ def logits_ce_x3_kd(rep: torch.Tensor, emb: torch.Tensor, pos: torch.Tensor, ex_
             or Bp > 4096):
         raise RuntimeError("ader::logits_ce_x3_kd: bad shapes (B=%d, n_train=%d, n_ex=%d, H=%d, Np=%d, N=%d, item_num=%d)"
                            % (B, n_train, n_ex, H, Np, N, item_num))
-    _check_labels(pos, "logits_ce_x3_kd pos", N), _check_labels(ex_trow, "logits_ce_x3_kd ex_trow", E_all - 1, lo=0)
+    _check_labels(pos, "logits_ce_x3_kd pos", N), _check_labels(ex_trow, "logits_ce_x3_kd ex_trow", E_all - 1)
     dev = rep.device
     i32 = dict(dtype=torch.int32, device=dev)
     tlse_all = torch.empty(E_all, device=dev)

@@ -79,7 +79,9 @@ def real_shape_line(name, dev, seconds=1.2):
     batches = [synth_batch(B + E, T, N, 1000 * s + 77, dev, "realistic") for s in range(4)]
     eng = Engine(N, maxlen=T, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device=dev)
     eng.pack_density = float(np.mean([float((sq != 0).float().mean()) for sq, _ in batches]))
-    teacher = torch.randn(E, int(0.9 * N), generator=torch.Generator().manual_seed(7)).to(dev)
+    Np = int(0.9 * N)
+    teacher = torch.empty(E, (Np + 3) // 4 * 4, device=dev)[:, :Np]          # rows 16-byte aligned, as Engine.teacher_logits allocates them
+    teacher.copy_(torch.randn(E, Np, generator=torch.Generator().manual_seed(7)))
     kw = dict(rate=rate, teacher=teacher, ex_trow=torch.arange(E, dtype=torch.int32, device=dev), lambda_=0.8)
 
     def step(i):
@@ -152,7 +154,10 @@ def cpu_baseline(N, B, T, H, L, heads, rate, lr, E=0, Np=0):
             break
     out = {"value": Bs * n / dt, "unit": "sessions/s", "cores": cores, "kind": "port",
            "sample": "%d step(s) of B=%d train%s rows x T=%d at the full N=%d catalog (%.1f s), torch-CPU float32 restatement, %d threads"
-                     % (n, Bs, " + %d distilled" % E if E else "", T, N, dt, cores)}
+                     % (n, Bs, " + %d distilled" % E if E else "", T, N, dt, cores)
+                     + ("; ONE step on purpose: it is already about twice the 10-30 s of CPU work this leg is bounded to, and a median "
+                        "of three would put three minutes of host time into every default run (the warm-up step above has paid for "
+                        "the thread pool and the allocator)" if n == 1 else "")}
     # single-thread figure on a smaller sample of the same workload: 16 rows at the full catalog
     try:
         torch.set_num_threads(1)
@@ -197,6 +202,8 @@ def main():
     ap.add_argument("--pack-window", default=None, help="w1_min,w1_max,target of the packing plan (tuning; default: the engine's)")
     ap.add_argument("--no-real-shapes", action="store_true",
                     help="skip the real_shapes block (cfgD / cfgY step shapes with the realistic length law and ADER rows, ~2 s each)")
+    ap.add_argument("--no-other-dp-leg", action="store_true",
+                    help="N > 1: skip the leg of the OTHER data-parallel scheme (comm.replicated_ms_per_step beside the catalog default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32grade", "--no-companion", dest="no_companion", action="store_true",
                     help="skip the companion run of the other logits type (bf16 beside the x3 headline)")
@@ -225,6 +232,7 @@ def main():
         if r.returncode != 0 or not lines:
             sys.stderr.write(r.stdout[-4000:] + r.stderr[-4000:])
             sys.exit(r.returncode or 1)
+        sys.stderr.write("\n".join(ln for ln in r.stderr.splitlines() if ln.startswith("[rank ")) + "\n")     # the ranks' collective lists
         print(lines[-1])
         sys.exit(0)
 
@@ -253,7 +261,8 @@ def main():
     kw = dict(rate=rate, n_train_global=B * world)
     if E:
         Np = int(0.9 * N)
-        teacher = torch.randn(E, Np, generator=torch.Generator().manual_seed(7)).to(dev)     # resident teacher logits [E,Np]
+        teacher = torch.empty(E, (Np + 3) // 4 * 4, device=dev)[:, :Np]      # resident teacher logits [E,Np]; rows 16-byte aligned, as
+        teacher.copy_(torch.randn(E, Np, generator=torch.Generator().manual_seed(7)))     # Engine.teacher_logits allocates them
         kw.update(teacher=teacher, ex_trow=torch.arange(E, dtype=torch.int32, device=dev), lambda_=0.8, n_ex_global=E * world)
         batches = [(sq, ps[:B]) for sq, ps in batches]
 
@@ -262,12 +271,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_engine(logits):
+    def make_engine(logits, dp_mode=None):
         eng_ = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=logits,
                       dp_rank=rank, dp_world=world)
         dp_ = adist.DataParallel(eng_, rank, world)
         if world > 1 and (logits == "x3" or (logits == "bf16" and not E)):     # (distilled rows on the sharded table: float32 grade)
-            eng_.dp_mode = args.dp_mode
+            eng_.dp_mode = dp_mode or args.dp_mode
         dp_.set_rows(rank * B, N)
         # the feeder's announcement: fraction of real positions of the batches (what Sampler.to_device tells the engine in main.py)
         eng_.pack_density = float(np.mean([float((sq != 0).float().mean()) for sq, _ in batches]))
@@ -290,11 +299,29 @@ def main():
                     rows.append(np.concatenate([sq.numpy().reshape(-1), ps.numpy()]).astype(np.int32))
                 pack_kw[s_] = {"pack_counts": pack_counts_host(np.stack(rows), B * T, eng_.shard_items)}
 
+    guard_logs = {}
+
     def timed(eng_, reps, sections=True):
         """5 untimed initialisation steps, W warm-up steps (per-kernel HIP events on the last three), then `reps` repetitions of
         EXACTLY K steps, each bracketed by a barrier + synchronize on both sides; per repetition the MAX over ranks."""
         sec_all = {}
         prepare_pack_counts(eng_)
+        if world > 1:
+            # first contact (the multi-GPU node is the driver's): ONE guarded step before anything is timed -- every collective is
+            # announced and compared across the ranks before it is issued (ader_amd/dist.py: CollectiveGuard), a mismatch raises with
+            # the rank and the call site instead of hanging in RCCL -- and every rank prints what it issued
+            adist.guard.start()
+            try:
+                eng_.train_step(*batches[0], N, lr, **kw, **pack_kw[0])
+                torch.cuda.synchronize()
+            finally:
+                log_ = adist.guard.stop()
+            sys.stderr.write("\n".join(["[rank %d] dp_mode=%s world=%d backend=%s: %d collectives per step"
+                                         % (rank, eng_.dp_mode, world, dist.get_backend(), len(log_))] + adist.guard.describe(rank)) + "\n")
+            sys.stderr.flush()
+            guard_logs[eng_.dp_mode] = [{"site": a_, "kind": b_, "shape": list(c_), "dtype": d_,
+                                         "splits": None if e_ is None else {"send": list(e_[0]), "recv": list(e_[1])}}
+                                        for a_, b_, c_, d_, e_ in log_]
         for i in range(5):        # engine initialisation (workspace allocation, kernel attributes, side streams): never timed
             eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
         for i in range(args.warmup):
@@ -332,7 +359,20 @@ def main():
 
     eng = make_engine(args.logits)
     dts, sections, loss = timed(eng, args.reps, not args.no_sections)
+    session_tiles = "packed" if eng._act.get("pack") is not None else "one session per workgroup"
     dt = float(np.median(dts))
+    value_dp_mode = eng.dp_mode if world > 1 else None
+    # the other data-parallel scheme in the same invocation (north_star words the replicated one: dense all-reduce over xGMI overlapped
+    # with backward; `value` is the catalog-sharded default): one repetition of the same K steps
+    other_leg = None
+    if world > 1 and not args.no_other_dp_leg and args.logits == "x3" and not E:
+        other = "replicated" if eng.dp_mode == "catalog" else "catalog"
+        eng_o = make_engine(args.logits, dp_mode=other)
+        dts_o, _, loss_o = timed(eng_o, 1, False)
+        other_leg = {"dp_mode": other, "ms_per_step": dts_o[0] / args.steps * 1e3, "value": B * world * args.steps / dts_o[0],
+                     "final_loss": loss_o, "steps": args.steps}
+        del eng_o
+        torch.cuda.empty_cache()
 
     # ---- sustained figure: the K-step repetitions above are ~40 ms bursts on a chip that clocks down under the logit kernels
     # (MI355X_MICROARCH.md, DVFS): one multi-second region of the SAME steps, no per-kernel events, same barrier + synchronize
@@ -541,6 +581,14 @@ def main():
             else:
                 rb = 2.0 * (W - 1) / W * (N + 1) * H * 4 + (W - 1) * (B * T * 4 + B * T * H * 4) + small
             comm = {"dp_mode": dp_mode if cat > 1 or eng_sharded(args.logits) else "dense all-reduce", "packed_rows": bool(dp_pack),
+                    "value_is": "the %s scheme" % (value_dp_mode,),
+                    ("%s_ms_per_step" % (other_leg["dp_mode"] if other_leg else "other")): (other_leg["ms_per_step"] if other_leg else None),
+                    "other_leg": other_leg,
+                    # what rank 0 announced in the guarded first step of each scheme (every rank prints its own list to stderr)
+                    "collectives": guard_logs,
+                    "split_sizes": ("precomputed outside the timed region from the synthetic batches (pack_counts); a training loop "
+                                    "derives them per step on the host: dist.global_ids_host + engine.pack_counts_host"
+                                    if (cat > 1 and dp_pack) else None),
                     # per step of the catalog-sharded scheme: collectives issued, launches of exchange bookkeeping, host syncs
                     "collectives_per_step": (8 if cat > 1 else None),
                     "bookkeeping_launches_per_step": ((1 + 7) if (cat > 1 and dp_pack) else (2 if cat > 1 else None)),
@@ -600,8 +648,8 @@ def main():
                                        [args.workload], N, B, E, args.regime)),
                        "items": N, "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "hidden": H, "blocks": L, "heads": heads,
                        "dropout": rate, "optimizer": "dense TF-Adam", "exchange": exchange, "precision": prec[args.logits],
-                       "parallelism": "dp%d" % world, "final_loss": loss,
-                       "session_tiles": ("packed" if eng._act.get("pack") is not None else "one session per workgroup"),
+                       "parallelism": "dp%d" % world, "dp_mode_of_value": value_dp_mode, "final_loss": loss,
+                       "session_tiles": session_tiles,
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1)},
             "sustained": sustained,
             "comm": comm,

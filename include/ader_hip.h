@@ -32,21 +32,13 @@ typedef struct { unsigned key, thr; float scale; unsigned base, split, base2; } 
 /* ---- embedding prologue: modules.py:118-130 + ADER.py:41-60 ------------------------------------------- */
 int ader_embed_fwd(const int* seq, const float* emb, const float* pos, float* x, int rows, int T, int H, int V,
                    const AderDrop* drop, int* status, void* stream);
-/* backward: dx [B*T,H] is overwritten with the masked/dropout-scaled gradient; sqrt(H)*that is scatter-added into
- * demb (must already hold the logits-side gradient); dpos [T,H] is overwritten. */
-int ader_embed_bwd(const int* seq, float* dx, float* demb, float* dpos, int B, int T, int H, int V,
-                   const AderDrop* drop, void* stream);
-
-/* as ader_embed_bwd but without the scatter into demb: dx is left holding the per-position gradient rows (consumed by
- * ader_lbf_bwd_adam through an id-sorted list); dpos is overwritten.  seq == NULL: dx already holds those rows
+/* backward of the prologue: dx [B*T,H] is overwritten with the masked / dropout-scaled per-position gradient rows (consumed by the
+ * fused table update through an id-sorted list, or added into demb by ader_scatter_rows_ordered); dpos [T,H] is overwritten.  seq == NULL: dx already holds those rows
  * (ader_seq_bwd_qkv with emb_bwd) and only dpos is computed. */
 int ader_embed_bwd_rows(const int* seq, float* dx, float* dpos, int B, int T, int H, int V, const AderDrop* drop, void* stream);
-/* demb[ids[p]] += rows[p] * scale, p < n (id 0 skipped; float atomics): the scatter of the gather's gradient (modules.py:127
- * differentiated) for rows already masked / dropout-scaled by ader_embed_bwd_rows -- used by the data-parallel dense exchange to add
- * the input-embedding rows of every rank after the table gradient's all-reduce. */
-int ader_scatter_rows(const int* ids, const float* rows, int n, int H, int V, float scale, float* demb, void* stream);
-/* ... without atomics: (ids, rws, start) = the bucketed lists ader_sparse_lists builds from the ids (nb buckets); every table row is
- * summed in position order -- bit-identical on every data-parallel rank that holds the same gathered rows (modules.py:127 gradient) */
+/* demb[ids[k]] += rows[rws[k]] * scale without atomics (the scatter of the gather's gradient, modules.py:127 differentiated, for rows
+ * already masked / dropout-scaled by ader_embed_bwd_rows): (ids, rws, start) = the bucketed lists ader_sparse_lists builds from the ids
+ * (nb buckets); every table row is summed in position order -- bit-identical on every data-parallel rank that holds the same gathered rows (modules.py:127 gradient) */
 int ader_scatter_rows_ordered(const int* ids, const int* rws, const int* start, int nb, const float* rows, int H, int V, float scale,
                               float* demb, void* stream);
 
@@ -365,8 +357,9 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
  * [Bp,168]; ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned; Bp % 32 == 0).  Replaces the dense-Adam + table-gradient op
  * sites ADER.py:91-96 for the item table, as ader_tab_update does. */
 int ader_x3_rep_image_bytes(int Bp);
-/* kernel choice of ader_tab_update_x3 on large catalogs: 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
- * (csrc/table_update_x3p.hip: >= 4 tile pairs per CU, no EXTRA / KD term), 0 (default) = always k_tab32x3; negative: query only.
+/* kernel choice of ader_tab_update_x3 on large catalogs: k >= 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
+ * (csrc/table_update_x3p.hip: >= 4 tile pairs per workgroup, no EXTRA / KD term) with k workgroups per CU in its grid (1: persistent;
+ * k > 1: semi-persistent workgroups that retire after 1/k of a CU's share), 0 (default) = always k_tab32x3; negative: query only.
  * Returns the previous setting.  Bit-identical results either way (same op sites: ADER.py:91-96). */
 int ader_x3_update_pipelined(int mode);
 /* ... and between its two plain kernels: catalogs of more than `tiles` 64-row tiles take a pair of tiles per workgroup (k_tab32x3),

@@ -222,3 +222,50 @@ def test_pack_counts_and_global_ids_on_the_host():
             own = [(min((i - 1) // S, W - 1) if i > 0 else -1) for i in ids[d].tolist()]
             assert C_all[o][d] == sum(1 for x in own if x == o)
             assert C_pos[o][d] == sum(1 for x in own[:per * T] if x == o)
+
+
+# ---------------------------------------------------------------------------------------------- first-contact guard
+def _guard_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = adist.guard
+    res = {}
+    g.start()
+    g.check("site_a", "all_gather", (4, 3), torch.float32)                        # identical on both ranks: passes
+    g.check("site_b", "all_to_all(uneven)", (5,), torch.float32, ([2, 3], [2, 1]) if rank == 0 else ([1, 4], [3, 4]))   # mirrored splits
+    res["ok_log"] = len(g.stop())
+    for name, args0, args1 in (
+            ("shape", ("site_c", "all_gather", (4, 3), torch.float32), ("site_c", "all_gather", (4, 5), torch.float32)),
+            ("site", ("site_d", "all_reduce", (7,), torch.float32), ("site_e", "all_gather", (7,), torch.float32)),
+            ("splits", ("site_f", "all_to_all(uneven)", (5,), torch.float32, ([2, 3], [2, 1])),
+             ("site_f", "all_to_all(uneven)", (5,), torch.float32, ([1, 4], [9, 4])))):
+        g.start()
+        try:
+            g.check(*(args0 if rank == 0 else args1))
+            res[name] = None
+        except RuntimeError as e:
+            res[name] = str(e)
+        g.stop()
+    g.check("off", "all_gather", (1,), torch.float32)                             # off: a no-op (no collective is issued)
+    torch.save(res, out_path + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_guard_names_the_rank_and_the_call_site_on_a_mismatch():
+    """dist.CollectiveGuard (what bench.py --gpus N runs around its first step): matching collectives pass, a rank that arrives
+    with another shape, at another call site, or with split sizes that do not mirror its peer's raises on EVERY rank, before the
+    data collective would be issued, with the ranks and the call site in the message."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "g.pt")
+        mp.spawn(_guard_worker, args=(2, port, out), nprocs=2, join=True)
+        res = [torch.load(out + ".%d" % r) for r in range(2)]
+    for r in range(2):
+        assert res[r]["ok_log"] == 2
+        assert "site_c" in res[r]["shape"] and "rank %d" % r in res[r]["shape"] and "[4, 5]" in res[r]["shape"].replace("(", "[").replace(")", "]")
+        assert "diverged" in res[r]["site"] and "site_d" in res[r]["site"] and "site_e" in res[r]["site"]
+        assert "site_f" in res[r]["splits"] and "expects" in res[r]["splits"]

@@ -21,7 +21,9 @@ def _run(args, env=None):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    out = json.loads(lines[0])
+    out["_stderr"] = r.stderr
+    return out
 
 
 def test_single_gpu_line_has_the_contract_fields():
@@ -49,3 +51,14 @@ def test_gpus_2_starts_its_own_ranks(mode):
     assert d["comm"]["exchange_bytes_per_step"] > 0 and d["comm"]["comm_ms"] >= 0
     assert (d["comm"]["dp_mode"] == "catalog") == (mode == "catalog")
     assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # first-contact insurance: the guarded first step of BOTH schemes (the value's and the other leg's) announced its collectives,
+    # rank 0's lists are on the line, every rank printed its own, and the line says which scheme `value` is
+    other = "replicated" if mode == "catalog" else "catalog"
+    c = d["comm"]
+    assert d["config"]["dp_mode_of_value"] == mode and mode in c["value_is"]
+    assert c["other_leg"]["dp_mode"] == other and c["%s_ms_per_step" % other] > 0
+    assert len(c["collectives"][mode]) >= 3 and len(c["collectives"][other]) >= 3
+    assert any(x["kind"].startswith("all_reduce") for x in c["collectives"]["replicated"])
+    assert any(x["kind"] == "all_gather" for x in c["collectives"]["catalog"])
+    for r_ in (0, 1):
+        assert "[rank %d] dp_mode=%s world=2" % (r_, mode) in d["_stderr"] and "[rank %d] collective  0:" % r_ in d["_stderr"]

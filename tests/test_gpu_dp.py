@@ -224,12 +224,20 @@ def _rccl_worker(rank, world, port, out):
         rows = torch.randn(7, 5, device="cuda")
         assert torch.equal(eng._a2a_rows(rows, [[7]]), rows)                 # uneven all_to_all_single (split sizes)
         for step in range(2):
+            if step == 0:
+                adist.guard.start()         # first-contact guard (dist.CollectiveGuard): every collective announced over RCCL first
             if mode == "sharded":
                 eng.loss_and_grad(seq, pos, N, rate=0.3, _defer_table=True, n_train_global=B)
                 eng._fused_table_adam_sharded(5e-4)                          # all_gather_into_tensor x6, all_reduce x2, row all-gather
             else:
                 eng.dp_pack = mode == "catalog_packed"
                 eng._train_step_catalog(seq, pos, N, 5e-4, rate=0.3, n_train_global=B)
+            if step == 0:
+                log = adist.guard.stop()
+                kinds = [k for _, k, _, _, _ in log]
+                assert len(log) >= 6 and "all_reduce" in kinds and "all_gather" in kinds, log
+                assert (mode != "catalog_packed") or "all_to_all(uneven)" in kinds, log
+                assert all("engine.py:" in site for site, _, _, _, _ in log) and len(adist.guard.describe(0)) == len(log)
         eng.sync_table()
         torch.cuda.synchronize()
         d = (eng.theta - want).abs()
