@@ -174,7 +174,7 @@ def test_x3_fast_path_ops_step_the_table_like_the_engine_bitwise(mode):
     ader_amd.ops.check_status()
     bad = pos_d.clone()
     bad[0] = N + 1
-    torch.ops.ader.logits_ce_x3(rep.detach(), emb, bad, torch.zeros(0, dtype=torch.int32, device=dev), N, w_train, 0.0) \
+    torch.ops.ader.logits_ce_x3(rep.detach(), emb, bad, torch.from_numpy(ex_pos).to(dev), N, w_train, w_ex) \
         if mode != "kd" else torch.ops.ader.logits_ce_x3_kd(rep.detach(), emb, bad, torch.from_numpy(trow).to(dev), teacher, N, 1.0, 1.0)
     with pytest.raises(RuntimeError):
         ader_amd.ops.check_status()
