@@ -3,6 +3,11 @@
 #pragma once
 #include "seq_common.h"
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 #define OOBH 0x40000000u            // out-of-range half: OOBH + OOBH stays out of range and does not wrap
 
 // rows [first_row, first_row + nrows) of a [., row_elems] fp32 tensor

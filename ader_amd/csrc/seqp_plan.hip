@@ -8,12 +8,14 @@
 // ([tile*64 + row, H]); only the representations [B,H], the compact tensors of a pruned last block [B,..] and the gradient rows
 // of the input embeddings [B*T,H] stay session-indexed.
 //
-// Packing rule (no sequential dependency between sessions, so it is two scans): sessions fall into three classes by length --
-// short (<= 16), medium (<= 32), long; inside a class the sessions' rows form one stream in batch order and a session goes to the
-// tile floor(start / w) of the stream offset it starts at; because a session is shorter than 64 - w + 1 the rows that land in a
-// tile never exceed 64 (16 <= w <= 49 for short, 33 for medium; long sessions get a tile each).  w of the short class shrinks when
-// the batch would otherwise fill fewer tiles than the chip has CUs (`target`): the session kernels are latency-bound per tile, a
-// half-filled tile is faster than a full one, and an idle CU is worth nothing.
+// Packing rule (no sequential dependency between sessions, so it is two scans): the SHORT sessions (<= 16 positions: 97 % of the
+// shipped data) form one stream of rows in batch order and a session goes to the tile floor(start / w) of the stream offset it
+// starts at; because a session is shorter than 64 - w + 1 the rows that land in a tile never exceed 64 (16 <= w <= 49).  w
+// shrinks when the batch would otherwise fill fewer tiles than the chip has CUs (`target`): the session kernels are latency-bound
+// per tile, a half-filled tile is faster than a full one, and an idle CU is worth nothing -- at the default w = 17 a tile holds at
+// most 32 rows, which is what the forward's 16-column mapping is for.  Every longer session gets a tile of its own (17..32
+// positions: still a small tile; a tile with more rows takes the 32x32 mapping and, being the slowest workgroup, sets the launch's
+// duration -- rounds 5a's medium class, two or three such sessions per 64-row tile, put one in nearly every batch).
 //
 // Launch 1 (k_plan_len, one workgroup per 64 sessions): the first item of every session (its ids read once, coalesced; an LDS
 // atomicMin over the positions) -> slen; the workgroup whose ticket is last then runs the scans for the whole batch (slen read
@@ -118,33 +120,29 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_len(const int* __restrict
     // ---- stream offsets per class (thread t owns sessions [t spt, (t+1) spt))
     const int spt = (B + PLAN_THREADS - 1) / PLAN_THREADS;
     const int s0 = tid * spt, s1 = min(B, s0 + spt);
-    int a1 = 0, a2 = 0, a3 = 0, tot = 0;
+    int a1 = 0, a3 = 0, tot = 0;
     for (int s = s0; s < s1; ++s) {
         const int ln = len_l[s];
         tot += ln;
-        if (ln <= 16) a1 += ln; else if (ln <= 32) a2 += ln; else a3 += 1;
+        if (ln <= 16) a1 += ln; else a3 += 1;
     }
     PST(1)
-    int P1, P2, C3, TOT;
+    int P1, C3, TOT;
     int e1 = block_excl_scan(a1, tmp, &P1);
-    int e2 = block_excl_scan(a2, tmp, &P2);
     int e3 = block_excl_scan(a3, tmp, &C3);
     block_excl_scan(tot, tmp, &TOT);
     int w1 = w1_max;
     if (target > 0) w1 = max(w1_min, min(w1_max, (P1 + target - 1) / target));
     w1 = max(16, min(49, w1));          // (>= 16: every window then holds a session start, so the raw tile count never exceeds B)
     PST(2)
-    const int w2 = 33;
     const int n1 = P1 > 0 ? (P1 - 1) / w1 + 1 : 0;
-    const int n2 = P2 > 0 ? (P2 - 1) / w2 + 1 : 0;
     // (every window [k w, (k+1) w) below the stream's last start holds at least one session start, because no session is longer than w;
     //  the window that holds the stream's end may hold none: the tile numbering is compacted below)
     for (int s = s0; s < s1; ++s) {
         const int ln = len_l[s];
         int tile, st;
         if (ln <= 16) { st = e1; tile = e1 / w1; e1 += ln; }
-        else if (ln <= 32) { st = e2; tile = n1 + e2 / w2; e2 += ln; }
-        else { st = 0; tile = n1 + n2 + e3; e3 += 1; }
+        else { st = 0; tile = n1 + e3; e3 += 1; }
         tile_l[s] = (unsigned short)tile; off_l[s] = st;
         atomicMin(&first_l[tile], st);
         atomicMax(&end_l[tile], st + ln);
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_len(const int* __restrict
     __syncthreads();
     PST(3)
     // ---- compact the tile numbering (a window without a session start is no tile)
-    const int nt_raw = n1 + n2 + C3;
+    const int nt_raw = n1 + C3;
     int cnt = 0;
     const int tpt = (nt_raw + PLAN_THREADS - 1) / PLAN_THREADS;
     const int t0 = tid * tpt, t1 = min(nt_raw, t0 + tpt);
