@@ -111,7 +111,8 @@ __device__ __forceinline__ void stage_rows_pk(const Out& src, bool pr, bf16* R, 
     }
 }
 
-__global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPack pk) {
+template <bool SMALL>
+__device__ __forceinline__ void seqp_bwd_ffn_body(const AderSeqBwdFfn& a, const AderSeqPack& pk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R0 = (bf16*)smem_raw;
     bf16* R1 = R0 + RSZ;
@@ -122,10 +123,6 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPa
     uint32_t* gph_l = (uint32_t*)(info_l + TR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x, H = a.H;
-    if (tile >= pk.hdr[0]) {                 // (the grid is the host's bound of the tile count: the slab reduction sums every slot)
-        if (tid < 2 * H) a.slab[(size_t)tile * 2 * H + tid] = 0.0f;
-        return;
-    }
     const int nrows = pk.tile_rows[tile];
     const size_t prow0 = (size_t)tile * TR;
     const int nb = wave % 5, mh = wave / 5;
@@ -134,10 +131,9 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPa
     const size_t mrow0 = pruned ? 0 : prow0;
     const uint32_t H4 = (uint32_t)H * 4u;
     bf16x8 bh[10], bl[10];
-    {
-        const int r = lane & 31, hh = lane >> 5;
-        load_bfrags((const bf16*)a.w2 + 2 * WSZ, nb, r, hh, bh, bl);        // W2 planes [n][k] = W2[n][k]: A . W2^T
-    }
+    const int nrb = nrows > 16 ? 2 : 1;
+    if (SMALL) load_bfrags16((const bf16*)a.w2 + 2 * WSZ, wave, lane, bh, bl);      // W2 planes [n][k] = W2[n][k]: A . W2^T
+    else load_bfrags((const bf16*)a.w2 + 2 * WSZ, nb, lane & 31, lane >> 5, bh, bl);
     if (tid < TR) {
         const bool ok = tid < nrows;
         sq_l[tid] = ok ? pk.ids[prow0 + tid] : 0;
@@ -181,6 +177,51 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPa
         }
     }
     lds_barrier();
+    if (SMALL) {
+        // (16-column mapping of tiles with at most 32 rows: seqp_common.h)
+        const int lane_s = opaque(lane);
+        const int c = lane_s & 15, g = lane_s >> 4;
+        const int n = 16 * wave + c;
+        const uint32_t n4 = (n < H) ? (uint32_t)n * 4u : OOBH;
+        // ---- da = (dh2 . W2^T) * relu/dropout-grad -> memory, hi/lo -> R1
+        {
+            const Out oh = make_rows(a.h1d, mrow0, mrows, H), oda = make_rows(a.da, mrow0, mrows, H);
+            float h1[8];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h1[4 * rb + i] = bload(oh, row_base(pruned, 16 * rb + 4 * g + i, H4, info_l) + n4);
+            f32x4v acc[2];
+            tile_mma16(R0, c, g, bh, bl, nrb, acc);
+            load_bfrags16((const bf16*)a.w1 + 2 * WSZ, wave, lane_s, bh, bl);
+            bf16* Th = R1 + (4 * g) * LDR + n;
+            const float sc1 = a.d_ffn1.scale;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                if (rb >= nrb) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = (h1[4 * rb + i] != 0.0f) ? acc[rb][i] * sc1 : 0.0f;
+                    put_split(Th, Th + TR * LDR, (16 * rb + i) * LDR, v);
+                    bstore(oda, row_base(pruned, 16 * rb + 4 * g + i, H4, info_l) + n4, v);
+                }
+            }
+        }
+        lds_barrier();
+        // ---- dy = da . W1^T + g  (in place in Xf)
+        {
+            f32x4v acc[2];
+            tile_mma16(R1, c, g, bh, bl, nrb, acc);
+            float* Xp = Xf + (4 * g) * XS + n;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                if (rb >= nrb) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Xp[(16 * rb + i) * XS] += acc[rb][i];
+            }
+        }
+        lds_barrier();
+    } else {
     // ---- da = (dh2 . W2^T) * relu/dropout-grad (modules.py:254-257) -> memory, hi/lo -> R1
     {
         PHASE_IDS;
@@ -215,6 +256,7 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPa
         }
     }
     lds_barrier();
+    }
     // ---- LayerNorm2 backward -> dx1 (memory) + gamma/beta partials of the tile
     float dg[10], db[10];
 #pragma unroll
@@ -227,7 +269,19 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPa
     flush_ln_partials_pk(dg, db, red_l, a.slab, tile, H, tid);
 }
 
-__global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPack pk) {
+__global__ __launch_bounds__(640) void k_seqp_bwd_ffn(AderSeqBwdFfn a, AderSeqPack pk) {
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    if (tile >= pk.hdr[0]) {                 // (the grid is the host's bound of the tile count: the slab reduction sums every slot)
+        if (tid < 2 * a.H) a.slab[(size_t)tile * 2 * a.H + tid] = 0.0f;
+        return;
+    }
+    // (two instantiations, not a branch per phase: see k_seqp_fwd)
+    if (pk.tile_rows[tile] <= 32) seqp_bwd_ffn_body<true>(a, pk);
+    else seqp_bwd_ffn_body<false>(a, pk);
+}
+
+template <bool SMALL>
+__device__ __forceinline__ void seqp_bwd_qkv_body(const AderSeqBwdQkv& a, const AderSeqPack& pk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* R0 = (bf16*)smem_raw;
     bf16* R1 = R0 + RSZ;
@@ -239,10 +293,6 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPa
     int* lp_l = (int*)(gph_l + TR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x, H = a.H;
-    if (tile >= pk.hdr[0]) {
-        if (tid < 2 * H) a.slab[(size_t)tile * 2 * H + tid] = 0.0f;
-        return;
-    }
     const int nrows = pk.tile_rows[tile];
     const size_t prow0 = (size_t)tile * TR;
     const int nb = wave % 5, mh = wave / 5;
@@ -251,10 +301,9 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPa
     const size_t mrow0 = pruned ? 0 : prow0;
     const uint32_t H4 = (uint32_t)H * 4u;
     bf16x8 bh[10], bl[10];
-    {
-        const int r = lane & 31, hh = lane >> 5;
-        load_bfrags((const bf16*)a.wq + 2 * WSZ, nb, r, hh, bh, bl);
-    }
+    const int nrb = nrows > 16 ? 2 : 1;
+    if (SMALL) load_bfrags16((const bf16*)a.wq + 2 * WSZ, wave, lane, bh, bl);
+    else load_bfrags((const bf16*)a.wq + 2 * WSZ, nb, lane & 31, lane >> 5, bh, bl);
     if (tid < TR) {
         const bool ok = tid < nrows;
         sq_l[tid] = ok ? pk.ids[prow0 + tid] : 0;
@@ -276,6 +325,30 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPa
         stage_rows_pk(ok, false, R1, nrows, npass, H, info_l, wave, lane);
     }
     lds_barrier();
+    if (SMALL) {
+        const int lane_s = opaque(lane);
+        const int c = lane_s & 15, g = lane_s >> 4;
+        const int n = 16 * wave + c;
+        const uint32_t n4 = (n < H) ? (uint32_t)n * 4u : OOBH;
+        // ---- dqin = dQ . Wq^T + dx1 -> Xf
+        const Out ox1 = make_rows(a.dx1, mrow0, mrows, H);
+        float res[8];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[4 * rb + i] = bload(ox1, row_base(pruned, 16 * rb + 4 * g + i, H4, info_l) + n4);
+        f32x4v acc[2];
+        tile_mma16(R0, c, g, bh, bl, nrb, acc);
+        load_bfrags16((const bf16*)a.wk + 2 * WSZ, wave, lane_s, bh, bl);
+        float* Xp = Xf + (4 * g) * XS + n;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (rb >= nrb) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Xp[(16 * rb + i) * XS] = acc[rb][i] + res[4 * rb + i];
+        }
+        lds_barrier();
+    } else {
     // ---- dqin = dQ . Wq^T + dx1 -> Xf
     {
         PHASE_IDS;
@@ -294,6 +367,7 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPa
         }
     }
     lds_barrier();
+    }
     // ---- dV rows -> R0 (dQ is consumed); LayerNorm1 backward in place in Xf + gamma/beta partials
     float dg[10], db[10];
 #pragma unroll
@@ -307,6 +381,51 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPa
         ln_bwd_rows_pk<false>(Xf, ox, false, om, os, pruned, gam, ox, nrows, npass, H, pruned, info_l, wave, lane, dg, db);
     }
     lds_barrier();
+    if (SMALL) {
+        // ---- dx = LN1-backward + dK . Wk^T + dV . Wv^T  [block 0: * (id != 0) * keep * scale of the embedding prologue, rows stored by position]
+        const int lane_s = opaque(lane);
+        const int c = lane_s & 15, g = lane_s >> 4;
+        const int n = 16 * wave + c;
+        const uint32_t n4 = (n < H) ? (uint32_t)n * 4u : OOBH;
+        f32x4v acc[2];
+        tile_mma16(R1, c, g, bh, bl, nrb, acc);
+        load_bfrags16((const bf16*)a.wv + 2 * WSZ, wave, lane_s, bh, bl);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (rb >= nrb) continue;
+            const bf16* Ah = R0 + (16 * rb + c) * LDR + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const bf16x8 ah = *(const bf16x8*)(Ah + 32 * ks);
+                const bf16x8 al = *(const bf16x8*)(Ah + TR * LDR + 32 * ks);
+                acc[rb] = mfma16_bf16(al, bh[ks], acc[rb]);
+                acc[rb] = mfma16_bf16(ah, bl[ks], acc[rb]);
+                acc[rb] = mfma16_bf16(ah, bh[ks], acc[rb]);
+            }
+        }
+        const bool eb = a.emb_bwd != 0;
+        const Out odx = eb ? make_rows(a.dx, 0, a.B * a.T, H) : make_rows(a.dx, prow0, nrows, H);
+        const uint32_t thr = a.d_emb.thr, key = a.d_emb.key;
+        const float scale = thr ? a.d_emb.scale : 1.0f;
+        const float* Xp = Xf + (4 * g) * XS + n;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (rb >= nrb) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * rb + 4 * g + i;
+                float v = Xp[(16 * rb + i) * XS] + acc[rb][i];
+                uint32_t rb_ = (uint32_t)t * H4;
+                if (eb) {
+                    if (thr) v = ((lowbias32((gph_l[t] + (uint32_t)n) ^ key) >> 8) >= thr) ? v * scale : 0.0f;
+                    v = (sq_l[t] != 0) ? v : 0.0f;
+                    const int lp = lp_l[t];
+                    rb_ = (lp >= 0) ? (uint32_t)lp * H4 : OOBH;
+                }
+                bstore(odx, rb_ + n4, v);
+            }
+        }
+    } else {
     // ---- dx = LN1-backward + dK . Wk^T + dV . Wv^T  [block 0: * (id != 0) * keep * scale of the embedding prologue, rows stored by position]
     {
         PHASE_IDS;
@@ -347,7 +466,18 @@ __global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPa
             }
         }
     }
+    }
     flush_ln_partials_pk(dg, db, red_l, a.slab, tile, H, tid);
+}
+
+__global__ __launch_bounds__(640) void k_seqp_bwd_qkv(AderSeqBwdQkv a, AderSeqPack pk) {
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    if (tile >= pk.hdr[0]) {
+        if (tid < 2 * a.H) a.slab[(size_t)tile * 2 * a.H + tid] = 0.0f;
+        return;
+    }
+    if (pk.tile_rows[tile] <= 32) seqp_bwd_qkv_body<true>(a, pk);
+    else seqp_bwd_qkv_body<false>(a, pk);
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward, packed

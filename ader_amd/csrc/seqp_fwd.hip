@@ -35,36 +35,6 @@ extern "C" int ader_dbg_read_sfp(void* dst, int n) { return (int)hipMemcpyFromSy
 #define SFS_DUMP {}
 #endif
 
-// ---- small-tile mapping: wave w owns output columns 16 w .. 16 w + 15 of the tile's (at most 32) rows.  v_mfma_f32_16x16x32_bf16: lane (c = lane & 15,
-// g = lane >> 4) supplies A[row c][k = 8 g ..] and B[k = 8 g ..][column c] and holds D[rows 4 g + i][column c].
-// B fragments from the planes of k_wprep (fragment order of the 32x32x16 maps): the 16 bytes (n, k .. k + 7) a lane needs are one chunk there
-__device__ __forceinline__ void load_bfrags16(const bf16* __restrict__ W, int w, int lane, bf16x8 (&bh)[10], bf16x8 (&bl)[10]) {
-    const int c = lane & 15, g = lane >> 4;
-    const bf16* p = W + ((size_t)(w >> 1) * 10 * 64 + 32 * (g & 1) + 16 * (w & 1) + c) * 8 + (g >> 1) * 512;
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-        bh[ks] = *(const bf16x8*)(p + 1024 * ks);
-        bl[ks] = *(const bf16x8*)(p + WSZ + 1024 * ks);
-    }
-}
-// acc[rb] = tile rows 16 rb .. (hi/lo in LDS) . W columns 16 w ..
-__device__ __forceinline__ void tile_mma16(const bf16* Th, int c, int g, const bf16x8 (&bh)[10], const bf16x8 (&bl)[10], int nrb, f32x4v (&acc)[2]) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        acc[rb] = (f32x4v){0.0f, 0.0f, 0.0f, 0.0f};
-        if (rb >= nrb) continue;
-        const bf16* Ah = Th + (16 * rb + c) * LDR + 8 * g;
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            const bf16x8 ah = *(const bf16x8*)(Ah + 32 * ks);
-            const bf16x8 al = *(const bf16x8*)(Ah + TR * LDR + 32 * ks);
-            acc[rb] = mfma16_bf16(al, bh[ks], acc[rb]);
-            acc[rb] = mfma16_bf16(ah, bl[ks], acc[rb]);
-            acc[rb] = mfma16_bf16(ah, bh[ks], acc[rb]);
-        }
-    }
-}
-
 struct SeqpCtx {
     bf16 *R0, *R1, *R2;
     float *km_l, *qm_l, *red_l;
