@@ -632,9 +632,16 @@ __global__ __launch_bounds__(256) void k_attnp_bwd(AttnPkArgs a, AderSeqPack pk)
     if (tile >= pk.hdr[0]) return;
     const int nrows = pk.tile_rows[tile];
     const size_t prow0 = (size_t)tile * TR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 1, half = tid >> 7;
+    // tiles of at most 32 rows (nearly all of them): there is ONE query / key block, so the four waves split the five channel blocks
+    // {0,1} {2} {3} {4} instead of two of them idling, and the 64-row LDS tile holds TWO operands at once (V + K, then dO + Q): two
+    // staging rounds and four workgroup barriers instead of four and eight
+    const bool small = nrows <= 32;
+    const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+    const int wave = small ? 0 : (part & 1), half = part >> 1;
     const int r = lane & 31, hh = lane >> 5;
-    const int nb0 = half ? 3 : 0, nb1 = half ? 5 : 3;        // this wave's channel blocks of dQ / dV / dK
+    const int nb0 = small ? (part == 0 ? 0 : part + 1) : (half ? 3 : 0);       // this wave's channel blocks of dQ / dV / dK
+    const int nb1 = small ? (part == 0 ? 2 : part + 2) : (half ? 5 : 3);
+    const bool writer = small ? part == 0 : half == 0;                         // who writes the P_drop / dS tiles
     const int H = a.H;
     const size_t base = prow0 * H;
     const int ksteps = (H + 15) >> 4, nblocks = (H + 31) >> 5;
@@ -654,6 +661,7 @@ __global__ __launch_bounds__(256) void k_attnp_bwd(AttnPkArgs a, AderSeqPack pk)
         row_frags_pk(a.dO + base + (size_t)(qok ? q : 0) * H, qok, H, hh, gh, gl);              // dO rows
         __syncthreads();
         stage_split_pk<256>(Th, Tl, a.V + base, nrows, H, tid);
+        if (small) stage_split_pk<256>(Th + 32 * LDR, Tl + 32 * LDR, a.K + base, nrows, H, tid);   // K behind V: rows 32..
         __syncthreads();
         rows_times_frags_pk(Th, Tl, gh, gl, ksteps, nkb, r, hh, X);                              // dP_drop^T = V . dO^T
     }
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(256) void k_attnp_bwd(AttnPkArgs a, AderSeqPack pk)
             Pv[kb][j] = p;
             X[kb][j] = dp;
             const bf16 ph = (bf16)pd;
-            if (half == 0) {
+            if (writer) {
                 Pdh[key * LDP + q] = ph;
                 Pdl[key * LDP + q] = (bf16)(pd - (float)ph);
             }
@@ -705,43 +713,54 @@ __global__ __launch_bounds__(256) void k_attnp_bwd(AttnPkArgs a, AderSeqPack pk)
             if (in && km_l[key] != 0.0f) ds = (Pv[kb][j] * (X[kb][j] - dot)) / a.sqrt_dh;
             X[kb][j] = ds;
             const bf16 sh_ = (bf16)ds;
-            if (half == 0) {
+            if (writer) {
                 dSh[key * LDP + q] = sh_;
                 dSl[key * LDP + q] = (bf16)(ds - (float)sh_);
             }
         }
     f32x16 O[5];
     const int nks = nrows > 32 ? 4 : 2;                     // 16-query steps that hold rows
+#define ZERO_O() _Pragma("unroll") for (int nb = 0; nb < 5; ++nb) _Pragma("unroll") for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    if (small) {
+        // dQ[q][c] = sum_key dS^T[key][q] K[key][c]: K is already staged (rows 32..)
+        ZERO_O()
+        acc_times_rows_pk(X, Th + 32 * LDR, Tl + 32 * LDR, min(nblocks, nb1), 1, lane, O, nb0);
+        store_rows_pk(a.dQ + base, O, 0, lane, nrows, H, nb0, nb1);
+        __syncthreads();                                   // V / K consumed; the P_drop / dS tiles are written
+        stage_split_pk<256>(Th, Tl, a.dO + base, nrows, H, tid);
+        stage_split_pk<256>(Th + 32 * LDR, Tl + 32 * LDR, a.Q + base, nrows, H, tid);
+        __syncthreads();
+        // dV[key][c] = sum_q P_drop^T[key][q] dO[q][c];  dK[key][c] = sum_q dS^T[key][q] Q[q][c]
+        ZERO_O()
+        ptile_times_rows_pk(Pdh, Pdl, Th, Tl, min(nblocks, nb1), nks, lane, 0, O, nb0);
+        store_rows_pk(a.dV + base, O, 0, lane, nrows, H, nb0, nb1);
+        ZERO_O()
+        ptile_times_rows_pk(dSh, dSl, Th + 32 * LDR, Tl + 32 * LDR, min(nblocks, nb1), nks, lane, 0, O, nb0);
+        store_rows_pk(a.dK + base, O, 0, lane, nrows, H, nb0, nb1);
+        return;
+    }
     // dQ[q][c] = sum_key dS^T[key][q] K[key][c]   (accumulator operand)
     __syncthreads();
     stage_split_pk<256>(Th, Tl, a.K + base, nrows, H, tid);
     __syncthreads();
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    ZERO_O()
     if (wave < nkb) acc_times_rows_pk(X, Th, Tl, min(nblocks, nb1), nkb, lane, O, nb0);
     store_rows_pk(a.dQ + base, O, wave, lane, nrows, H, nb0, nb1);
     // dV[key][c] = sum_q P_drop^T[key][q] dO[q][c]   (wave = key block)
     __syncthreads();
     stage_split_pk<256>(Th, Tl, a.dO + base, nrows, H, tid);
     __syncthreads();
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    ZERO_O()
     if (wave < nkb) ptile_times_rows_pk(Pdh, Pdl, Th, Tl, min(nblocks, nb1), nks, lane, wave, O, nb0);
     store_rows_pk(a.dV + base, O, wave, lane, nrows, H, nb0, nb1);
     // dK[key][c] = sum_q dS^T[key][q] Q[q][c]
     __syncthreads();
     stage_split_pk<256>(Th, Tl, a.Q + base, nrows, H, tid);
     __syncthreads();
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) O[nb][j] = 0.0f;
+    ZERO_O()
     if (wave < nkb) ptile_times_rows_pk(dSh, dSl, Th, Tl, min(nblocks, nb1), nks, lane, wave, O, nb0);
     store_rows_pk(a.dK + base, O, wave, lane, nrows, H, nb0, nb1);
+#undef ZERO_O
 }
 
 // ------------------------------------------------------------------------------------------------ pruned block: one query per session
