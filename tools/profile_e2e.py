@@ -13,5 +13,5 @@ pr.enable()
 M.run(args, log=lambda *a: None)
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40)
+pstats.Stats(pr, stream=s).sort_stats(os.environ.get("PROF_SORT", "cumulative")).print_stats(45)
 print(s.getvalue()[:8000])
