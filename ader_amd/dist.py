@@ -45,6 +45,18 @@ def init(backend="nccl"):
     return rank, world, local
 
 
+def pad_rows(x, n, fill=0):
+    """x (numpy array or torch tensor, first dimension = rows) padded with `fill` rows to n rows (unchanged if it has them).
+    Padding rows are id-0 sessions with label 0 / teacher row -1: weight 0 in every loss kernel (csrc/logits.hip:k_build_rowinfo)."""
+    pad = n - len(x)
+    if pad <= 0:
+        return x
+    if isinstance(x, torch.Tensor):
+        return torch.cat([x, torch.full((pad,) + tuple(x.shape[1:]), fill, dtype=x.dtype, device=x.device)])
+    x = np.asarray(x)
+    return np.concatenate([x, np.full((pad,) + x.shape[1:], fill, dtype=x.dtype)])
+
+
 class CollectiveGuard:
     """First-contact insurance for a multi-rank run (the 8-GPU node is the driver's: nothing in the build container can execute
     RCCL with more than one rank).  While `on`, every collective of the engine / the exchange hooks first announces itself --

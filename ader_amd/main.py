@@ -57,6 +57,9 @@ _BUILD_FLAGS = (
     ("device_feed", True, bool, "keep the packed training rows on the GPU and gather batches there"),
     ("eval_batch", 1024, int, "rows per evaluation launch (results do not depend on it)"),
     ("pack_sessions", "auto", str, ("auto", "on", "off")),
+    ("fixed_batches", True, bool, "pad every train / exemplar batch to its nominal row count with weight-0 rows: the feeder drops "
+                                  "invalid sub-sequences, so the row count wanders by a few rows from step to step (251..256 on "
+                                  "DIGINETICA) and every new count re-allocates and clears the engine's ~45 activation buffers"),
 )
 
 
@@ -183,9 +186,21 @@ def run(args, log=print):
                         dp.set_rows(lo, max_item)
                     else:
                         seq_t, pos_t = seq, pos
+                        if args.fixed_batches and 0 < len(pos) < train_sampler.batch_size:
+                            # same step, same loss (the padding rows have weight 0 and the means divide by the real count), one shape
+                            seq_t, pos_t = adist.pad_rows(seq, train_sampler.batch_size), adist.pad_rows(pos, train_sampler.batch_size)
+                            kw.update(n_train_global=len(pos))
+                        dp.set_rows(0, max_item)
                     if use_ex and not args.ewc:                                   # main.py:225
                         ex_seq, ex_pos, idx = exemplar_sampler.next_exemplar_batch()
                         idx = np.asarray(idx, dtype=np.int32)
+                        if world == 1 and args.fixed_batches and (len(pos_t) > len(pos) or 0 < len(ex_seq) < exemplar_sampler.batch_size):
+                            kw.update(n_ex_global=len(ex_seq))
+                            dp.set_rows(0, max_item, ex_row0=len(pos))             # the exemplar rows keep the dropout counters of the unpadded batch
+                            if 0 < len(ex_seq) < exemplar_sampler.batch_size:
+                                ex_seq, ex_pos = (adist.pad_rows(ex_seq, exemplar_sampler.batch_size),
+                                                  adist.pad_rows(ex_pos, exemplar_sampler.batch_size))
+                                idx = adist.pad_rows(idx, exemplar_sampler.batch_size, fill=-1)
                         if world > 1:                                            # ... and exemplar rows (main.py:229 order kept)
                             kw.update(n_ex_global=len(ex_seq))
                             elo, _ = adist.shard_bounds(len(ex_seq), world, rank)

@@ -152,7 +152,8 @@ def main():
         label = "flags beyond the defaults: " + " ".join(argv)
     torch.set_num_threads(threads)
     M.Ader = OracleAder                                    # the only substitution: everything else is the product's host driver
-    args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--device_feed", "False", "--save_dir", "oracle-ader16",
+    # (--fixed_batches False: the oracle takes the feeder's batches as they come -- weight-0 padding rows are a device-side convenience)
+    args = M.build_parser().parse_args(["--dataset", "DIGINETICA", "--device_feed", "False", "--fixed_batches", "False", "--save_dir", "oracle-ader16",
                                         "--results_root", "/tmp/oracle_ader16"] + argv)
     t0 = time.time()
     out = M.run(args)
