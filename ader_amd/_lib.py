@@ -71,6 +71,8 @@ _SIGS = {
     "ader_lx3_merge_parts_kd": [P, P, I, I, I, I, P, P, P, P, P, P, P],
     "ader_lx3_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lx3_fwd_img": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_lx3_fwd_img_lnf": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_lx3_fwd_kd_lnf": [P, P, I, I, I, I, I, I, I, I, P, P, P, L, P, F, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_tab_grad": [P, P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_tab_grad_kd": [P, P, P, I, I, I, I, I, I, P, P, P, P, L, P, P, P, P],
     "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
@@ -128,6 +130,11 @@ class AderSeqFwd(ctypes.Structure):
     _fields_ = ([(k, c_void_p) for k in ("seq", "emb", "pos", "x0", "status", "lnf_g", "lnf_b", "rep", "meanf", "stdf")] +
                 [(k, c_int) for k in ("B", "T", "H", "V", "L")] + [("sqrtH", c_float), ("sqrt_dh", c_float), ("pad_", c_int),
                                                                   ("d_emb", AderDrop), ("blk", AderSeqBlock * SEQ_MAXL)])
+
+
+class AderLnfBwd(ctypes.Structure):
+    """include/ader_hip.h: AderLnfBwd"""
+    _fields_ = [(k, c_void_p) for k in ("x", "mean", "std", "gamma", "dx", "slab")]
 
 
 class AderSeqPack(ctypes.Structure):

@@ -333,7 +333,7 @@ template <bool X3>
 __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __restrict__ lab, const float* __restrict__ wrow,
                                                      float* __restrict__ lse, float* __restrict__ off, float* __restrict__ rowloss,
                                                      float* __restrict__ drep, const float* __restrict__ emb1_f,
-                                                     const float* __restrict__ rep_f) {
+                                                     const float* __restrict__ rep_f, AderLnfBwd lnf) {
     __shared__ float sc[1024];          // per-range scale 2^(pm - M) (0 for empty ranges)
     __shared__ float red[640], red2[640];
     __shared__ float sM, sL;
@@ -407,6 +407,34 @@ __global__ __launch_bounds__(640) void k_lbf_combine(LbfArgs a, const int* __res
             else { et = (float)a.sh1[(size_t)t * LDR + tid]; part = (float)a.rep_bf[(size_t)b * LDR + tid] * et; }
         }
         drep[(size_t)bc_ * H + tid] = w * (oh / L - et);
+    }
+    if (lnf.x) {
+        // ---- fused backward of the final LayerNorm (ADER.py:83-85 differentiated; k_ln_bwd of rowwise.hip for this row, the same
+        //      operations in the same order -- lane c sums channels c, c + 64, c + 128, then the wave butterfly -- so dx is bit-equal
+        //      to the separate launch): dx = (dxh - mean(dxh) - xh mean(dxh xh)) / sd, dxh = g gamma, xh = (x - mean) / sd, g = dRep.
+        //      gamma / beta partials of the row go to slab[row][2][H] (reduced later, beside the table update).
+        __syncthreads();
+        const float g = (tid < H) ? w * (oh / L - et) : 0.0f;
+        const float sd = lnf.std[bc_];
+        const float xh = (tid < H) ? (lnf.x[(size_t)bc_ * H + tid] - lnf.mean[bc_]) / sd : 0.0f;
+        const float dxh = (tid < H) ? g * lnf.gamma[tid] : 0.0f;
+        red[tid] = dxh;
+        red2[tid] = dxh * xh;
+        __syncthreads();
+        if (tid < 64) {
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { s1 += red[tid + 64 * i]; s2 += red2[tid + 64 * i]; }
+            s1 = wave_sum(s1) / (float)H;
+            s2 = wave_sum(s2) / (float)H;
+            if (tid == 0) { sM = s1; sL = s2; }
+        }
+        __syncthreads();
+        if (tid < H) {
+            lnf.dx[(size_t)bc_ * H + tid] = (dxh - sM - xh * sL) / sd;
+            lnf.slab[((size_t)bc_ * 2 + 0) * H + tid] = g * xh;
+            lnf.slab[((size_t)bc_ * 2 + 1) * H + tid] = g;
+        }
     }
     __syncthreads();
     red[tid] = (tid < H) ? part : 0.0f;
@@ -898,7 +926,7 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
     hipLaunchKernelGGL(k_lbf_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, B, Bp, H);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * (Bp / 128)), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, (const float*)nullptr,
-                       (const float*)nullptr);
+                       (const float*)nullptr, AderLnfBwd{});
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -936,7 +964,7 @@ int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_tr
                        kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * nsm + a.ranges2 * nkd), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
-                       (const float*)nullptr, (const float*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, AderLnfBwd{});
     hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -1046,6 +1074,14 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
 int ader_lx3_fwd_img(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
                      void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
                      float* drep, void* rep_img, void* stream) {
+    return ader_lx3_fwd_img_lnf(rep, emb, item_num, B, Bp, H, N, lab, wrow, rep_hi, rep_lo, pm, pl, pO, lse, off, rowloss, loss, drep, rep_img,
+                                nullptr, stream);
+}
+// ... with the backward of the FINAL LayerNorm fused into the merge (lnf != NULL; include/ader_hip.h AderLnfBwd): rep = LN_f(x) (ADER.py:83-85),
+// so the row that has just formed dRep also forms dx = LN_f'(dRep) -- one launch and one kernel boundary fewer on the critical path of every step
+int ader_lx3_fwd_img_lnf(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab, const float* wrow,
+                         void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off, float* rowloss, float* loss,
+                         float* drep, void* rep_img, const AderLnfBwd* lnf, void* stream) {
     if (B <= 0) return 0;
     if (rep_img && ((uintptr_t)rep_img & 15)) return -2;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || ((uintptr_t)emb & 7)) return -2;
@@ -1064,7 +1100,8 @@ int ader_lx3_fwd_img(const float* rep, const float* emb, int item_num, int B, in
     hipLaunchKernelGGL(k_lx3_prep, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, B, Bp, H, (char*)rep_img);
     if (nk) { rc = lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
-    hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep);
+    hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, lab, wrow, lse, off, rowloss, drep, emb + H, rep,
+                       lnf ? *lnf : AderLnfBwd{});
     if (loss) hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, B, loss);     // NULL: ader_lbf_sum later (off the critical path)
     HIP_LAUNCH_CHECK();
     return 0;
@@ -1095,6 +1132,14 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
                     int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all, float w_train,
                     float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo, float* pm, float* pl,
                     float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
+    return ader_lx3_fwd_kd_lnf(rep, emb, item_num, n_train, n_ex, kd_row0, Bp, H, N, Np, pos, ex_trow, teacher, ldt, tlse_all, w_train, w_ex,
+                               lab, wrow, trow, tlse2, rep_hi, rep_lo, pm, pl, pO, pO2, lse, off, rowloss, loss, drep, nullptr, stream);
+}
+int ader_lx3_fwd_kd_lnf(const float* rep, const float* emb, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
+                        int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all, float w_train,
+                        float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo, float* pm, float* pl,
+                        float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, const AderLnfBwd* lnf,
+                        void* stream) {
     if (n_train + n_ex <= 0) return 0;
     if (Bp % 128 != 0 || kd_row0 % 128 != 0 || n_train > kd_row0 || kd_row0 + n_ex > Bp || H > HP || (H & 1) || H < 2 || N > item_num ||
         Np > N || Np < 1 || ((uintptr_t)emb & 7)) return -2;
@@ -1120,7 +1165,7 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
     if (lx3r_supports(x)) { rc = lx3r_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2, true>), dim3(x.ranges2 * ((Bp - kd_row0) / 128)), dim3(256), lds, st, x);
     hipLaunchKernelGGL(k_lbf_combine<true>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
-                       emb + H, rep);
+                       emb + H, rep, lnf ? *lnf : AderLnfBwd{});
     if (loss) hipLaunchKernelGGL(k_lbf_sum, dim3(1), dim3(256), 0, st, rowloss, Bp, loss);     // NULL: ader_lbf_sum(rowloss, Bp) later
     HIP_LAUNCH_CHECK();
     return 0;

@@ -262,6 +262,10 @@ class Engine:
         self.ewc = None          # EWC baseline (EWC.py): dict(F=, prev=, lam=) -> quadratic penalty added between backward and Adam
         self.timer = None        # optional SectionTimer
         self.prune_last = True   # final block: query/FFN path only for position T-1 (exact; see forward())
+        # float32-grade flash forward: the backward of the final LayerNorm runs inside the merge launch of the logit forward (the
+        # workgroup that forms a row of dRep also forms LN_f'(dRep)): k_ln_bwd and its kernel boundary leave the critical path
+        self.fuse_final_ln = True
+        self._lnf_done = None
         # single-GPU bf16-logits steps: apply Adam to the item table inside the table-gradient GEMM (the table gradient
         # is never written to memory); needs the complete gradient locally, so it is off whenever a grad_hook is set
         self.fuse_adam = True
@@ -563,6 +567,8 @@ class Engine:
         The final block computes only position T-1 of its query / FFN path (Engine.prune_last): the representation is
         x[:, -1, :] (ADER.py:85) and rows interact only through K/V, so the other T-1 rows of that block are dead work."""
         self._refresh_stream()
+        if save:
+            self._lnf_done = None          # (a fused final-LayerNorm backward belongs to the forward it followed)
         if self.seq_fused:
             if self._use_pack(seq):
                 return self._forward_packed(seq, training, rate, step, save)
@@ -828,6 +834,20 @@ class Engine:
             self._act = A
         return rep
 
+    def _lnf_desc(self, B):
+        """AderLnfBwd of the forward just saved (prune_last: xL / meanf / stdf are compact [B, ..]), or None when not fused."""
+        A = self._act
+        if not (self.fuse_final_ln and self.prune_last and self.lx3):
+            self._lnf_done = None
+            return None
+        H = self.H
+        dxl = self.buf("dx_L", (B, H))
+        fslab = self.buf("lnf_slab_rows", (B * 2 * H,))
+        c = _lib.AderLnfBwd()
+        c.x, c.mean, c.std, c.gamma, c.dx, c.slab = ptr(A["xL"]), ptr(A["meanf"]), ptr(A["stdf"]), self._pp["lnf_g"], ptr(dxl), ptr(fslab)
+        self._lnf_done = (dxl, fslab, B, c)
+        return ctypes.byref(c)
+
     # ---------------------------------------------------------------------------------------- loss rows
     def _rowinfo(self, B, pos, n_train, ex_pos, ex_trow, N, Np, w_train, w_ex, teacher, tag="ri_"):
         Bp = (B + 63) // 64 * 64
@@ -964,9 +984,10 @@ class Engine:
                     # (the operand images of the fused update are cut by the same launch as the operand planes)
                     img = (self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", Bp),), torch.uint8, zero=True)
                            if (defer and self.x3_update == "tab16" and not split_kd) else None)
-                    call("ader_lx3_fwd_img", ptr(rep), emb, self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(rep_lo),
+                    lnf = self._lnf_desc(B) if (Bb == B) else None      # (split_kd: the exemplar rows' dRep comes from other kernels)
+                    call("ader_lx3_fwd_img_lnf", ptr(rep), emb, self.item_num, Bb, Bp, H, N, ptr(lab), ptr(wrow), ptr(rep_bf), ptr(rep_lo),
                          ptr(pm), ptr(pl), ptr(pO), ptr(lse), ptr(off), ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep),
-                         ptr(img), st)
+                         ptr(img), lnf, st)
                     self._img_ready = img is not None
                     self._pending_loss = (rowloss, Bb) if late_loss else None
                 else:
@@ -1045,10 +1066,10 @@ class Engine:
             if self.lx3:
                 # (as in the vanilla step: the loss scalar feeds nothing in the backward pass -- summed beside the table update)
                 late_loss = bool(fused and self.dp_world == 1 and self.late_side_stream and self.seq_fused)
-                call("ader_lx3_fwd_kd", ptr(rep), self._pp["emb"], self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
+                call("ader_lx3_fwd_kd_lnf", ptr(rep), self._pp["emb"], self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
                      ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
                      ptr(trow), ptr(tlse2), ptr(rep_bf), ptr(rep_lo), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off),
-                     ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), st)
+                     ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), self._lnf_desc(B), st)
                 self._pending_loss = (rowloss, Bp) if late_loss else None
             else:
                 call("ader_lbf_fwd_kd", ptr(rep), ptr(self.shadow), self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
@@ -1097,7 +1118,12 @@ class Engine:
             dx = self.buf("dx_a", (rows, H), zero=True)
             dxn = self.buf("dx_b", (rows, H), zero=True)
         self._late_on = bool(defer and (self.dp_world == 1 or self._late_force) and self.seq_fused and self.late_side_stream)
-        if self.prune_last:
+        lnf_done, self._lnf_done = self._lnf_done, None
+        if self.prune_last and lnf_done is not None and lnf_done[2] == B:
+            # the merge launch of the logit forward has already written dx of the final LayerNorm and the per-row gamma / beta partials
+            dxl, fslab = lnf_done[0], lnf_done[1]
+            self._late_call("ader_reduce_slabs", ptr(fslab), 2 * H, B, H, 1, H, gp["lnf_g"], gp["lnf_b"])
+        elif self.prune_last:
             dxl = self.buf("dx_L", (B, H))        # gradient of the final block's output row T-1 (compact)
             if self._late_on:       # gamma / beta partials reduced later, beside the table update (their own slab buffer)
                 G = call("ader_ln_bwd_slabs", B)
