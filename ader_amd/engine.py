@@ -11,6 +11,7 @@ import collections
 import ctypes
 import math
 import os
+import time as _time
 
 import numpy as np
 import torch
@@ -153,6 +154,63 @@ def param_layout(item_num, T, H, L, align=64, table_rows_alloc=None):
             off = max(off, int(table_rows_alloc) * H)
         off = (off + align - 1) // align * align
     return layout, off
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, main):
+    """The stream the engine's second lane runs on (sparse lists under the block kernels, small launches under the table update),
+    shared by every engine of this process on (device, main).
+
+    Not simply torch.cuda.Stream(priority=-1): HIP multiplexes its streams over four hardware queues per priority, and on the
+    MI355X boxes ONE of the four high-priority queues answers a cross-stream dependency in ~180 us instead of ~33 us -- an engine
+    whose side stream landed on it stepped in 1.24 ms instead of 0.39 ms at the real-data shapes (every 4th stream of torch's
+    pool, stable within a process: profiles/r5_packed/side_stream_queues.txt; that is what the "not reproducible" 2x end-to-end
+    outliers of tools/e2e_breakdown.py were -- the 4th engine of a process).  A normal-priority stream that shares the MAIN
+    stream's hardware queue overlaps nothing (0.54 ms).  So: four consecutive high-priority pool streams (one per hardware queue)
+    are probed once -- a main -> side -> main ping-pong of 24 tiny launches for the dependency latency, and one small side launch
+    beside ~0.2 ms of main-stream work for the overlap -- and the best one that overlaps is kept."""
+    key = (torch.device(device).index or 0, main.cuda_stream)
+    if key in _SIDE_STREAMS:
+        return _SIDE_STREAMS[key]
+    dev = torch.device(device)
+    with torch.cuda.device(dev), torch.cuda.stream(main):
+        x = torch.zeros(1 << 12, device=dev)
+        y = torch.zeros(1 << 12, device=dev)
+        big = torch.zeros(1 << 24, device=dev)
+        ev_m, ev_s = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for pr in (-1, 0):
+            for _ in range(4):
+                s = torch.cuda.Stream(device=dev, priority=pr)
+                for rep in range(2):                              # (first pass: the runtime creates the hardware queue)
+                    torch.cuda.synchronize(dev)
+                    t0 = _time.perf_counter()
+                    for i in range(24 if rep else 4):
+                        x.add_(1.0)
+                        s.wait_stream(main)
+                        with torch.cuda.stream(s):
+                            y.add_(1.0)
+                        main.wait_stream(s)
+                    torch.cuda.synchronize(dev)
+                    lat = (_time.perf_counter() - t0) / 24
+                for i in range(6):
+                    big.add_(1.0)
+                ev_m.record(main)
+                with torch.cuda.stream(s):
+                    y.add_(1.0)
+                    ev_s.record(s)
+                torch.cuda.synchronize(dev)
+                overlaps = ev_s.elapsed_time(ev_m) > 0.02          # the side launch finished well before the main-stream work did
+                cand = (not overlaps, lat, s)
+                if best is None or cand[:2] < best[:2]:
+                    best = cand
+            if best is not None and not best[0]:
+                break                                              # a high-priority stream that overlaps: done
+        del big
+    _SIDE_STREAMS[key] = best[2]
+    return best[2]
 
 
 def _check(cond, msg):
@@ -1383,7 +1441,7 @@ class Engine:
             self._lists = self._sparse_lists(seq, lab, N)
             return
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+            self._side = side_stream(self.device, main)
         self._side.wait_stream(main)         # inputs ready; also orders reuse of last step's list memory after its reader
         with Engine._OnStream(self, self._side):
             self._lists = self._sparse_lists(seq, lab, N)
@@ -1429,7 +1487,7 @@ class Engine:
             # small launches enqueued first the update reached the queue 100 us after the backward chain had finished
             # (profiles/r5_packed/timeline_cfgY_update_late.txt)
             if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=self.device, priority=-1)
+                self._side = side_stream(self.device, main)
             self._side.wait_stream(main)
         with self._sec("logits_bwd_adam"):
             if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
@@ -1810,7 +1868,7 @@ class Engine:
         main = self._main
         if self._late or self._atb_q:      # ... and run on the side stream under the row exchange below (the CUs are idle there)
             if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=self.device, priority=-1)
+                self._side = side_stream(self.device, main)
             self._side.wait_stream(main)
             with Engine._OnStream(self, self._side):
                 self._flush_late()
