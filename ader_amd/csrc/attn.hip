@@ -422,7 +422,8 @@ int ader_attn_fwd(const float* Q, const float* K, const float* V, const float* q
                   float* out, float* P, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     if (T > TR || heads < 1 || H % heads != 0 || H / heads > 160) return -2;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnFwdLds);
         if (e != hipSuccess) return (int)e;
@@ -442,7 +443,8 @@ int ader_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
                   const float* qmask, float* dQ, float* dK, float* dV, int B, int T, int H, int heads, const AderDrop* drop, void* stream) {
     if (B <= 0) return 0;
     if (T > TR || heads < 1 || H % heads != 0 || H / heads > 160) return -2;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnBwdLds);
         if (e != hipSuccess) return (int)e;
@@ -473,7 +475,8 @@ int ader_attn_last_fwd(const float* Q_last, const float* K, const float* V, cons
     AttnLastArgs a;
     int rc = attn_last_args(a, B, T, H, heads, drop);
     if (rc) return rc;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_last_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLastLds);
         if (e != hipSuccess) return (int)e;

@@ -403,7 +403,8 @@ int ader_attn_x3_fwd(const float* Q, const float* K, const float* V, const float
     AttnX3Args a;
     int rc = x3_args(a, B, T, H, heads, drop);
     if (rc) return rc;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_x3_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
         if (e != hipSuccess) return (int)e;
@@ -422,7 +423,8 @@ int ader_attn_x3_bwd(const float* dO, const float* Q, const float* K, const floa
     AttnX3Args a;
     int rc = x3_args(a, B, T, H, heads, drop);
     if (rc) return rc;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_x3_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
         if (e != hipSuccess) return (int)e;

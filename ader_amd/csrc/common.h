@@ -10,6 +10,15 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Launch-side caches (hipFuncSetAttribute done, CU count, largest dynamic-LDS size granted) are kept PER DEVICE: a function attribute
+// belongs to the device that was current when it was set, and a process may drive engines on several devices.
+#define ADER_MAX_DEV 32
+static inline int ader_cur_dev() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ADER_MAX_DEV) d = 0;
+    return d;
+}
+
 // status bits written by kernels into the engine's status word
 #define ADER_ST_BAD_ID 1
 

@@ -143,7 +143,8 @@ static const size_t kGemmAtbLds = (size_t)(2 * TM * LDT) * sizeof(float);
 
 template <int EPI, bool TB>
 static int launch_rows(const GemmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_rows<EPI, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmRowsLds);
         if (e != hipSuccess) return (int)e;
@@ -191,7 +192,8 @@ int ader_gemm_atb_slabs(int M) {
 int ader_gemm_atb(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream) {
     if (M <= 0) return 0;
     if (H >= HP || H < 1) return -2;     // needs one spare row for the ones-column bias trick
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_atb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmAtbLds);
         if (e != hipSuccess) return (int)e;

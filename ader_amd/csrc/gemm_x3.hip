@@ -434,7 +434,8 @@ static const size_t kAtbX3Lds = (size_t)4 * TM * LDR * sizeof(bf16);
 
 template <int EPI>
 static int launch_x3(const GemmX3Args& g, hipStream_t st) {
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_x3<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmX3Lds);
         if (e != hipSuccess) return (int)e;
@@ -487,7 +488,8 @@ int ader_gemm_x3(const float* A, const void* wplanes, const float* bias, float* 
 int ader_gemm_atb_x3(const float* A, const float* G, float* slab, float* dW, float* db, int M, int H, void* stream) {
     if (M <= 0) return 0;
     if (H >= HP || H < 2 || (H & 1) || H > 2 * PFA * 5) return -2;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_atb_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAtbX3Lds);
         if (e != hipSuccess) return (int)e;

@@ -424,8 +424,10 @@ int ader_herding_select(const float* rep, const long* seg, const int* quota, con
     if (G <= 0) return 0;
     if (H != HR_H) return ader_herding_select_generic(rep, seg, quota, max_steps, G, n_total, H, D, chosen, sel, sel_cnt, steps_out, stream);
     hipStream_t st = (hipStream_t)stream;
-    static int cus = 0;
-    static bool attr = false;
+    static int cus_dev[ADER_MAX_DEV] = {};
+    int& cus = cus_dev[ader_cur_dev()];
+    static bool attr_dev[ADER_MAX_DEV] = {};
+    bool& attr = attr_dev[ader_cur_dev()];
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_herding_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHerdLds);
         if (e != hipSuccess) return (int)e;

@@ -468,7 +468,8 @@ int ader_logits_loss_fwd(const float* rep, const float* emb, int B, int Bp, int 
     LogitArgs a;
     int rc = fill_args(a, rep, emb, B, Bp, H, N, lab, ncol, wrow, trow, tlse, teacher, ldt);
     if (rc) return rc;
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     rc = set_lds(k_logits_tile<MODE_LSE>, kTileLds, f);
     if (rc) return rc;
     a.part = part; a.sub = ader_logits_sub(N);
@@ -489,7 +490,8 @@ int ader_logits_bwd_drep(const float* rep, const float* emb, int B, int Bp, int 
     LogitArgs a;
     int rc = fill_args(a, rep, emb, B, Bp, H, N, lab, ncol, wrow, trow, tlse, teacher, ldt);
     if (rc) return rc;
-    static bool f1 = false;
+    static bool f1_dev[ADER_MAX_DEV] = {};
+    bool& f1 = f1_dev[ader_cur_dev()];
     rc = set_lds(k_logits_bwd_drep, kBwdLds, f1);
     if (rc) return rc;
     a.lse = lse; a.slab = slab; a.ranges = ader_logits_ranges(N, Bp);
@@ -507,7 +509,8 @@ int ader_logits_bwd_demb(const float* rep, const float* emb, int B, int Bp, int 
     LogitArgs a;
     int rc = fill_args(a, rep, emb, B, Bp, H, N, lab, ncol, wrow, trow, tlse, teacher, ldt);
     if (rc) return rc;
-    static bool f2 = false;
+    static bool f2_dev[ADER_MAX_DEV] = {};
+    bool& f2 = f2_dev[ader_cur_dev()];
     rc = set_lds(k_logits_bwd_de, kBwdLds, f2);
     if (rc) return rc;
     a.lse = lse; a.demb1 = demb + H;
@@ -523,7 +526,8 @@ int ader_logits_store(const float* rep, const float* emb, int B, int Bp, int H, 
     LogitArgs a;
     int rc = fill_args(a, rep, emb, B, Bp, H, N, nullptr, ncol_all, nullptr, nullptr, nullptr, nullptr, 0);
     if (rc) return rc;
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     rc = set_lds(k_logits_tile<MODE_STORE>, kTileLds, f);
     if (rc) return rc;
     a.out = out; a.ldo = ldo;
@@ -540,7 +544,9 @@ int ader_rank_targets(const float* rep, const float* emb, int B, int Bp, int H, 
     LogitArgs a;
     int rc = fill_args(a, rep, emb, B, Bp, H, N, target, ncol, nullptr, nullptr, nullptr, nullptr, 0);
     if (rc) return rc;
-    static bool f1 = false, f2 = false;
+    static bool f1_dev[ADER_MAX_DEV] = {}, f2_dev[ADER_MAX_DEV] = {};
+    bool& f1 = f1_dev[ader_cur_dev()];
+    bool& f2 = f2_dev[ader_cur_dev()];
     rc = set_lds(k_logits_tile<MODE_RANK>, kTileLds, f1);
     if (rc) return rc;
     rc = set_lds(k_target_logit, kTgtLds, f2);

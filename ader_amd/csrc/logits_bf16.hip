@@ -911,7 +911,8 @@ int ader_lbf_fwd(const float* rep, const void* shadow, int item_num, int B, int 
                  void* stream) {
     if (B <= 0) return 0;
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2) return -2;
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lbf_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
         if (e != hipSuccess) return (int)e;
@@ -945,7 +946,8 @@ int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_tr
     if (n_train + n_ex <= 0) return 0;
     if (Bp % 128 != 0 || kd_row0 % 128 != 0 || n_train > kd_row0 || kd_row0 + n_ex > Bp || H > HP || (H & 1) || H < 2 || N > item_num ||
         Np > N || Np < 1) return -2;
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lbf_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
         if (e != hipSuccess) return (int)e;
@@ -999,7 +1001,8 @@ int ader_lbf_fwd_shard(const void* rep_bf, const void* shadow, int item_num, int
                        float* pm, float* pl, float* pO, float* part, void* stream) {
     if (Bp <= 0) return 0;
     if (Bp % 128 != 0 || H > HP || (H & 1) || H < 2 || N > item_num || item_begin < 0) return -2;
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lbf_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
         if (e != hipSuccess) return (int)e;
@@ -1047,7 +1050,8 @@ int ader_lx3_prep(const float* rep, void* rep_hi, void* rep_lo, int B, int Bp, i
 // Forward of the one-hot softmax CE over items 1..N at float32 grade (three bf16 MFMAs per product), streaming the fp32
 // table itself.  Same scratch and outputs as ader_lbf_fwd; rep_hi / rep_lo: Bp*168 bf16 each.
 static int lx3_attr() {
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lx3_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)((size_t)2 * 2 * FB * LDR * sizeof(bf16)));

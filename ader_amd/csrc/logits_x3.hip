@@ -849,7 +849,8 @@ bool lx3r_supports(const Lx3Args& x) {
     return x.H == 150 && x.Np >= F3_FB && (x.ldt & 3) == 0 && (((uintptr_t)x.teacher) & 15) == 0 && (long)(x.vrows + 5 * F3_FB) * x.H * 4 < (1l << 31);      // (block offsets are 32-bit; the stream runs 4 blocks ahead)
 }
 int lx3r_launch(const Lx3Args& x, void* stream) {
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lx3r, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3B_IMG_B);
         if (e != hipSuccess) return (int)e;
@@ -863,7 +864,8 @@ bool lx3f_supports(int H) { return (H & 1) == 0 && H >= 8 && H <= HP && ((H & 7)
 
 // x.ranges must be ader_lbf_ranges(x.N, x.Bp); Bp % 128 == 0
 int lx3g_launch(const Lx3Args& x, void* stream) {
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lx3g<150>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3B_IMG_B);
         if (e != hipSuccess) return (int)e;
@@ -878,7 +880,8 @@ int lx3g_launch(const Lx3Args& x, void* stream) {
 }
 
 int lx3p_launch(const Lx3Args& x, void* stream) {
-    static bool f = false;
+    static bool f_dev[ADER_MAX_DEV] = {};
+    bool& f = f_dev[ader_cur_dev()];
     if (!f) {
         hipError_t e = hipFuncSetAttribute((const void*)k_lx3p<150>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3B_IMG_B);
         if (e != hipSuccess) return (int)e;

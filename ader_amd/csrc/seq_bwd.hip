@@ -353,7 +353,8 @@ int ader_seq_bwd_ffn(const AderSeqBwdFfn* desc, void* stream) {
     const AderSeqBwdFfn& a = *desc;
     const int rc = check_dims(a.B, a.T, a.H);
     if (rc) return rc < 0 ? rc : 0;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_seq_bwd_ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSeqBwdLds);
         if (e != hipSuccess) return (int)e;
@@ -368,7 +369,8 @@ int ader_seq_bwd_qkv(const AderSeqBwdQkv* desc, void* stream) {
     const AderSeqBwdQkv& a = *desc;
     const int rc = check_dims(a.B, a.T, a.H);
     if (rc) return rc < 0 ? rc : 0;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_seq_bwd_qkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSeqBwdLds);
         if (e != hipSuccess) return (int)e;

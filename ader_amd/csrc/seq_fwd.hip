@@ -553,7 +553,8 @@ int ader_seq_fwd(const AderSeqFwd* desc, void* stream) {
     const AderSeqFwd& a = *desc;
     if (a.B <= 0) return 0;
     if (a.T < 1 || a.T > TR || a.H < 2 || a.H > 150 || (a.H & 1) || a.L < 1 || a.L > ADER_SEQ_MAXL) return -2;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_seq_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSeqFwdLds);
         if (e != hipSuccess) return (int)e;

@@ -923,7 +923,8 @@ int ader_seqp_bwd_ffn(const AderSeqBwdFfn* desc, const AderSeqPack* pack, int ma
     if (rc) return rc < 0 ? rc : 0;
     if (!pack) return -2;
     if (max_tiles <= 0 || max_tiles > a.B) max_tiles = a.B;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (int e = set_lds(k_seqp_bwd_ffn, kSeqpBwdLds, attr_set)) return e;
     hipLaunchKernelGGL(k_seqp_bwd_ffn, dim3(max_tiles), dim3(640), kSeqpBwdLds, (hipStream_t)stream, a, *pack);
     HIP_LAUNCH_CHECK();
@@ -936,7 +937,8 @@ int ader_seqp_bwd_qkv(const AderSeqBwdQkv* desc, const AderSeqPack* pack, int ma
     if (rc) return rc < 0 ? rc : 0;
     if (!pack) return -2;
     if (max_tiles <= 0 || max_tiles > a.B) max_tiles = a.B;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (int e = set_lds(k_seqp_bwd_qkv, kSeqpBwdLds, attr_set)) return e;
     hipLaunchKernelGGL(k_seqp_bwd_qkv, dim3(max_tiles), dim3(640), kSeqpBwdLds, (hipStream_t)stream, a, *pack);
     HIP_LAUNCH_CHECK();
@@ -950,7 +952,8 @@ int ader_attnp_bwd(const float* dO, const float* Q, const float* K, const float*
     if (rc) return rc < 0 ? rc : 0;
     if (!pack) return -2;
     if (max_tiles <= 0 || max_tiles > B) max_tiles = B;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (int e = set_lds(k_attnp_bwd, kAttnpBwdLds, attr_set)) return e;
     AttnPkArgs a;
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.kmask = kmask; a.qmask = qmask; a.PT = PT; a.dQ = dQ; a.dK = dK; a.dV = dV;

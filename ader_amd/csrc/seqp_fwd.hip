@@ -827,7 +827,8 @@ int ader_seqp_fwd(const AderSeqFwd* desc, const AderSeqPack* pack, int max_tiles
     if (a.B <= 0) return 0;
     if (a.T < 1 || a.T > TR || a.H < 2 || a.H > 150 || (a.H & 1) || a.L < 1 || a.L > ADER_SEQ_MAXL || a.B > 4096 || !pack) return -2;
     if (max_tiles <= 0 || max_tiles > a.B) max_tiles = a.B;
-    static bool attr_set = false;
+    static bool attr_set_dev[ADER_MAX_DEV] = {};
+    bool& attr_set = attr_set_dev[ader_cur_dev()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_seqp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSeqpFwdLds);
         if (e != hipSuccess) return (int)e;

@@ -503,7 +503,8 @@ static size_t tab_lds(int Bp, int H, bool x3, bool adam) {
 
 template <bool X3, bool ADAM, bool EXTRA, bool KD = false>
 static int tab_launch(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
-    static int lds_set = 0;
+    static int lds_set_dev[ADER_MAX_DEV] = {};
+    int& lds_set = lds_set_dev[ader_cur_dev()];
     if ((int)lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tab_upd<X3, ADAM, EXTRA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

@@ -405,7 +405,8 @@ static int tab_update_sh(const void* rep_bf, void* shadow, int item_num, int B, 
     if (Bp % 128 != 0 || B > Bp || H > HP || (H & 1) || H < 2 || N > item_num || !shadow) return -2;
     const bool kd = kd_row0 < Bp;
     if (kd && (kd_row0 % 128 != 0 || extra_grad || !teacher || !trow || !tlse2 || Np < 1 || Np > N)) return -2;
-    static int lds_set = 0;
+    static int lds_set_dev[ADER_MAX_DEV] = {};
+    int& lds_set = lds_set_dev[ader_cur_dev()];
     const size_t lds = bwd_lds(Bp, kd ? Bp - kd_row0 : 0);
     if ((int)lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tab16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

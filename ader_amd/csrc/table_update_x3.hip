@@ -909,7 +909,8 @@ static int g_x3_pipelined = 0;            // ader_x3_update_pipelined(): off by 
 
 template <bool EXTRA, bool KD>
 static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
-    static int lds_set = 0;
+    static int lds_set_dev[ADER_MAX_DEV] = {};
+    int& lds_set = lds_set_dev[ader_cur_dev()];
     if ((int)lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tab16x3<EXTRA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -920,7 +921,8 @@ static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, siz
 }
 template <bool EXTRA, bool KD>
 static int tab32x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
-    static int lds_set = 0;
+    static int lds_set_dev[ADER_MAX_DEV] = {};
+    int& lds_set = lds_set_dev[ader_cur_dev()];
     if ((int)lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tab32x3<EXTRA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

@@ -593,7 +593,8 @@ static size_t tabp_lds(int Bp) {
 // Launch the pipelined kernel over tiles [a.tile_off, a.tile_off + tiles) if the shape is one it is built for; returns 1 if it
 // was launched, 0 if the caller should use k_tab32x3 / k_tab16x3, < 0 / a hipError_t on failure.
 int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, int wg_per_cu, hipStream_t st) {
-    static int cus = 0;
+    static int cus_dev[ADER_MAX_DEV] = {};
+    int& cus = cus_dev[ader_cur_dev()];
     if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t p;
@@ -613,7 +614,8 @@ int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, int wg_per_cu, hip
     { static int ko = -1; if (ko < 0) { const char* e = getenv("ADER_TP_KO"); ko = e ? atoi(e) : 0; } a.ko = ko; }
 #endif
     const size_t lds = tabp_lds(a.Bp);
-    static int lds_set = 0;
+    static int lds_set_dev[ADER_MAX_DEV] = {};
+    int& lds_set = lds_set_dev[ader_cur_dev()];
     if ((int)lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tabp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

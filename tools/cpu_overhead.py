@@ -33,7 +33,7 @@ for K in (4, 8):
     print("K=%d  host enqueue %.3f ms/step   total %.3f ms/step" % (K, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3))
 import cProfile, pstats, io
 pr = cProfile.Profile(); pr.enable()
-for i in range(8):
+for i in range(200):
     eng.train_step(*batches[i % 4], N, 5e-4, rate=0.3)
 pr.disable(); torch.cuda.synchronize()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14); print(s.getvalue()[:3500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(34); print(s.getvalue()[:7000])

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 python3 bench.py --steps 40 --warmup 5 $EXTRA > $OUT/bench.json 2> $OUT/bench.err || true
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sections --no-companion --no-herding --sustained-steps 0 $EXTRA"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sections --no-companion --no-herding --no-real-shapes --sustained-steps 0 $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $B --steps 20 --warmup 3 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 6 --warmup 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $B --steps 6 --warmup 2 > $OUT/pmc_write.log 2>&1
