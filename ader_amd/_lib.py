@@ -72,7 +72,7 @@ _SIGS = {
     "ader_lx3_fwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lx3_fwd_img": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_lx3_fwd_img_lnf": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "ader_lx3_fwd_kd_lnf": [P, P, I, I, I, I, I, I, I, I, P, P, P, L, P, F, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "ader_lx3_fwd_kd_lnf": [P, P, I, I, I, I, I, I, I, I, P, P, P, L, P, F, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_tab_grad": [P, P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_tab_grad_kd": [P, P, P, I, I, I, I, I, I, P, P, P, P, L, P, P, P, P],
     "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],

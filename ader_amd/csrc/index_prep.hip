@@ -74,39 +74,49 @@ __global__ __launch_bounds__(256) void k_ip_scan(int* __restrict__ cnt, int nkey
 
 __global__ __launch_bounds__(256) void k_ip_scatter(const int* __restrict__ ids0, int n0, const int* __restrict__ ids1, int n1, int gran,
                                                     int nkeys, int* __restrict__ cnt, const int* __restrict__ first,
-                                                    int* __restrict__ tmp) {
+                                                    int* __restrict__ tmp, int* __restrict__ tmp_id) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the id travels with the position: the rank pass then reads two sequential arrays instead of one array and a dependent random
+    //  load per comparison -- a hot item's bucket holds hundreds of entries and every one of them walks the whole bucket)
     if (i < n0) {
-        const int k = key_of(ids0[i], gran, nkeys);
-        if (k) tmp[first[k] + atomicAdd(cnt + k, 1)] = i;
+        const int id = ids0[i], k = key_of(id, gran, nkeys);
+        if (k) { const int s = first[k] + atomicAdd(cnt + k, 1); tmp[s] = i; tmp_id[s] = id; }
     } else if (i < n0 + n1) {
-        const int k = key_of(ids1[i - n0], gran, nkeys);
-        if (k) tmp[n0 + first[nkeys + 1 + k] + atomicAdd(cnt + nkeys + k, 1)] = i - n0;
+        const int id = ids1[i - n0], k = key_of(id, gran, nkeys);
+        if (k) { const int s = n0 + first[nkeys + 1 + k] + atomicAdd(cnt + nkeys + k, 1); tmp[s] = i - n0; tmp_id[s] = id; }
     }
 }
 
 __global__ __launch_bounds__(256) void k_ip_rank(const int* __restrict__ ids0, int n0, const int* __restrict__ ids1, int n1, int gran,
                                                  int nkeys, const int* __restrict__ first, const int* __restrict__ tmp,
-                                                 int* __restrict__ sid0, int* __restrict__ srow0, int* __restrict__ sid1,
+                                                 const int* __restrict__ tmp_id, int* __restrict__ sid0, int* __restrict__ srow0, int* __restrict__ sid1,
                                                  int* __restrict__ srow1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n0 + n1) return;
     const int lst = i >= n0;
-    const int* ids = lst ? ids1 : ids0;
     const int* tp = tmp + (lst ? n0 : 0);
+    const int* ti = tmp_id + (lst ? n0 : 0);
     const int* f = first + (lst ? nkeys + 1 : 0);
     const int s = lst ? i - n0 : i;
     if (s >= f[nkeys]) return;                        // only the real (non-padding) entries were scattered: slots [0, total)
     const int my = tp[s];
-    const int id = ids[my];
+    const int id = ti[s];
     const int k = key_of(id, gran, nkeys);
     const int k0 = f[k], k1 = f[k + 1];
     // order inside a bucket: by id, then by position (a table row's entries are consecutive and in position order: the update
     // kernels sum a row's run in a register).  Quadratic in the bucket's size: buckets hold a handful of entries, a hot item's
     // a few hundred.
     int rank = 0;
-    for (int u = k0; u < k1; ++u) {
-        const int pu = tp[u], iu = ids[pu];
+    int u = k0;
+    for (; u + 4 <= k1; u += 4) {
+        int pu[4], iu[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pu[j] = tp[u + j]; iu[j] = ti[u + j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rank += (iu[j] < id) || (iu[j] == id && pu[j] < my);
+    }
+    for (; u < k1; ++u) {
+        const int pu = tp[u], iu = ti[u];
         rank += (iu < id) || (iu == id && pu < my);
     }
     (lst ? sid1 : sid0)[k0 + rank] = id;
@@ -115,9 +125,9 @@ __global__ __launch_bounds__(256) void k_ip_rank(const int* __restrict__ ids0, i
 
 extern "C" {
 
-// scratch ints needed by ader_sparse_lists: counters [2][nkeys], first [2][nkeys + 1], tmp [n_sp + n_tg]
+// scratch ints needed by ader_sparse_lists: counters [2][nkeys], first [2][nkeys + 1], tmp [n_sp + n_tg], tmp_id [n_sp + n_tg]
 static int ip_nkeys(int N) { return (N + ader_fused_bucket_gran() - 1) / ader_fused_bucket_gran() + 1; }
-int ader_sparse_lists_scratch_n(int n_sp, int n_tg, int N) { return 2 * ip_nkeys(N) + 2 * (ip_nkeys(N) + 1) + n_sp + n_tg; }
+int ader_sparse_lists_scratch_n(int n_sp, int n_tg, int N) { return 2 * ip_nkeys(N) + 2 * (ip_nkeys(N) + 1) + 2 * (n_sp + n_tg); }
 // number of bucket offsets per list: ceil(N / gran) + 1
 int ader_sparse_lists_starts(int N) { return ip_nkeys(N); }
 
@@ -134,15 +144,16 @@ int ader_sparse_lists(const int* seq, int n_sp, const int* lab, int n_tg, int N,
     int* cnt = scratch;
     int* first = cnt + 2 * nkeys;
     int* tmp = first + 2 * (nkeys + 1);
+    int* tmp_id = tmp + n;
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)2 * nkeys * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     const int g = (n + 255) / 256;
     if (g > 0) hipLaunchKernelGGL(k_ip_count, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, cnt);
     hipLaunchKernelGGL(k_ip_scan, dim3(2), dim3(256), 0, st, cnt, nkeys, first, sp_start, tg_start);
     if (g > 0) {
-        hipLaunchKernelGGL(k_ip_scatter, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, cnt, (const int*)first, tmp);
+        hipLaunchKernelGGL(k_ip_scatter, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, cnt, (const int*)first, tmp, tmp_id);
         hipLaunchKernelGGL(k_ip_rank, dim3(g), dim3(256), 0, st, seq, n_sp, lab, n_tg, gran, nkeys, (const int*)first, (const int*)tmp,
-                           sp_ids, sp_rows, tg_ids, tg_rows);
+                           (const int*)tmp_id, sp_ids, sp_rows, tg_ids, tg_rows);
     }
     HIP_LAUNCH_CHECK();
     return 0;

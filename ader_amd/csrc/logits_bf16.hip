@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_lbf_prep_kd(const float* __restrict__ r
                                                      int kd_row0, int Bp, int H, const int* __restrict__ pos,
                                                      const int* __restrict__ ex_trow, const float* __restrict__ tlse_all, float w_train,
                                                      float w_ex, int* __restrict__ lab, float* __restrict__ wrow, int* __restrict__ trow,
-                                                     float* __restrict__ tlse2) {
+                                                     float* __restrict__ tlse2, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp * LDR) return;
     const int b = i / LDR, c = i - b * LDR;
@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256) void k_lbf_prep_kd(const float* __restrict__ r
         const float x = (src >= 0 && c < H) ? rep[(size_t)src * H + c] : 0.0f;
         const bf16 h = (bf16)x;
         rep_bf[i] = h;
-        if (rep_lo) rep_lo[i] = (bf16)(x - (float)h);          // x3 mode: low-order operand rows
+        if (rep_lo) {                                          // x3 mode: low-order operand rows
+            const bf16 l = (bf16)(x - (float)h);
+            rep_lo[i] = l;
+            if (img && c < HP) {                               // ... and the fused update's operand images (as k_lx3_prep)
+                char* p = img + (size_t)(b >> 5) * X3_IMG_B + x3_kc_off(c >> 3) + 16 * (b & 31) + 2 * (c & 7);
+                *(bf16*)p = h;
+                *(bf16*)(p + X3_PLANE_B) = l;
+            }
+        }
     }
     if (c == 0) {
         int l = 0, tr = -1; float w = 0.0f, tl = 0.0f;
@@ -963,7 +971,7 @@ int ader_lbf_fwd_kd(const float* rep, const void* shadow, int item_num, int n_tr
     a.kd_row0 = kd_row0; a.Np = Np; a.n_train = n_train; a.n_ex = n_ex; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
     a.pO2 = pO2; a.ranges2 = ader_lbf_readout_ranges(N, Bp, kd_row0);
     hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_bf, (bf16*)nullptr, n_train, n_ex,
-                       kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
+                       kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2, (char*)nullptr);
     hipLaunchKernelGGL(k_lbf_fwd, dim3(a.ranges * nsm + a.ranges2 * nkd), dim3(256), kFwdLds, st, a);
     hipLaunchKernelGGL(k_lbf_combine<false>, dim3(Bp), dim3(640), 0, st, a, (const int*)lab, (const float*)wrow, lse, off, rowloss, drep,
                        (const float*)nullptr, (const float*)nullptr, AderLnfBwd{});
@@ -1137,16 +1145,16 @@ int ader_lx3_fwd_kd(const float* rep, const float* emb, int item_num, int n_trai
                     float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo, float* pm, float* pl,
                     float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* stream) {
     return ader_lx3_fwd_kd_lnf(rep, emb, item_num, n_train, n_ex, kd_row0, Bp, H, N, Np, pos, ex_trow, teacher, ldt, tlse_all, w_train, w_ex,
-                               lab, wrow, trow, tlse2, rep_hi, rep_lo, pm, pl, pO, pO2, lse, off, rowloss, loss, drep, nullptr, stream);
+                               lab, wrow, trow, tlse2, rep_hi, rep_lo, pm, pl, pO, pO2, lse, off, rowloss, loss, drep, nullptr, nullptr, stream);
 }
 int ader_lx3_fwd_kd_lnf(const float* rep, const float* emb, int item_num, int n_train, int n_ex, int kd_row0, int Bp, int H, int N,
                         int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all, float w_train,
                         float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo, float* pm, float* pl,
-                        float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, const AderLnfBwd* lnf,
-                        void* stream) {
+                        float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep, void* rep_img,
+                        const AderLnfBwd* lnf, void* stream) {
     if (n_train + n_ex <= 0) return 0;
     if (Bp % 128 != 0 || kd_row0 % 128 != 0 || n_train > kd_row0 || kd_row0 + n_ex > Bp || H > HP || (H & 1) || H < 2 || N > item_num ||
-        Np > N || Np < 1 || ((uintptr_t)emb & 7)) return -2;
+        Np > N || Np < 1 || ((uintptr_t)emb & 7) || ((uintptr_t)rep_img & 15)) return -2;
     const size_t lds = (size_t)2 * 2 * FB * LDR * sizeof(bf16);
     int rc = lx3_attr();
     if (rc) return rc;
@@ -1163,7 +1171,7 @@ int ader_lx3_fwd_kd_lnf(const float* rep, const float* emb, int item_num, int n_
     a.kd_row0 = kd_row0; a.Np = Np; a.n_train = n_train; a.n_ex = n_ex; a.teacher = teacher; a.ldt = ldt; a.trow = trow; a.tlse2 = tlse2;
     a.pO2 = pO2; a.ranges2 = x.ranges2;
     hipLaunchKernelGGL(k_lbf_prep_kd, dim3((Bp * LDR + 255) / 256), dim3(256), 0, st, rep, (bf16*)rep_hi, (bf16*)rep_lo, n_train, n_ex,
-                       kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2);
+                       kd_row0, Bp, H, pos, ex_trow, tlse_all, w_train, w_ex, lab, wrow, trow, tlse2, (char*)rep_img);
     if (nk) { rc = lx3gh_launch(x, stream); if (rc) return rc; }
     else hipLaunchKernelGGL((k_lx3_fwd<2, 2>), dim3(x.ranges * (Bp / 128)), dim3(256), lds, st, x);
     if (lx3r_supports(x)) { rc = lx3r_launch(x, stream); if (rc) return rc; }

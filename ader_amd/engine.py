@@ -1124,10 +1124,14 @@ class Engine:
             if self.lx3:
                 # (as in the vanilla step: the loss scalar feeds nothing in the backward pass -- summed beside the table update)
                 late_loss = bool(fused and self.dp_world == 1 and self.late_side_stream and self.seq_fused)
+                # (... and the operand images of the fused update are cut by the launch that cuts the operand planes)
+                img = (self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", Bp),), torch.uint8, zero=True)
+                       if (fused and self.x3_update == "tab16") else None)
                 call("ader_lx3_fwd_kd_lnf", ptr(rep), self._pp["emb"], self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
                      ptr(ex_trow), ptr(teacher), teacher.stride(0), ptr(tlse_all), float(w_train), float(w_ex), ptr(lab), ptr(wrow),
                      ptr(trow), ptr(tlse2), ptr(rep_bf), ptr(rep_lo), ptr(pm), ptr(pl), ptr(pO), ptr(pO2), ptr(lse), ptr(off),
-                     ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), self._lnf_desc(B), st)
+                     ptr(rowloss), None if late_loss else ptr(self.loss), ptr(drep), ptr(img), self._lnf_desc(B), st)
+                self._img_ready = img is not None
                 self._pending_loss = (rowloss, Bp) if late_loss else None
             else:
                 call("ader_lbf_fwd_kd", ptr(rep), ptr(self.shadow), self.item_num, n_train, n_ex, Bt, Bp, H, N, Np, ptr(pos),
@@ -1492,7 +1496,7 @@ class Engine:
         with self._sec("logits_bwd_adam"):
             if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
                 img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", D["Bp"]),), torch.uint8, zero=True)
-                if not (self._img_ready and not D.get("kd")):
+                if not self._img_ready:
                     call("ader_x3_rep_image", ptr(D["rep_bf"]), ptr(D["rep_lo"]), D["Bp"], ptr(img), st)
                 self._img_ready = False
             if self.lx3 and D.get("kd"):

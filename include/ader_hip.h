@@ -314,7 +314,8 @@ int ader_lx3_fwd(const float* rep, const float* emb, int item_num, int B, int Bp
  * row of dRep also forms dx = LN_f'(dRep) for it (bit-equal to ader_ln_bwd) and the row's gamma / beta partials.  x [B,H] the input of
  * the final LayerNorm (compact rows, as rep), mean / std [B] its statistics, gamma [H]; dx [B,H] out; slab [B][2][H] out (reduce with
  * ader_reduce_slabs(slab, 2 H, B, H, 1, H, dgamma, dbeta)).  lnf == NULL: exactly ader_lx3_fwd_img / ader_lx3_fwd_kd (loss may be NULL
- * in both: ader_lbf_sum(rowloss, ...) later). */
+ * in both: ader_lbf_sum(rowloss, ...) later).  rep_img of the distilled form: as in ader_lx3_fwd_img -- the operand images of
+ * ader_tab_update_x3_kd over the padded row layout, cut by the launch that cuts the planes (NULL: ader_x3_rep_image later). */
 typedef struct { const float *x, *mean, *std, *gamma; float *dx, *slab; } AderLnfBwd;
 int ader_lx3_fwd_img_lnf(const float* rep, const float* emb, int item_num, int B, int Bp, int H, int N, const int* lab,
                          const float* wrow, void* rep_hi, void* rep_lo, float* pm, float* pl, float* pO, float* lse, float* off,
@@ -323,7 +324,7 @@ int ader_lx3_fwd_kd_lnf(const float* rep, const float* emb, int item_num, int n_
                         int Np, const int* pos, const int* ex_trow, const float* teacher, long ldt, const float* tlse_all,
                         float w_train, float w_ex, int* lab, float* wrow, int* trow, float* tlse2, void* rep_hi, void* rep_lo,
                         float* pm, float* pl, float* pO, float* pO2, float* lse, float* off, float* rowloss, float* loss, float* drep,
-                        const AderLnfBwd* lnf, void* stream);
+                        void* rep_img, const AderLnfBwd* lnf, void* stream);
 /* loss = sum of rowloss[0..n) in a fixed order: the last launch of ader_lx3_fwd when that was given loss = NULL (reference
  * ADER.py:93: reduce_mean of the per-row cross entropies; the weights 1/B are already in rowloss). */
 int ader_lbf_sum(const float* rowloss, int n, float* loss, void* stream);
