@@ -312,6 +312,8 @@ class Engine:
         self._grad_hi = 0
         self._ws = {}
         self._ws_store = {}
+        self._ws_gen, self._dcache, self._dcache_gen = 0, {}, -1
+        self.cache_descriptors = True      # packed session kernels: descriptors of a step shape are built once (host time, see _dc)
         self.grad_hook = None    # called between backward and Adam (data-parallel gradient exchange)
         # data-parallel dense path: called right after the logits backward has written the table gradient's dense term (99.8 % of
         # the gradient bytes) so that its all-reduce runs UNDER the blocks backward; returns the pending collectives
@@ -478,6 +480,7 @@ class Engine:
                                    "the main stream, unordered with the side-stream kernels" % name)
             t = (torch.zeros if zero else torch.empty)(key[0], dtype=dtype, device=self.device)
             per[key] = t
+            self._ws_gen += 1          # (cached launch descriptors hold raw pointers of workspace tensors: any allocation or eviction retires them)
             while len(per) > 4:
                 per.popitem(last=False)
         else:
@@ -550,6 +553,26 @@ class Engine:
         return _Drop(self.seed, step, site, rate, training, per_row, self.row0, self.split_rows, self.row0_ex)
 
     _ND = (None,)
+
+    def _dc(self, key):
+        """Descriptor cache of the packed session path: the ctypes structs, argument tuples and saved-activation dicts of a step
+        shape are built once and reused -- per step only the batch pointer and the dropout keys change (the host spent ~90 us
+        per step rebuilding them: ~90 workspace lookups, ~170 pointer conversions).  Every entry is retired as soon as the
+        workspace allocates or evicts anything (Engine.buf bumps _ws_gen), so a raw pointer never outlives its tensor."""
+        if self._dcache_gen != self._ws_gen:
+            self._dcache, self._dcache_gen = {}, self._ws_gen
+        return self._dcache.get(key)
+
+    def _dc_put(self, key, val):
+        if self._dcache_gen == self._ws_gen:      # (building the entry may itself have allocated: then it is not kept)
+            self._dcache[key] = val
+        return val
+
+    def _rekey(self, drops, step):
+        """New step, same shape: the persistent dropout descriptors of a cached entry take the step's keys in place."""
+        for dr, site in drops:
+            if dr.c.thr:
+                dr.c.key = dropout_key(self.seed, step, site)
 
     def _gemm(self, A, wname, bname, C, aux, seq, M, epi, trans=0, drop=None, rmap=(1, 0)):
         d = drop.args() if drop is not None else self._ND
@@ -741,6 +764,7 @@ class Engine:
             da = self._drop(step, site_attn(l), rate, training, self.heads * T * T)
             d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
             d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
+            drops += [(da, site_attn(l)), (d1, site_ffn1(l)), (d2, site_ffn2(l))]
             M, sfx = (B, "L") if pruned else (rows, "")
             kmask = self.buf(n("km"), (rows,), zero=True)
             K, Vv = self.buf(n("K"), (rows, H), zero=True), self.buf(n("V"), (rows, H), zero=True)
@@ -810,12 +834,13 @@ class Engine:
                                                                               ptr(info), ptr(srow0), ptr(slen))
         split = -1 if self.split_rows is None else int(self.split_rows)
         w1_min, w1_max, target = self.pack_window
-        call("ader_seq_pack_plan", ptr(seq), B, T, int(self.row0), split, int(self.row0_ex), w1_min, w1_max, target, ctypes.byref(c),
-             self._stream())
+        ref = ctypes.byref(c)
+        plan_args = (B, T, int(self.row0), split, int(self.row0_ex), w1_min, w1_max, target, ref)
+        call("ader_seq_pack_plan", ptr(seq), *plan_args, self._stream())
         d = self.pack_density if self.pack_density is not None else 0.15
         est = int(min(n, max(64, 1.25 * d * B * T + 64)))          # rows expected to exist: how the weight-gradient workgroups are shared out
-        return dict(c=c, ref=ctypes.byref(c), hdr=hdr, trows=trows, ids=ids, lpos=lpos, gpos=gpos, info=info, srow0=srow0, slen=slen,
-                    B=B, rows=n, max_tiles=B, est=est)
+        return dict(c=c, ref=ref, hdr=hdr, trows=trows, ids=ids, lpos=lpos, gpos=gpos, info=info, srow0=srow0, slen=slen,
+                    B=B, rows=n, max_tiles=B, est=est, plan_args=plan_args)
 
     def unpack_rows(self, t, pack=None, pruned=False):
         """Tile-ordered activation [B*64, ...] of the last packed forward -> the session-indexed [B*T, ...] layout of the unpacked
@@ -839,6 +864,26 @@ class Engine:
         path, the tensors of the K / V side and of unpruned blocks in tile order ([B*64, ..], see include/ader_hip.h)."""
         B, T, H, L = seq.shape[0], self.T, self.H, self.L
         tag = "pt" if save else "pe"
+        ck = ("fwdp", tag, B, bool(training), float(rate), self.seed, self.row0, self.split_rows, self.row0_ex, self.pack_window,
+              self.pack_density, self.prune_last)
+        ent = self._dc(ck) if self.cache_descriptors else None
+        if ent is not None:
+            # same step shape as before: only the batch pointer and the dropout keys are new
+            d, A, pk, drops, plan_args = ent
+            self._rekey(drops, step)
+            sp = ptr(seq)
+            d.seq = sp
+            d.d_emb = A["d_emb"].c
+            for l in range(L):
+                k, S = d.blk[l], A[l]
+                k.d_attn, k.d_ffn1, k.d_ffn2 = S["da"].c, S["d1"].c, S["d2"].c
+            A["seq"], A["step"] = seq, step
+            st = self._stream()
+            call("ader_seq_pack_plan", sp, *plan_args, st)
+            call("ader_seqp_fwd", ctypes.byref(d), pk["ref"], pk["max_tiles"], st)
+            if save:
+                self._act = A
+            return A["rep"]
         pk = self._pack_plan(seq, tag)
         rows = pk["rows"]
         A = {"B": B, "seq": seq, "rate": rate, "training": training, "step": step, "pack": pk}
@@ -847,6 +892,7 @@ class Engine:
         d = _lib.AderSeqFwd()
         d0 = self._drop(step, SITE_EMB, rate, training, per_row)
         A["d_emb"] = d0
+        drops = [(d0, SITE_EMB)]
         x = self.buf(tag + "x0", (rows, H), zero=True)
         rep = self.buf(tag + "rep", (B, H))
         meanf, stdf = self.buf(tag + "mf", (B,)), self.buf(tag + "sf", (B,))
@@ -890,6 +936,8 @@ class Engine:
         A.update(xL=x, rep=rep, meanf=meanf, stdf=stdf)
         if save:
             self._act = A
+        if self.cache_descriptors:
+            self._dc_put(ck, (d, A, pk, drops, pk["plan_args"]))
         return rep
 
     def _lnf_desc(self, B):
@@ -1355,6 +1403,29 @@ class Engine:
         pruned = 1 if S["pruned"] else 0
         M = B if pruned else rows
         mpk = None if pruned else pk           # the compact tensors of a pruned block are plain [B, H]
+        # (cached only on the default training path: small launches queued for the side stream, weight gradients batched)
+        cacheable = bool(self.cache_descriptors and self._late_on and self.gemm_x3 and self.atb_batch)
+        ck = ("bwdp", l, B, ptr(dxo), ptr(dxn), bool(emb_bwd))
+        ent = self._dc(ck) if cacheable else None
+        if ent is not None and ent[0] is S and ent[1] is pk and ent[2] is d_emb:
+            # same saved-activation dict (a cached forward's): the descriptors stand, the dropout keys are this step's
+            _, _, _, f, q, attn_name, attn_args, late2, late1, atbs2, atbs1 = ent
+            f.d_ffn1, f.d_ffn2 = S["d1"].c, S["d2"].c
+            q.d_emb = d_emb.c
+            call("ader_seqp_bwd_ffn", ctypes.byref(f), pk["ref"], mt, st)
+            self._late.append(late2)
+            for it in atbs2:
+                self._atb_q.append(it)
+                if len(self._atb_q) == 16:
+                    self._atb_flush()
+            call(attn_name, *attn_args, st)
+            call("ader_seqp_bwd_qkv", ctypes.byref(q), pk["ref"], mt, st)
+            self._late.append(late1)
+            for it in atbs1:
+                self._atb_q.append(it)
+                if len(self._atb_q) == 16:
+                    self._atb_flush()
+            return
         wp = lambda w: self.wbf.data_ptr() + self._widx[p + w] * self._wplane     # noqa: E731
         sfx = "L" if pruned else ""
         dh2, da_ = self.buf("pbw_dh2%d%s" % (l, sfx), (M, H), zero=True), self.buf("pbw_da%d%s" % (l, sfx), (M, H), zero=True)
@@ -1372,12 +1443,10 @@ class Engine:
         wslab = self._ws["w_slab"]
         self._atb(S["h1d"], dh2, p + "w2", p + "b2", wslab, M, mpk)
         self._atb(S["y"], da_, p + "w1", p + "b1", wslab, M, mpk)
-        if pruned:
-            call("ader_attnp_last_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]),
-                 ptr(S["qmask"]), ptr(dQ), ptr(dK), ptr(dV), B, T, H, *S["da"].args(), pk["ref"], st)
-        else:
-            call("ader_attnp_bwd", ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]),
-                 ptr(dQ), ptr(dK), ptr(dV), B, T, H, *S["da"].args(), pk["ref"], mt, st)
+        attn_args = (ptr(dx1), ptr(S["Q"]), ptr(S["K"]), ptr(S["V"]), ptr(S["P"]), ptr(S["kmask"]), ptr(S["qmask"]), ptr(dQ), ptr(dK),
+                     ptr(dV), B, T, H, *S["da"].args(), pk["ref"]) + (() if pruned else (mt,))
+        attn_name = "ader_attnp_last_bwd" if pruned else "ader_attnp_bwd"
+        call(attn_name, *attn_args, st)
         q = _lib.AderSeqBwdQkv()
         q.seq, q.dQ, q.dx1, q.dK, q.dV, q.x = None, ptr(dQ), ptr(dx1), ptr(dK), ptr(dV), ptr(S["x"])
         q.mean1, q.std1, q.ln1_g = ptr(S["mean1"]), ptr(S["std1"]), pp[p + "ln1_g"]
@@ -1390,6 +1459,13 @@ class Engine:
         self._atb(S["q_in"], dQ, p + "wq", p + "bq", wslab, M, mpk)
         self._atb(S["x"], dK, p + "wk", p + "bk", wslab, rows, pk)
         self._atb(S["x"], dV, p + "wv", p + "bv", wslab, rows, pk)
+        if cacheable:
+            late2 = ("ader_reduce_slabs", (ptr(slab2), 2 * H, mt, H, 1, H, gp[p + "ln2_g"], gp[p + "ln2_b"]))
+            late1 = ("ader_reduce_slabs", (ptr(slab1), 2 * H, mt, H, 1, H, gp[p + "ln1_g"], gp[p + "ln1_b"]))
+            atbs2 = [(S["h1d"], dh2, gp[p + "w2"], gp[p + "b2"], M, mpk), (S["y"], da_, gp[p + "w1"], gp[p + "b1"], M, mpk)]
+            atbs1 = [(S["q_in"], dQ, gp[p + "wq"], gp[p + "bq"], M, mpk), (S["x"], dK, gp[p + "wk"], gp[p + "bk"], rows, pk),
+                     (S["x"], dV, gp[p + "wv"], gp[p + "bv"], rows, pk)]
+            self._dc_put(ck, (S, pk, d_emb, f, q, attn_name, attn_args, late2, late1, atbs2, atbs1))
 
     def _lr_t(self, lr):
         return float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))

@@ -239,6 +239,43 @@ def test_packed_step_is_bitwise_reproducible():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_cached_descriptors_change_nothing():
+    """Engine.cache_descriptors (the descriptors of a step shape built once, dropout keys and batch pointer refreshed per step)
+    against descriptors rebuilt every step: bitwise the same parameters after ten steps that alternate between two batch shapes,
+    distilled and plain steps, with an evaluation forward in between and dropout on; and the cache was actually used."""
+    item_num, T, H, L, N, Np = 700, 50, 150, 2, 650, 600
+    teacher = (torch.randn(30, Np, generator=torch.Generator().manual_seed(2)) * 2).cuda()
+    outs, losses = [], []
+    for cached in (True, False):
+        e = _engine(item_num, T, H, L, 1, seed=3, logits_dtype="x3")
+        e.pack_sessions, e.cache_descriptors = True, cached
+        rs = np.random.RandomState(11)
+        ls = []
+        for step in range(10):
+            B = (160, 96)[step % 2]
+            seq = _law(rs, B, T, N, "geom" if step % 3 else "mixed")
+            if step % 4 == 3:
+                pos = rs.randint(1, N + 1, size=B).astype(np.int32)
+                e.train_step(e._dev_i32(seq), pos, N, 1e-3, rate=0.3)
+            else:
+                pos = rs.randint(1, N + 1, size=B - 30).astype(np.int32)
+                e.train_step(e._dev_i32(seq), pos, N, 1e-3, rate=0.3, teacher=teacher, ex_trow=np.arange(30, dtype=np.int32),
+                             lambda_=0.7)
+            ls.append(float(e.loss))
+            if step == 4:
+                e.encode(_law(rs, 64, T, N, "geom"))
+        torch.cuda.synchronize()
+        if cached:
+            assert any(k[0] == "fwdp" for k in e._dcache) and any(k[0] == "bwdp" for k in e._dcache), list(e._dcache)
+        else:
+            assert not e._dcache
+        outs.append(e.theta.clone())
+        losses.append(ls)
+        e.check_status()
+    assert losses[0] == losses[1]
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_auto_packing_follows_the_batch_density():
     e = _engine(300, 50, 150, 2, 1)
     assert e.pack_sessions == "auto"
