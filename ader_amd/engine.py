@@ -764,7 +764,6 @@ class Engine:
             da = self._drop(step, site_attn(l), rate, training, self.heads * T * T)
             d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
             d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
-            drops += [(da, site_attn(l)), (d1, site_ffn1(l)), (d2, site_ffn2(l))]
             M, sfx = (B, "L") if pruned else (rows, "")
             kmask = self.buf(n("km"), (rows,), zero=True)
             K, Vv = self.buf(n("K"), (rows, H), zero=True), self.buf(n("V"), (rows, H), zero=True)
@@ -909,6 +908,7 @@ class Engine:
             da = self._drop(step, site_attn(l), rate, training, self.heads * T * T)
             d1 = self._drop(step, site_ffn1(l), rate, training, per_row)
             d2 = self._drop(step, site_ffn2(l), rate, training, per_row)
+            drops += [(da, site_attn(l)), (d1, site_ffn1(l)), (d2, site_ffn2(l))]
             M, sfx = (B, "L") if pruned else (rows, "")
             kmask = self.buf(n("km"), (rows,), zero=True)
             K, Vv = self.buf(n("K"), (rows, H), zero=True), self.buf(n("V"), (rows, H), zero=True)

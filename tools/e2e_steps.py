@@ -1,0 +1,44 @@
+"""Step and epoch counts of a continual-learning run beside its wall time (dev tool): python tools/e2e_steps.py name:flag=value,... ..."""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ader_amd import main as M
+from ader_amd import model as MD
+from ader_amd import data as D
+
+cnt = {"steps": 0, "evals": 0}
+_ts = MD.Ader.train_step
+
+
+def ts(self, *a, **k):
+    cnt["steps"] += 1
+    return _ts(self, *a, **k)
+
+
+MD.Ader.train_step = ts
+_ev = D.Evaluator.evaluate
+
+
+def ev(self, *a, **k):
+    cnt["evals"] += 1
+    return _ev(self, *a, **k)
+
+
+D.Evaluator.evaluate = ev
+M.Evaluator = D.Evaluator
+for spec in sys.argv[1:]:
+    name, _, fl = spec.partition(":")
+    argv = []
+    for f in filter(None, fl.split(",")):
+        k, _, v = f.partition("=")
+        argv += ["--" + k, v]
+    with tempfile.TemporaryDirectory() as d:
+        cnt["steps"] = cnt["evals"] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        args = M.build_parser().parse_args(argv + ["--results_root", d, "--save_dir", name])
+        out = M.run(args, log=lambda s="": None)
+        torch.cuda.synchronize()
+        a = out["average"]
+        print("%-22s Recall@20 %.2f MRR@20 %.2f | %.1f s, %d train steps, %d evaluations" % (
+            name, 100 * a["recall20"], 100 * a["mrr20"], time.perf_counter() - t0, cnt["steps"], cnt["evals"]), flush=True)
