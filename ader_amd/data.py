@@ -142,20 +142,38 @@ class Sampler:
     # -- internal
     def _repack(self):
         self._rows, self._valid = pack_rows(self.prepared_data, self.maxlen)
-        self._rows_dev = None
+        self._rows_dev = self._seq_dev = self._lab_dev = self._epoch = None
+        self.last_idx_dev = None
         self._logit_mat = None
         self.data_indices = list(range(len(self.prepared_data)))
         random.shuffle(self.data_indices)
+
+    def _advance(self):
+        self.batch_counter += 1
+        if self.batch_counter == self.batch_num():
+            self.batch_counter = 0
+            random.shuffle(self.data_indices)
+            self._epoch = None
 
     def _next_indices(self):
         lo = self.batch_counter * self.batch_size
         idx = np.asarray(self.data_indices[lo:lo + self.batch_size], dtype=np.int64)
         idx = idx[self._valid[idx]] if len(idx) else idx
-        self.batch_counter += 1
-        if self.batch_counter == self.batch_num():
-            self.batch_counter = 0
-            random.shuffle(self.data_indices)
+        self._advance()
         return idx
+
+    def _plan_epoch(self):
+        """Device-resident feeder: the batches of the whole epoch at once -- the shuffled order (the reference's `random` stream, as
+        _next_indices reads it) with the invalid rows dropped per batch, uploaded in ONE copy per epoch; a batch is then a slice of
+        that device array (per step this replaces a list -> array conversion, a filter and a pageable host-to-device copy)."""
+        import torch
+        perm = np.asarray(self.data_indices, dtype=np.int64)
+        keep = self._valid[perm] if len(perm) else np.zeros(0, dtype=bool)
+        bounds = np.minimum(np.arange(self.batch_num() + 1, dtype=np.int64) * self.batch_size, len(perm))
+        offs = np.concatenate([[0], np.cumsum(keep)])[bounds]
+        flat = perm[keep]
+        dev = torch.from_numpy(flat).to(self._seq_dev.device)
+        self._epoch = (flat, offs, dev, dev.to(torch.int32))
 
     # -- reference surface
     def label_generator(self, session):
@@ -187,6 +205,9 @@ class Sampler:
         Call again after split_data / add_exemplar (they repack)."""
         import torch
         self._rows_dev = torch.from_numpy(self._rows).to(device)
+        self._seq_dev = self._rows_dev[:, :self.maxlen].contiguous()        # gathered by index_select: contiguous outputs, no slicing copies
+        self._lab_dev = self._rows_dev[:, self.maxlen].contiguous()
+        self._epoch = None
         # fraction of real positions (sessions are left-padded to maxlen, util.py:161-169): what the engine's packed session
         # kernels go by when the batches no longer pass through the host (Engine.pack_density)
         self.density = float(np.count_nonzero(self._rows[:, :self.maxlen])) / max(self._rows[:, :self.maxlen].size, 1)
@@ -200,13 +221,28 @@ class Sampler:
         rows = self._rows_dev.index_select(0, torch.from_numpy(idx).to(self._rows_dev.device, non_blocking=True))
         return rows[:, :self.maxlen].contiguous(), rows[:, self.maxlen].contiguous()
 
+    def _next_device_batch(self):
+        if self._epoch is None:
+            self._plan_epoch()
+        flat, offs, dev, dev32 = self._epoch
+        o0, o1 = int(offs[self.batch_counter]), int(offs[self.batch_counter + 1])
+        self._advance()
+        idx_dev = dev[o0:o1]
+        self.last_idx_dev = dev32[o0:o1]            # the same row indices as an int32 device tensor (e.g. teacher rows of the batch)
+        return self._seq_dev.index_select(0, idx_dev), self._lab_dev.index_select(0, idx_dev), flat[o0:o1]
+
     def next_batch(self):
         """Fast path: (seq [b, maxlen] int32, pos [b] int32), contiguous; numpy arrays, or device tensors after to_device()."""
+        if getattr(self, "_seq_dev", None) is not None:
+            return self._next_device_batch()[:2]
         return self._rows_of(self._next_indices())
 
     def next_exemplar_batch(self):
         """Fast path: (seq, pos, row indices into the exemplar list) -- teacher logits stay wherever
-        the caller keeps them (e.g. one [E, Np] device tensor) and are gathered by index."""
+        the caller keeps them (e.g. one [E, Np] device tensor) and are gathered by index (Sampler.last_idx_dev: the indices as an
+        int32 device tensor, after to_device())."""
+        if getattr(self, "_seq_dev", None) is not None:
+            return self._next_device_batch()
         idx = self._next_indices()
         seq, pos = self._rows_of(idx)
         return seq, pos, idx

@@ -194,6 +194,7 @@ def run(args, log=print):
                     if use_ex and not args.ewc:                                   # main.py:225
                         ex_seq, ex_pos, idx = exemplar_sampler.next_exemplar_batch()
                         idx = np.asarray(idx, dtype=np.int32)
+                        idx_dev = getattr(exemplar_sampler, "last_idx_dev", None) if world == 1 else None   # (same indices, already on the device)
                         if world == 1 and args.fixed_batches and (len(pos_t) > len(pos) or 0 < len(ex_seq) < exemplar_sampler.batch_size):
                             kw.update(n_ex_global=len(ex_seq))
                             dp.set_rows(0, max_item, ex_row0=len(pos))             # the exemplar rows keep the dropout counters of the unpadded batch
@@ -201,6 +202,7 @@ def run(args, log=print):
                                 ex_seq, ex_pos = (adist.pad_rows(ex_seq, exemplar_sampler.batch_size),
                                                   adist.pad_rows(ex_pos, exemplar_sampler.batch_size))
                                 idx = adist.pad_rows(idx, exemplar_sampler.batch_size, fill=-1)
+                                idx_dev = None
                         if world > 1:                                            # ... and exemplar rows (main.py:229 order kept)
                             kw.update(n_ex_global=len(ex_seq))
                             elo, _ = adist.shard_bounds(len(ex_seq), world, rank)
@@ -216,7 +218,7 @@ def run(args, log=print):
                             model.train_step(seq_l, pos_t, max_item, args.lr, args.dropout_rate, ex_pos=ex_pos, **kw)
                         else:
                             model.train_step(seq_l, pos_t, max_item, args.lr, args.dropout_rate, teacher=store.logits,
-                                             ex_trow=idx, **kw)
+                                             ex_trow=idx if idx_dev is None else idx_dev, **kw)
                     else:
                         model.train_step(seq_t, pos_t, max_item, args.lr, args.dropout_rate, **kw)
                 model.engine.check_status()

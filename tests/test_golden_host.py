@@ -69,6 +69,35 @@ def test_sampler_subseq_and_exemplar_paths(golden_dir):
     assert np.array_equal(np.array(elog, dtype=np.float64), g["ex_logits"])
 
 
+def test_epoch_planned_feeder_yields_the_reference_batches():
+    """Sampler.to_device plans a whole epoch at once (shuffled order, invalid rows dropped per batch, one upload) and serves batches
+    as slices: same batches, same index arrays and the same consumption of the `random` stream as the per-batch host path that the
+    golden vectors above pin -- across three reshuffles, with sessions too short to train on in the data.  (The tensor device is
+    the CPU here; tests/test_gpu_shim.py runs it on the GPU.)"""
+    import random
+    import torch
+    rs = np.random.RandomState(4)
+    sessions = [rs.randint(1, 90, size=rs.randint(1, 30)).tolist() for _ in range(157)]
+    out = []
+    for dev in (False, True):
+        random.seed(11)
+        smp = D.Sampler(sessions, 50, 16)
+        if dev:
+            smp.to_device(torch.device("cpu"))
+        got = []
+        for _ in range(3 * smp.batch_num() + 2):
+            seq, pos, idx = smp.next_exemplar_batch()
+            if dev:
+                assert seq.dtype == torch.int32 and seq.is_contiguous() and pos.is_contiguous()
+                assert smp.last_idx_dev.dtype == torch.int32 and np.array_equal(smp.last_idx_dev.numpy(), idx)
+                seq, pos = seq.numpy(), pos.numpy()
+            got.append((np.array(seq), np.array(pos), np.array(idx)))
+        out.append((got, random.random()))
+    assert out[0][1] == out[1][1]
+    for (a, b, c), (d, e, f) in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, d) and np.array_equal(b, e) and np.array_equal(c, f)
+
+
 def test_split_data(golden_dir):
     g = np.load(os.path.join(golden_dir, "split.npz"))
     s = np.load(os.path.join(golden_dir, "sampler.npz"))
