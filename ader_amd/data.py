@@ -104,6 +104,24 @@ class DataLoader:
 
 
 # --------------------------------------------------------------------------------------- Sampler
+def shuffle_like_python(a):
+    """random.shuffle on an int64 numpy array: same permutation, same consumption of the `random` module's stream (the
+    reference shuffles its index list at every epoch and repack, util.py:149,186,211,237,261, and every later draw of the run --
+    validation split, exemplar selection -- continues that stream).  Long arrays go through ader_host_shuffle (csrc/host_feed.hip:
+    CPython's algorithm on the generator's state; 2-11 ms of pure-Python loop per epoch on the shipped datasets otherwise)."""
+    n = len(a)
+    if n >= 256:
+        from . import _lib
+        st = random.getstate()
+        mt = np.array(st[1], dtype=np.uint32)
+        _lib.call("ader_host_shuffle", mt.ctypes.data, a.ctypes.data, n)
+        random.setstate((st[0], tuple(mt.tolist()), st[2]))
+        return
+    lst = a.tolist()
+    random.shuffle(lst)
+    a[:] = lst
+
+
 def pack_rows(sessions, maxlen):
     """[n, maxlen+1] int32: up to the last `maxlen` inputs right-aligned in zeros, then the label
     (= last item).  Rows of sessions shorter than 2 are all-zero and flagged invalid
@@ -140,24 +158,29 @@ class Sampler:
         self._repack()
 
     # -- internal
-    def _repack(self):
-        self._rows, self._valid = pack_rows(self.prepared_data, self.maxlen)
+    def _repack(self, rows=None, valid=None):
+        self._rows, self._valid = pack_rows(self.prepared_data, self.maxlen) if rows is None else (np.ascontiguousarray(rows), valid)
         self._rows_dev = self._seq_dev = self._lab_dev = self._epoch = None
         self.last_idx_dev = None
         self._logit_mat = None
-        self.data_indices = list(range(len(self.prepared_data)))
-        random.shuffle(self.data_indices)
+        self._perm = np.arange(len(self.prepared_data), dtype=np.int64)
+        shuffle_like_python(self._perm)
+
+    @property
+    def data_indices(self):
+        """The shuffled index list of the reference's Sampler (util.py:148-149), kept as an int64 array."""
+        return self._perm.tolist()
 
     def _advance(self):
         self.batch_counter += 1
         if self.batch_counter == self.batch_num():
             self.batch_counter = 0
-            random.shuffle(self.data_indices)
+            shuffle_like_python(self._perm)
             self._epoch = None
 
     def _next_indices(self):
         lo = self.batch_counter * self.batch_size
-        idx = np.asarray(self.data_indices[lo:lo + self.batch_size], dtype=np.int64)
+        idx = self._perm[lo:lo + self.batch_size].copy()
         idx = idx[self._valid[idx]] if len(idx) else idx
         self._advance()
         return idx
@@ -167,7 +190,7 @@ class Sampler:
         _next_indices reads it) with the invalid rows dropped per batch, uploaded in ONE copy per epoch; a batch is then a slice of
         that device array (per step this replaces a list -> array conversion, a filter and a pageable host-to-device copy)."""
         import torch
-        perm = np.asarray(self.data_indices, dtype=np.int64)
+        perm = self._perm
         keep = self._valid[perm] if len(perm) else np.zeros(0, dtype=bool)
         bounds = np.minimum(np.arange(self.batch_num() + 1, dtype=np.int64) * self.batch_size, len(perm))
         offs = np.concatenate([[0], np.cumsum(keep)])[bounds]
@@ -196,7 +219,7 @@ class Sampler:
         valid_data = [self.prepared_data[s] for s in sidx[n_train:]]
         train_data = [self.prepared_data[s] for s in sidx[:n_train]]
         self.prepared_data = train_data
-        self._repack()
+        self._repack(self._rows[sidx[:n_train]], self._valid[sidx[:n_train]])       # (a row depends on its own session only)
         return (valid_data, train_data) if return_train else valid_data
 
     def to_device(self, device):

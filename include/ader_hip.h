@@ -16,6 +16,7 @@
 #ifndef ADER_HIP_H
 #define ADER_HIP_H
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -475,6 +476,12 @@ int ader_herding_select(const float* rep, const long* seg, const int* quota, con
  * n_total*H floats): what ader_herding_select runs for H != 150, exported for kernel-vs-kernel checks and A/B timing */
 int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
                                 int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
+
+/* ---- host-side feeder helper (no device work, no stream) --------------------------------------------------------------------
+ * Python's random.shuffle on an int64 array given the `random` module's Mersenne-Twister state (mt_state[0..623] words, [624] index =
+ * random.getstate()[1]); array and state are advanced in place exactly as CPython advances them.  The reference's Sampler
+ * re-shuffles its index list every epoch (util.py:152-157, 226-235) and every later draw of the run continues that stream. */
+int ader_host_shuffle(uint32_t* mt_state, int64_t* x, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,25 @@ def test_sampler_subseq_and_exemplar_paths(golden_dir):
     assert np.array_equal(np.array(elog, dtype=np.float64), g["ex_logits"])
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 65537, 131072, 300001])
+def test_native_shuffle_is_random_shuffle(n):
+    """ader_host_shuffle (csrc/host_feed.hip) against random.shuffle itself: same permutation and the same generator state after,
+    from several points of the stream (incl. across a regeneration of the Mersenne-Twister block)."""
+    for seed, burn in ((0, 0), (7, 623), (123456789, 1000)):
+        random.seed(seed)
+        for _ in range(burn):
+            random.random()
+        st0 = random.getstate()
+        want = list(range(n))
+        random.shuffle(want)
+        st_want = random.getstate()
+        random.setstate(st0)
+        a = np.arange(n, dtype=np.int64)
+        D.shuffle_like_python(a)
+        assert a.tolist() == want
+        assert random.getstate() == st_want
+
+
 def test_epoch_planned_feeder_yields_the_reference_batches():
     """Sampler.to_device plans a whole epoch at once (shuffled order, invalid rows dropped per batch, one upload) and serves batches
     as slices: same batches, same index arrays and the same consumption of the `random` stream as the per-batch host path that the
