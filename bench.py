@@ -303,18 +303,37 @@ def main():
         return eng_
 
     # packed catalog exchange (the default from 8 ranks on): its all-to-all split sizes come from the ids of the GLOBAL batch, which
-    # every rank can form on the host (the synthetic batches of all ranks are a function of (s, rank)): no device-to-host sync per step
-    pack_kw = [{} for _ in range(nbatch)]
+    # every rank can form on the host (the synthetic batches of all ranks are a function of (s, rank); a training loop's feeder
+    # holds the rows on the host too: Sampler._rows).  The counts themselves are computed INSIDE the timed region, per step, as a
+    # training loop has to -- by a one-step-ahead worker thread (numpy releases the interpreter lock), so no device-to-host
+    # synchronisation and no host work on the step's critical path
+    pack_ids = [None] * nbatch
+    pack_state = {"eng": None, "ex": None, "fut": None, "fut_i": -1}
 
     def prepare_pack_counts(eng_):
+        pack_state.update(eng=None, fut=None, fut_i=-1)
         if world > 1 and eng_.dp_mode == "catalog" and eng_.dp_pack and not E:
-            from ader_amd.engine import pack_counts_host
+            import concurrent.futures
             for s_ in range(nbatch):
-                rows = []
-                for r_ in range(world):
-                    sq, ps = synth_batch(B, T, N, 1000 * s_ + r_, "cpu", args.regime)
-                    rows.append(np.concatenate([sq.numpy().reshape(-1), ps.numpy()]).astype(np.int32))
-                pack_kw[s_] = {"pack_counts": pack_counts_host(np.stack(rows), B * T, eng_.shard_items)}
+                if pack_ids[s_] is None:
+                    rows = []
+                    for r_ in range(world):
+                        sq, ps = synth_batch(B, T, N, 1000 * s_ + r_, "cpu", args.regime)
+                        rows.append(np.concatenate([sq.numpy().reshape(-1), ps.numpy()]).astype(np.int32))
+                    pack_ids[s_] = np.stack(rows)
+            if pack_state["ex"] is None:
+                pack_state["ex"] = concurrent.futures.ThreadPoolExecutor(1)
+            pack_state["eng"] = eng_
+
+    def pack_for(i):
+        eng_ = pack_state["eng"]
+        if eng_ is None:
+            return {}
+        from ader_amd.engine import pack_counts_host
+        ex = pack_state["ex"]
+        fut = pack_state["fut"] if pack_state["fut_i"] == i else ex.submit(pack_counts_host, pack_ids[i % nbatch], B * T, eng_.shard_items)
+        pack_state["fut"], pack_state["fut_i"] = ex.submit(pack_counts_host, pack_ids[(i + 1) % nbatch], B * T, eng_.shard_items), i + 1
+        return {"pack_counts": fut.result()}
 
     guard_logs = {}
 
@@ -329,7 +348,7 @@ def main():
             # the rank and the call site instead of hanging in RCCL -- and every rank prints what it issued
             adist.guard.start()
             try:
-                eng_.train_step(*batches[0], N, lr, **kw, **pack_kw[0])
+                eng_.train_step(*batches[0], N, lr, **kw, **pack_for(0))
                 torch.cuda.synchronize()
             finally:
                 log_ = adist.guard.stop()
@@ -340,11 +359,11 @@ def main():
                                          "splits": None if e_ is None else {"send": list(e_[0]), "recv": list(e_[1])}}
                                         for a_, b_, c_, d_, e_ in log_]
         for i in range(5):        # engine initialisation (workspace allocation, kernel attributes, side streams): never timed
-            eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
+            eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_for(i))
         for i in range(args.warmup):
             if sections and i == max(0, args.warmup - 3):
                 eng_.timer = SectionTimer()
-            eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
+            eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_for(i))
         eng_.check_status()
         if sections:
             if eng_.timer is not None:
@@ -362,7 +381,7 @@ def main():
             sync()
             t0 = time.perf_counter()
             for i in range(args.steps):
-                eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
+                eng_.train_step(*batches[i % nbatch], N, lr, **kw, **pack_for(i))
             sync()
             dt_ = time.perf_counter() - t0
             if world > 1:
@@ -399,7 +418,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for i in range(args.sustained_steps):
-            eng.train_step(*batches[i % nbatch], N, lr, **kw, **pack_kw[i % nbatch])
+            eng.train_step(*batches[i % nbatch], N, lr, **kw, **pack_for(i))
         sync()
         dts_ = time.perf_counter() - t0
         if world > 1:
@@ -603,8 +622,8 @@ def main():
                     "other_leg": other_leg,
                     # what rank 0 announced in the guarded first step of each scheme (every rank prints its own list to stderr)
                     "collectives": guard_logs,
-                    "split_sizes": ("precomputed outside the timed region from the synthetic batches (pack_counts); a training loop "
-                                    "derives them per step on the host: dist.global_ids_host + engine.pack_counts_host"
+                    "split_sizes": ("computed per step INSIDE the timed region from the host copy of the global batch's ids "
+                                    "(engine.pack_counts_host on a one-step-ahead worker thread): no device-to-host synchronisation"
                                     if (cat > 1 and dp_pack) else None),
                     # per step of the catalog-sharded scheme: collectives issued, launches of exchange bookkeeping, host syncs
                     "collectives_per_step": (8 if cat > 1 else None),
