@@ -78,7 +78,6 @@ _SIGS = {
     "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_host_shuffle": [P, P, L],
     "ader_x3_rep_image_bytes": [I],
-    "ader_x3_update_pipelined": [I],
     "ader_x3_update_pair_min_tiles": [I],
     "ader_x3_rep_image": [P, P, I, P, P],
     "ader_tab_update_x3": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
@@ -156,7 +155,7 @@ class AderSeqBwdQkv(ctypes.Structure):
                 [("d_emb", AderDrop)] + [(k, c_int) for k in ("B", "T", "H", "pruned", "emb_bwd", "pad_")])
 
 
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_lbf_ranges_kd", "ader_lbf_readout_ranges", "ader_lx3_readout_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints", "ader_x3_rep_image_bytes", "ader_x3_update_pipelined", "ader_x3_update_pair_min_tiles", "ader_sparse_lists_scratch_n", "ader_sparse_lists_starts"}
+_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_lbf_ranges_kd", "ader_lbf_readout_ranges", "ader_lx3_readout_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints", "ader_x3_rep_image_bytes", "ader_x3_update_pair_min_tiles", "ader_sparse_lists_scratch_n", "ader_sparse_lists_starts"}
 
 
 class AderHipError(RuntimeError):

@@ -902,10 +902,7 @@ static bool tab_pairs() {                 // (ADER_DIAG, ADER_X3_TILE=64: k_tab1
 #endif
 }
 
-// table_update_x3p.hip: the pipelined kernel (large catalogs); 1 = launched, 0 = shape not covered, otherwise an error
-int tabp_try_launch(TabArgs a, const FuseArgs& fa, int tiles, int wg_per_cu, hipStream_t st);
 static int g_x3_pair_min_tiles = 0;       // ader_x3_update_pair_min_tiles(): 0 = pairs always (measured: no difference on the shipped catalogs)
-static int g_x3_pipelined = 0;            // ader_x3_update_pipelined(): off by default -- see the measurements at the setter
 
 template <bool EXTRA, bool KD>
 static int tab16x3_launch_t(const TabArgs& a, const FuseArgs& fa, int tiles, size_t lds, hipStream_t st) {
@@ -941,11 +938,6 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
     const size_t lds = tab16x3_lds(a.Bp, kd ? a.Bp - a.kd_row0 : 0);
     hipStream_t st = (hipStream_t)stream;
     a.tile_end = a.tile_off + tiles;
-    if (g_x3_pipelined && !kd && !extra && !(a.ko & 0xff)) {
-        const int rc = tabp_try_launch(a, fa, tiles, g_x3_pipelined, st);
-        if (rc == 1) return 0;
-        if (rc != 0) return rc;
-    }
     // (A/B knob: below g_x3_pair_min_tiles tiles, one tile per workgroup.  Measured on the shipped catalogs, 400-700 tiles, distilled step:
     //  k_tab16x3 107.6 us against k_tab32x3 112.1 us, step 0.4594 against 0.4575 ms -- no difference, the default stays pairs)
     if (tab_pairs() && tiles > g_x3_pair_min_tiles && (a.tile_off & 1) == 0 && !(a.ko & 0xff)) {
@@ -960,24 +952,14 @@ static int tab16x3_launch(TabArgs a, const FuseArgs& fa, int tiles, bool extra, 
 
 extern "C" {
 
-// Kernel choice of ader_tab_update_x3 for large catalogs: k >= 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
-// (table_update_x3p.hip) with k workgroups per CU in the grid -- 1: fully persistent, one workgroup per CU walks its share of the tile
-// pairs; k > 1: SEMI-persistent, k x CUs workgroups that own 1/k of that share and retire, so that the side stream's small launches
-// find free CUs again --, 0 (default) = always k_tab32x3; a negative argument only queries.  Returns the previous setting.  Both
-// kernels give bit-identical results (tests/test_gpu_fullsize.py).  Why 0 is the default (round 4, cfg-S, same box): k_tabp runs the
-// update in 0.93 ms against 1.00 ms, but its persistent 512-thread workgroups own every register of every CU, so the weight-gradient
-// products, reductions and the small Adam of the side stream can no longer run INSIDE the update (0.14 ms when they follow it): the
-// step is 2.26 ms against 2.20.  DESIGN.md section 6 has the stamps.
+// (The role-split producer / consumer form of this update -- k_tabp, rounds 4-5, opt-in -- was removed in round 5: it never won in the
+//  step and the full-size bit-identity test caught it writing a few wrong vectors in one launch out of several on a
+//  cold process: a kernel with a rare race has no place behind the ABI.)
 // tiles (64 table rows each) above which the update takes a PAIR of tiles per workgroup (k_tab32x3) instead of one (k_tab16x3):
 // tuning / A-B knob, bit-identical results either way; negative: query.  Returns the previous setting.
 int ader_x3_update_pair_min_tiles(int tiles) {
     const int prev = g_x3_pair_min_tiles;
     if (tiles >= 0) g_x3_pair_min_tiles = tiles;
-    return prev;
-}
-int ader_x3_update_pipelined(int mode) {
-    const int prev = g_x3_pipelined;
-    if (mode >= 0) g_x3_pipelined = mode > 64 ? 64 : mode;
     return prev;
 }
 

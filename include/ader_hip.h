@@ -373,12 +373,7 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
  * [Bp,168]; ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned; Bp % 32 == 0).  Replaces the dense-Adam + table-gradient op
  * sites ADER.py:91-96 for the item table, as ader_tab_update does. */
 int ader_x3_rep_image_bytes(int Bp);
-/* kernel choice of ader_tab_update_x3 on large catalogs: k >= 1 = the role-split pipelined kernel k_tabp where its shape conditions hold
- * (csrc/table_update_x3p.hip: >= 4 tile pairs per workgroup, no EXTRA / KD term) with k workgroups per CU in its grid (1: persistent;
- * k > 1: semi-persistent workgroups that retire after 1/k of a CU's share), 0 (default) = always k_tab32x3; negative: query only.
- * Returns the previous setting.  Bit-identical results either way (same op sites: ADER.py:91-96). */
-int ader_x3_update_pipelined(int mode);
-/* ... and between its two plain kernels: catalogs of more than `tiles` 64-row tiles take a pair of tiles per workgroup (k_tab32x3),
+/* kernel choice between the update's two kernels: catalogs of more than `tiles` 64-row tiles take a pair of tiles per workgroup (k_tab32x3),
  * smaller ones a single tile (k_tab16x3); default 0 = pairs always; negative: query only.  Returns the previous value. */
 int ader_x3_update_pair_min_tiles(int tiles);
 int ader_x3_rep_image(const void* rep_hi, const void* rep_lo, int Bp, void* img, void* stream);
