@@ -23,12 +23,16 @@ def test_every_engine_of_a_process_steps_at_the_same_speed():
         eng.pack_density = 0.1
         for i in range(10):
             eng.train_step(seq, pos, N, 5e-4, rate=0.3)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(200):
-            eng.train_step(seq, pos, N, 5e-4, rate=0.3)
-        torch.cuda.synchronize()
-        ms.append((time.perf_counter() - t0) / 200 * 1e3)
+        best = None
+        for rep in range(3):                                   # (best of three: the host of a shared box is not quiet)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(150):
+                eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 150 * 1e3
+            best = dt if best is None else min(best, dt)
+        ms.append(best)
         assert eng._side is side_stream(dev, torch.cuda.current_stream())
         eng.check_status()
-    assert max(ms) < 1.35 * min(ms), ms
+    assert max(ms) < 1.6 * min(ms), ms                         # (an engine on the slow hardware queue stepped 3.2x slower)
