@@ -88,6 +88,7 @@ _SIGS = {
     "ader_sparse_lists_scratch_n": [I, I, I],
     "ader_sparse_lists_starts": [I],
     "ader_sparse_lists": [P, I, P, I, I, P, P, P, P, P, P, P, P],
+    "ader_sparse_lists_meta": [P, I, P, I, I, P, P, P, P, P, P, P, P, P],
     "ader_tab_tile_meta": [P, P, P, P, P, P, I, P, P],
     "ader_fused_bucket_gran": [],
     "ader_fused_bucket_id0": [],

@@ -123,6 +123,110 @@ __global__ __launch_bounds__(256) void k_ip_rank(const int* __restrict__ ids0, i
     (lst ? srow1 : srow0)[k0 + rank] = my;
 }
 
+// The whole chain as ONE launch for a small problem (catalogs of the shipped datasets' size: at most 2,049 keys, 128 k entries): one
+// 1,024-thread workgroup, counters and offsets in LDS, the phases of the kernels above separated by workgroup barriers (its global
+// writes -- tmp, tmp_id, the lists -- are read back by the same workgroup only), and the per-tile records of the update kernels
+// (k_tile_meta's: {k0, k1, first 8 (id, row)} per list) written at the end.  Same lists bit for bit: the rank fixes every slot.
+// Five launches and a memset fewer per step where the host, not the GPU, sets the pace.
+#define IP1_T 1024
+__global__ __launch_bounds__(IP1_T) void k_ip_one(const int* __restrict__ ids0, int n0, const int* __restrict__ ids1, int n1, int gran,
+                                                  int nkeys, int* __restrict__ tmp, int* __restrict__ tmp_id, int* __restrict__ sid0,
+                                                  int* __restrict__ srow0, int* __restrict__ start0, int* __restrict__ sid1,
+                                                  int* __restrict__ srow1, int* __restrict__ start1, int* __restrict__ rec, int tm_list) {
+    extern __shared__ int ip_sm[];
+    int* cnt = ip_sm;                         // [2][nkeys]
+    int* first = cnt + 2 * nkeys;             // [2][nkeys + 1]
+    int* part = first + 2 * (nkeys + 1);      // [IP1_T]
+    const int tid = threadIdx.x, n = n0 + n1;
+    for (int i = tid; i < 2 * nkeys; i += IP1_T) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += IP1_T) {
+        const int lst = i >= n0, k = key_of(lst ? ids1[i - n0] : ids0[i], gran, nkeys);
+        if (k) atomicAdd(cnt + lst * nkeys + k, 1);
+    }
+    __syncthreads();
+    {   // exclusive prefix per list: 512 threads per list, `per` consecutive keys each, Hillis-Steele over the 512 partial sums
+        const int lst = tid >> 9, t = tid & 511;
+        const int per = (nkeys + 511) / 512;
+        const int lo = min(nkeys, t * per), hi = min(nkeys, lo + per);
+        int* c = cnt + lst * nkeys;
+        int* f = first + lst * (nkeys + 1);
+        int* st = lst ? start1 : start0;
+        int sum = 0;
+        for (int k = lo; k < hi; ++k) sum += c[k];
+        part[tid] = sum;
+        __syncthreads();
+        int incl = sum;
+        for (int o = 1; o < 512; o <<= 1) {
+            const int v = (t >= o) ? part[tid - o] : 0;
+            __syncthreads();
+            incl += v;
+            part[tid] = incl;
+            __syncthreads();
+        }
+        int run = incl - sum;
+        for (int k = lo; k < hi; ++k) {
+            const int v = c[k];
+            f[k] = run;
+            if (k >= 1) st[k - 1] = run;
+            c[k] = 0;                           // (tickets of the scatter)
+            run += v;
+        }
+        if (hi == nkeys && lo < hi) { f[nkeys] = run; st[nkeys - 1] = run; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += IP1_T) {
+        const int lst = i >= n0, id = lst ? ids1[i - n0] : ids0[i], k = key_of(id, gran, nkeys);
+        if (k) {
+            const int s_ = (lst ? n0 : 0) + first[lst * (nkeys + 1) + k] + atomicAdd(cnt + lst * nkeys + k, 1);
+            tmp[s_] = lst ? i - n0 : i;
+            tmp_id[s_] = id;
+        }
+    }
+    __syncthreads();
+    const int tot0 = first[nkeys], tot1 = first[(nkeys + 1) + nkeys];
+    for (int i = tid; i < tot0 + tot1; i += IP1_T) {
+        const int lst = i >= tot0, s_ = lst ? i - tot0 : i;
+        const int* tp = tmp + (lst ? n0 : 0);
+        const int* ti = tmp_id + (lst ? n0 : 0);
+        const int* f = first + lst * (nkeys + 1);
+        const int my = tp[s_], id = ti[s_];
+        const int k = key_of(id, gran, nkeys);
+        const int k0 = f[k], k1 = f[k + 1];
+        int rank = 0, u = k0;
+        for (; u + 4 <= k1; u += 4) {
+            int pu[4], iu[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pu[j] = tp[u + j]; iu[j] = ti[u + j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rank += (iu[j] < id) || (iu[j] == id && pu[j] < my);
+        }
+        for (; u < k1; ++u) {
+            const int pu = tp[u], iu = ti[u];
+            rank += (iu < id) || (iu == id && pu < my);
+        }
+        (lst ? sid1 : sid0)[k0 + rank] = id;
+        (lst ? srow1 : srow0)[k0 + rank] = my;
+    }
+    if (!rec) return;
+    __syncthreads();
+    const int ntiles = nkeys - 1;
+    for (int i = tid; i < 2 * ntiles; i += IP1_T) {
+        const int tile = i >> 1, lst = i & 1;
+        const int* f = first + lst * (nkeys + 1);
+        const int* ids = lst ? sid1 : sid0;
+        const int* rows = lst ? srow1 : srow0;
+        int* mt = rec + (size_t)i * tm_list;
+        const int k0 = f[tile + 1], k1 = f[tile + 2];
+        mt[0] = k0; mt[1] = k1;
+        for (int j = 0; j < 8; ++j) {
+            const bool in = k0 + j < k1;
+            mt[2 + 2 * j] = in ? ids[k0 + j] : 0;
+            mt[3 + 2 * j] = in ? rows[k0 + j] : 0;
+        }
+    }
+}
+
 extern "C" {
 
 // scratch ints needed by ader_sparse_lists: counters [2][nkeys], first [2][nkeys + 1], tmp [n_sp + n_tg], tmp_id [n_sp + n_tg]
@@ -157,6 +261,26 @@ int ader_sparse_lists(const int* seq, int n_sp, const int* lab, int n_tg, int N,
     }
     HIP_LAUNCH_CHECK();
     return 0;
+}
+
+// ader_sparse_lists followed by ader_tab_tile_meta (rec: ader_tab_meta_ints(N) ints, or NULL for the lists alone) -- as ONE launch
+// when the problem is small enough for one workgroup's LDS (at most 2,049 keys = 131,072 items, 131,072 entries), as the chain of
+// launches above otherwise.  Same outputs either way.
+int ader_sparse_lists_meta(const int* seq, int n_sp, const int* lab, int n_tg, int N, int* scratch, int* sp_ids, int* sp_rows,
+                           int* sp_start, int* tg_ids, int* tg_rows, int* tg_start, int* rec, void* stream) {
+    if (n_sp < 0 || n_tg < 0 || N < 1) return -2;
+    const int gran = ader_fused_bucket_gran(), nkeys = ip_nkeys(N), n = n_sp + n_tg;
+    if (nkeys <= 2049 && n <= 131072 && n > 0) {
+        int* tmp = scratch + 2 * nkeys + 2 * (nkeys + 1);
+        const size_t lds = (size_t)(2 * nkeys + 2 * (nkeys + 1) + IP1_T) * sizeof(int);
+        hipLaunchKernelGGL(k_ip_one, dim3(1), dim3(IP1_T), lds, (hipStream_t)stream, seq, n_sp, lab, n_tg, gran, nkeys, tmp, tmp + n, sp_ids,
+                           sp_rows, sp_start, tg_ids, tg_rows, tg_start, rec, 18);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
+    int rc = ader_sparse_lists(seq, n_sp, lab, n_tg, N, scratch, sp_ids, sp_rows, sp_start, tg_ids, tg_rows, tg_start, stream);
+    if (rc || !rec) return rc;
+    return ader_tab_tile_meta(sp_ids, sp_rows, sp_start, tg_ids, tg_rows, tg_start, N, rec, stream);
 }
 
 }  // extern "C"

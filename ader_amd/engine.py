@@ -1502,13 +1502,12 @@ class Engine:
         tids, torder = self.buf("sl_tids", (n_tg,), i32), self.buf("sl_trows", (n_tg,), i32)
         sp_start, tg_start = self.buf("sl_sps", (nb1,), i32), self.buf("sl_tgs", (nb1,), i32)
         scratch = self.buf("sl_scratch", (call("ader_sparse_lists_scratch_n", n_sp, n_tg, N),), i32)
-        call("ader_sparse_lists", ptr(seq.contiguous()), n_sp, ptr(lab.contiguous()), n_tg, N, ptr(scratch), ptr(ids), ptr(order),
-             ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), self._stream())
         meta = None
         if self.lx3 or self.bf16_update == "resident":        # per-tile list records of the 64-row update kernel (table_update.hip)
             meta = self.buf("sl_meta", (call("ader_tab_meta_ints", N),), torch.int32)
-            call("ader_tab_tile_meta", ptr(ids), ptr(order), ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), N, ptr(meta),
-                 self._stream())
+        # (lists + records: ONE launch on the catalogs of the shipped datasets, the chain of launches on large ones)
+        call("ader_sparse_lists_meta", ptr(seq.contiguous()), n_sp, ptr(lab.contiguous()), n_tg, N, ptr(scratch), ptr(ids), ptr(order),
+             ptr(sp_start), ptr(tids), ptr(torder), ptr(tg_start), ptr(meta), self._stream())
         return ids, order, sp_start, tids, torder, tg_start, meta
 
     def _lists_async(self, seq, lab, N):

@@ -429,6 +429,11 @@ int ader_sparse_lists_scratch_n(int n_sp, int n_tg, int N);
 int ader_sparse_lists_starts(int N);
 int ader_sparse_lists(const int* seq, int n_sp, const int* lab, int n_tg, int N, int* scratch, int* sp_ids, int* sp_rows,
                       int* sp_start, int* tg_ids, int* tg_rows, int* tg_start, void* stream);
+/* ... followed by ader_tab_tile_meta (rec: ader_tab_meta_ints(N) ints; NULL: the lists alone) -- ONE launch when the problem fits one
+ * workgroup's LDS (at most 131,072 items and 131,072 entries: the shipped datasets), the same chain of launches otherwise; same
+ * outputs either way. */
+int ader_sparse_lists_meta(const int* seq, int n_sp, const int* lab, int n_tg, int N, int* scratch, int* sp_ids, int* sp_rows,
+                           int* sp_start, int* tg_ids, int* tg_rows, int* tg_start, int* rec, void* stream);
 int ader_fused_bucket_gran(void);
 int ader_fused_bucket_id0(void);
 

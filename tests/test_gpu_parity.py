@@ -935,6 +935,23 @@ def test_sparse_lists_are_bucketed_in_position_order(n_sp, n_tg, N):
             assert np.array_equal(got_rows.cpu().numpy()[:nr], o.astype(np.int32))
             assert np.array_equal(got_ids.cpu().numpy()[:nr], src[o])
             assert np.array_equal(got_st.cpu().numpy(), np.searchsorted(np.sort(src[src > 0]), bounds).astype(np.int32))
+    # ader_sparse_lists_meta: the same lists plus the per-tile records of the update kernels -- as ONE launch on small problems
+    # (every case here except the 1M-item catalogs), as ader_sparse_lists + ader_tab_tile_meta otherwise: identical outputs
+    nm = call("ader_tab_meta_ints", N)
+    meta_a, meta_b = torch.full((nm,), -7, **i32), torch.full((nm,), -9, **i32)
+    call("ader_tab_tile_meta", ptr(ids), ptr(rows), ptr(st), ptr(tids), ptr(trows), ptr(tst), N, ptr(meta_a),
+         torch.cuda.current_stream().cuda_stream)
+    ids2, rows2, st2 = torch.full((n_sp,), -1, **i32), torch.full((n_sp,), -1, **i32), torch.full((nb1,), -1, **i32)
+    tids2, trows2, tst2 = torch.full((max(n_tg, 1),), -1, **i32), torch.full((max(n_tg, 1),), -1, **i32), torch.full((nb1,), -1, **i32)
+    scratch2 = torch.empty(call("ader_sparse_lists_scratch_n", n_sp, n_tg, N), **i32)
+    for rep in range(2):
+        call("ader_sparse_lists_meta", ptr(d_seq), n_sp, ptr(d_lab), n_tg, N, ptr(scratch2), ptr(ids2), ptr(rows2), ptr(st2), ptr(tids2),
+             ptr(trows2), ptr(tst2), ptr(meta_b), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        nr0, nr1 = int((seq > 0).sum()), int((lab > 0).sum())
+        assert torch.equal(ids2[:nr0], ids[:nr0]) and torch.equal(rows2[:nr0], rows[:nr0]) and torch.equal(st2, st)
+        assert torch.equal(tids2[:nr1], tids[:nr1]) and torch.equal(trows2[:nr1], trows[:nr1]) and torch.equal(tst2, tst)
+        assert torch.equal(meta_a, meta_b)
 
 
 def test_herding_bit_exact_against_oracle(golden_dir):
