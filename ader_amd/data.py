@@ -141,12 +141,19 @@ def pack_rows(sessions, maxlen):
 
 
 class Sampler:
-    def __init__(self, data, maxlen, batch_size, is_subseq=False):
+    def __init__(self, data, maxlen, batch_size, is_subseq=False, packed=None):
+        """packed: (prepared_data, rows, valid) of an earlier Sampler over the SAME data (Evaluator keeps them: the reference builds a
+        new evaluator -- hence a new Sampler -- every epoch over an unchanged validation set, util.py:276-290; the shuffle of the new
+        index list is the part of that which consumes the `random` stream, and it is kept)."""
         self.maxlen = maxlen
         self.batch_size = batch_size
         self.batch_counter = 0
         self.logits = []
         self.prepared_data = []
+        if packed is not None:
+            self.prepared_data = packed[0]
+            self._repack(packed[1], packed[2])
+            return
         if not is_subseq:
             # a session of length l yields itself and its prefixes down to length 2 (util.py:138-143)
             for session in data:
@@ -307,6 +314,8 @@ class Evaluator:
     matrix as in the reference; when the model offers `rank_targets(seq, pos, max_item)` (the HIP
     count-greater kernel) that is used instead -- only pred[label-1] is ever read (util.py:325)."""
 
+    _packed = {}        # (id(data), len, maxlen, is_subseq) -> (data, (prepared_data, rows, valid)): see __init__
+
     def __init__(self, data, is_subseq, maxlen, batch_size, max_item, mode, model, sess, shard=(0, 1)):
         self.shard = shard          # (rank, world): evaluation batches are independent units (SURVEY 8e)
         self.max_item = max_item
@@ -315,7 +324,18 @@ class Evaluator:
         self.ranks = []
         self.mode = mode
         self.desc = 'Validating epoch ' if mode == 'valid' else 'Testing epoch '
-        self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq)
+        # (the packed rows of an unchanged session list are kept between evaluators -- one is built per epoch, main.py:264-266 -- and
+        #  only the new Sampler's shuffle, which the `random` stream sees, is repeated)
+        key = (id(data), len(data), maxlen, bool(is_subseq))
+        hit = Evaluator._packed.get(key)
+        if hit is not None and hit[0] is data:
+            self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq, packed=hit[1])
+        else:
+            self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq)
+            smp = self.evaluate_sampler
+            if len(Evaluator._packed) >= 4:
+                Evaluator._packed.pop(next(iter(Evaluator._packed)))
+            Evaluator._packed[key] = (data, (smp.prepared_data, smp._rows, smp._valid))
 
     def evaluate(self, epoch):
         rank, world = self.shard

@@ -117,6 +117,34 @@ def test_epoch_planned_feeder_yields_the_reference_batches():
         assert np.array_equal(a, d) and np.array_equal(b, e) and np.array_equal(c, f)
 
 
+def test_evaluators_over_an_unchanged_list_share_the_packed_rows_not_the_shuffle():
+    """One Evaluator is built per epoch over the same validation list (main.py:264-266): the second one reuses the first one's
+    packed rows, but its Sampler still shuffles a fresh index list -- same batches and same `random` stream as without the cache."""
+    rs = np.random.RandomState(8)
+    data = [rs.randint(1, 50, size=rs.randint(1, 12)).tolist() for _ in range(300)]
+    got = []
+    for cached in (True, False):
+        random.seed(3)
+        D.Evaluator._packed.clear()
+        seqs = []
+        for epoch in range(3):
+            if not cached:
+                D.Evaluator._packed.clear()
+            ev = D.Evaluator(data, True, 20, 64, 49, "valid", None, None)
+            smp = ev.evaluate_sampler
+            seqs.append([smp.next_batch() for _ in range(smp.batch_num())])
+        got.append((seqs, random.random()))
+        if cached:
+            assert len(D.Evaluator._packed) == 1
+    assert got[0][1] == got[1][1]
+    for ea, eb in zip(got[0][0], got[1][0]):
+        for (sa, pa), (sb, pb) in zip(ea, eb):
+            assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
+    data.append([1, 2, 3])                                   # a changed list is packed again
+    ev = D.Evaluator(data, True, 20, 64, 49, "valid", None, None)
+    assert len(ev.evaluate_sampler.prepared_data) == 301
+
+
 def test_split_data(golden_dir):
     g = np.load(os.path.join(golden_dir, "split.npz"))
     s = np.load(os.path.join(golden_dir, "sampler.npz"))
