@@ -1,4 +1,4 @@
-// Host-side helper of the GPU-resident feeder (no device code).
+// Host-side helpers of the GPU-resident feeder (no device code).
 // Reference: the Sampler re-shuffles its index list with Python's `random.shuffle` at every epoch and repack (util.py:152-157,
 // 226-235); every later draw of the run (validation split, exemplar selection, herding ties) continues that ONE Mersenne-Twister
 // stream, so a feeder that wants the reference's batches has to consume it draw for draw.  On the shipped datasets the list holds
@@ -42,6 +42,29 @@ int ader_host_shuffle(uint32_t* mt_state, int64_t* x, int64_t n) {
         const int64_t t = x[i]; x[i] = x[r]; x[r] = t;
     }
     mt_state[MT_N] = (uint32_t)idx;
+    return 0;
+}
+
+// Sampler rows of n sessions given as one flat item array (util.py:161-169, 226-227): row i = up to the last `maxlen` inputs of
+// session i right-aligned in zeros, then its label (= last item); sessions shorter than 2 leave an all-zero row flagged invalid.
+// flat: the sessions' items back to back, lens [n]; rows [n][maxlen + 1] must be ZERO on entry; valid [n] bytes.
+int ader_host_pack_rows(const int32_t* flat, const int64_t* lens, int64_t n, int maxlen, int32_t* rows, unsigned char* valid) {
+    if (n < 0 || maxlen < 1 || (n > 0 && (!flat || !lens || !rows || !valid))) return -2;
+    const int64_t w = (int64_t)maxlen + 1;
+    int64_t at = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t L = lens[i];
+        if (L < 0) return -2;
+        valid[i] = L > 1;
+        if (L > 1) {
+            const int64_t k = (L - 1 < maxlen) ? L - 1 : maxlen;
+            const int32_t* src = flat + at + (L - 1 - k);
+            int32_t* dst = rows + i * w + (maxlen - k);
+            for (int64_t j = 0; j < k; ++j) dst[j] = src[j];
+            rows[i * w + maxlen] = flat[at + L - 1];
+        }
+        at += L;
+    }
     return 0;
 }
 

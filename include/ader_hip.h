@@ -482,6 +482,9 @@ int ader_herding_select_generic(const float* rep, const long* seg, const int* qu
  * random.getstate()[1]); array and state are advanced in place exactly as CPython advances them.  The reference's Sampler
  * re-shuffles its index list every epoch (util.py:152-157, 226-235) and every later draw of the run continues that stream. */
 int ader_host_shuffle(uint32_t* mt_state, int64_t* x, int64_t n);
+/* The Sampler's packed rows (util.py:161-169, 226-227) of n sessions given as one flat int32 item array + lens [n]: rows [n][maxlen+1]
+ * (ZERO on entry) = up to the last maxlen inputs right-aligned, then the label; valid [n] bytes = session has at least 2 items. */
+int ader_host_pack_rows(const int32_t* flat, const int64_t* lens, int64_t n, int maxlen, int32_t* rows, unsigned char* valid);
 
 #ifdef __cplusplus
 }
