@@ -391,9 +391,23 @@ def group_by_label(data, batch_size, maxlen):
     (ExemplarGenerator.__init__, util.py:382-393): batches drawn from a shuffled is_subseq Sampler.
     Returns (order of labels, {label: [n_label, maxlen+1] int32 rows}, item frequency dict)."""
     smp = Sampler(data, maxlen, batch_size, is_subseq=True)
-    buckets = defaultdict(list)
-    for _ in range(smp.batch_num()):
-        idx = smp._next_indices()
-        for i in idx.tolist():
-            buckets[int(smp._rows[i, maxlen])].append(i)
-    return {k: smp._rows[np.asarray(v, dtype=np.int64)] for k, v in buckets.items()}
+    # One pass over the batches of the shuffled Sampler == its shuffled order with the invalid rows dropped; the pass ends with the
+    # Sampler's reshuffle (Sampler._advance), which the `random` stream sees and is therefore made here too.  Grouping: labels in the
+    # order of their first appearance, the rows of a label in visiting order (a stable sort), one gather for all rows.
+    n_batches = smp.batch_num()
+    order = smp._perm[smp._valid[smp._perm]] if len(smp._perm) else smp._perm
+    if n_batches > 0:
+        shuffle_like_python(smp._perm)
+    if len(order) == 0:
+        return {}
+    labels = smp._rows[order, maxlen]
+    o = np.argsort(labels, kind="stable")
+    sl = labels[o]
+    starts = np.flatnonzero(np.concatenate([[True], sl[1:] != sl[:-1]]))
+    ends = np.concatenate([starts[1:], [len(sl)]])
+    first_seen = o[starts]                                    # position in `order` of each label's first row
+    rows_sorted = smp._rows[order[o]]
+    out = {}
+    for g in np.argsort(first_seen, kind="stable").tolist():
+        out[int(sl[starts[g]])] = rows_sorted[starts[g]:ends[g]]
+    return out
