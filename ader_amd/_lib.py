@@ -78,6 +78,7 @@ _SIGS = {
     "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_host_shuffle": [P, P, L],
     "ader_host_pack_rows": [P, P, L, I, P, P],
+    "ader_host_prefix_rows": [P, P, L, I, P, P],
     "ader_x3_rep_image_bytes": [I],
     "ader_x3_update_pair_min_tiles": [I],
     "ader_x3_rep_image": [P, P, I, P, P],

@@ -68,4 +68,28 @@ int ader_host_pack_rows(const int32_t* flat, const int64_t* lens, int64_t n, int
     return 0;
 }
 
+// ... of every session AND its prefixes down to length 2 (util.py:138-143: a session of length L yields itself, then s[:L-1], ...,
+// s[:2]), in that order, straight from the flat item array -- the prefix lists themselves are not built (an evaluator needs only the
+// rows).  rows [sum_i max(1, lens[i] - 1)][maxlen + 1] ZERO on entry; valid one byte per row.
+int ader_host_prefix_rows(const int32_t* flat, const int64_t* lens, int64_t n, int maxlen, int32_t* rows, unsigned char* valid) {
+    if (n < 0 || maxlen < 1 || (n > 0 && (!flat || !lens || !rows || !valid))) return -2;
+    const int64_t w = (int64_t)maxlen + 1;
+    int64_t at = 0, r = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t L = lens[i];
+        if (L < 0) return -2;
+        if (L < 2) { valid[r++] = 0; at += L; continue; }         // the session itself: an all-zero, invalid row
+        for (int64_t p = L; p >= 2; --p, ++r) {                   // prefix lengths L, L - 1, ..., 2
+            valid[r] = 1;
+            const int64_t k = (p - 1 < maxlen) ? p - 1 : maxlen;
+            const int32_t* src = flat + at + (p - 1 - k);
+            int32_t* dst = rows + r * w + (maxlen - k);
+            for (int64_t j = 0; j < k; ++j) dst[j] = src[j];
+            rows[r * w + maxlen] = flat[at + p - 1];
+        }
+        at += L;
+    }
+    return 0;
+}
+
 }  // extern "C"

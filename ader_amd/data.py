@@ -149,7 +149,7 @@ def pack_rows(sessions, maxlen):
 
 
 class Sampler:
-    def __init__(self, data, maxlen, batch_size, is_subseq=False, packed=None):
+    def __init__(self, data, maxlen, batch_size, is_subseq=False, packed=None, rows_only=False):
         """packed: (prepared_data, rows, valid) of an earlier Sampler over the SAME data (Evaluator keeps them: the reference builds a
         new evaluator -- hence a new Sampler -- every epoch over an unchanged validation set, util.py:276-290; the shuffle of the new
         index list is the part of that which consumes the `random` stream, and it is kept)."""
@@ -161,6 +161,21 @@ class Sampler:
         if packed is not None:
             self.prepared_data = packed[0]
             self._repack(packed[1], packed[2])
+            return
+        if rows_only and not is_subseq and len(data) >= 512:
+            # an evaluator reads only the packed rows: they are cut for every session and its prefixes straight from the flat item
+            # array (ader_host_prefix_rows, the order of the loop below) and the ~6 prefix lists per session are never built;
+            # prepared_data keeps its length (batch_num / data_size)
+            from . import _lib
+            n = len(data)
+            lens = np.fromiter(map(len, data), dtype=np.int64, count=n)
+            flat = np.fromiter(itertools.chain.from_iterable(data), dtype=np.int32, count=int(lens.sum()))
+            total = int(np.where(lens > 2, lens - 1, 1).sum())
+            rows = np.zeros((total, maxlen + 1), dtype=np.int32)
+            valid = np.zeros(total, dtype=bool)
+            _lib.call("ader_host_prefix_rows", flat.ctypes.data, lens.ctypes.data, n, int(maxlen), rows.ctypes.data, valid.ctypes.data)
+            self.prepared_data = range(total)
+            self._repack(rows, valid)
             return
         if not is_subseq:
             # a session of length l yields itself and its prefixes down to length 2 (util.py:138-143)
@@ -339,7 +354,7 @@ class Evaluator:
         if hit is not None and hit[0] is data:
             self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq, packed=hit[1])
         else:
-            self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq)
+            self.evaluate_sampler = Sampler(data, maxlen, batch_size, is_subseq=is_subseq, rows_only=True)
             smp = self.evaluate_sampler
             if len(Evaluator._packed) >= 4:
                 Evaluator._packed.pop(next(iter(Evaluator._packed)))

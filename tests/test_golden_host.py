@@ -145,6 +145,23 @@ def test_evaluators_over_an_unchanged_list_share_the_packed_rows_not_the_shuffle
     assert len(ev.evaluate_sampler.prepared_data) == 301
 
 
+@pytest.mark.parametrize("n,maxlen", [(600, 50), (600, 4), (5000, 50)])
+def test_rows_only_sampler_equals_the_prefix_expansion(n, maxlen):
+    """An evaluator's Sampler cuts its rows straight from the flat item array (ader_host_prefix_rows) instead of building every prefix
+    list first: same rows, same validity flags, same length, same shuffle -- empty, 1-, 2- and 3-item sessions included."""
+    rs = np.random.RandomState(n + maxlen)
+    data = [rs.randint(1, 30000, size=rs.randint(0, 70)).tolist() for _ in range(n)] + [[], [5], [1, 2], [1, 2, 3]]
+    random.seed(1)
+    a = D.Sampler(data, maxlen, 64, is_subseq=False)
+    ra = random.random()
+    random.seed(1)
+    b = D.Sampler(data, maxlen, 64, is_subseq=False, rows_only=True)
+    rb = random.random()
+    assert len(a.prepared_data) == len(b.prepared_data) and a.batch_num() == b.batch_num()
+    assert np.array_equal(a._valid, b._valid) and np.array_equal(a._rows, b._rows)
+    assert ra == rb and a.data_indices == b.data_indices
+
+
 def test_split_data(golden_dir):
     g = np.load(os.path.join(golden_dir, "split.npz"))
     s = np.load(os.path.join(golden_dir, "sampler.npz"))

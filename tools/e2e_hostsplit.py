@@ -28,6 +28,21 @@ wrap(D.Sampler, "next_exemplar_batch", "next_exemplar_batch")
 wrap(MD.Ader, "train_step", "train_step (host enqueue)")
 wrap(D.Evaluator, "evaluate", "evaluate")
 wrap(D.Sampler, "_repack", "sampler repack")
+wrap(D.Sampler, "__init__", "Sampler.__init__ (incl. repack)")
+wrap(D.Sampler, "split_data", "split_data")
+wrap(D.DataLoader, "train_loader", "DataLoader.train_loader")
+wrap(D.DataLoader, "evaluate_loader", "DataLoader.evaluate_loader")
+wrap(D.Evaluator, "__init__", "Evaluator.__init__")
+from ader_amd import exemplar as X
+from ader_amd import engine as EN
+wrap(X.ExemplarGenerator, "__init__", "ExemplarGenerator.__init__ (group_by_label, quotas)")
+for nm in ("herding_selection", "loss_selection", "randomly_selection"):
+    wrap(X.ExemplarGenerator, nm, "exemplar selection (encode + herding + teacher logits)")
+wrap(EN.Engine, "load_state_dict", "Engine.load_state_dict")
+wrap(EN.Engine, "state_dict", "Engine.state_dict")
+wrap(EN.Engine, "init_params", "Engine.init_params")
+wrap(EN.Engine, "check_status", "Engine.check_status (sync)")
+wrap(EN.Engine, "__init__", "Engine.__init__")
 _sh = random.shuffle
 
 
