@@ -110,6 +110,15 @@ _SIGS = {
     "ader_attnp_last_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I] + _DROP + [P, P],
     "ader_pos_grad_packed": [P, P, P, I, I, I, P],
     "ader_gemm_atb_x3_batch_pk": [P, P, P, P, P, P, P, P, I, P, I, P],
+    "ader_feed_step": [P, P, I, I, P, P, I, I, I, P, P, P, P, P],
+    "ader_concat_i32": [P, I, P, I, P, P],
+    "ader_step_fn_index": [ctypes.c_char_p],
+    "ader_step_fn_args": [I],
+    "ader_step_plan_create": [P, I, P, I, P, I, P, I, U, P],
+    "ader_step_plan_destroy": [P],
+    "ader_step_enqueue": [P, P, I, U, P, P],
+    "ader_step_plan_peek": [P, P, I, U, P, P],
+    "ader_step_plan_failed_op": [P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
     "ader_herding_select_generic": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
@@ -158,7 +167,27 @@ class AderSeqBwdQkv(ctypes.Structure):
                 [("d_emb", AderDrop)] + [(k, c_int) for k in ("B", "T", "H", "pruned", "emb_bwd", "pad_")])
 
 
-_NO_CHECK = {"ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_lbf_ranges_kd", "ader_lbf_readout_ranges", "ader_lx3_readout_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints", "ader_x3_rep_image_bytes", "ader_x3_update_pair_min_tiles", "ader_sparse_lists_scratch_n", "ader_sparse_lists_starts"}
+STEP_MAX_ARGS, STEP_MAX_INPUTS = 48, 16
+
+
+class AderStepOp(ctypes.Structure):
+    """include/ader_hip.h: AderStepOp"""
+    _fields_ = [(k, c_int) for k in ("kind", "fn", "stream", "other", "n_args", "pad_")] + [("args", ctypes.c_uint64 * STEP_MAX_ARGS)]
+
+
+class AderStepBlob(ctypes.Structure):
+    _fields_ = [("op", c_int), ("arg", c_int), ("src", c_void_p), ("bytes", c_size_t)]
+
+
+class AderStepPatch(ctypes.Structure):
+    _fields_ = [("blob", c_int), ("op", c_int), ("arg", c_int), ("input", c_int), ("offset", c_size_t), ("delta", ctypes.c_int64)]
+
+
+class AderStepKey(ctypes.Structure):
+    _fields_ = [("blob", c_int), ("site", c_int), ("offset", c_size_t)]
+
+
+_NO_CHECK = {"ader_step_fn_index", "ader_step_fn_args", "ader_step_plan_failed_op", "ader_ln_bwd_slabs", "ader_gemm_atb_batch_slabs", "ader_gemm_atb_slabs", "ader_logits_sub", "ader_logits_parts", "ader_logits_ranges", "ader_lbf_ranges", "ader_lbf_ranges_kd", "ader_lbf_readout_ranges", "ader_lx3_readout_ranges", "ader_wprep_elems", "ader_fused_bucket_gran", "ader_fused_bucket_id0", "ader_tab_meta_ints", "ader_x3_rep_image_bytes", "ader_x3_update_pair_min_tiles", "ader_sparse_lists_scratch_n", "ader_sparse_lists_starts"}
 
 
 class AderHipError(RuntimeError):
@@ -189,8 +218,13 @@ def load():
     return lib
 
 
+recorder = None      # ader_amd.engine.plan.Recorder while a train step is being recorded into a native launch plan, else None
+
+
 def call(name, *args):
     """Invoke a launcher; raises on a non-zero return code."""
+    if recorder is not None and name not in _NO_CHECK:
+        recorder.launch(name, args)
     rc = getattr(load(), name)(*args)
     if name not in _NO_CHECK and rc != 0:
         raise AderHipError("%s failed with code %d" % (name, rc))

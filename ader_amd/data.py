@@ -12,11 +12,9 @@ gather that can be handed to the device as a single contiguous buffer, instead o
 loops on every step (reference util.py:218-239).
 """
 import itertools
-import json
 import math
 import os
 import random
-from collections import defaultdict
 
 import numpy as np
 

@@ -20,7 +20,6 @@ Trainable surface (second half of this file; every forward has an autograd formu
   ader::ffn_fwd / ffn_bwd                                      modules.py:232-271 + ADER.py:80
   ader::logits_ce / logits_ce_bwd                              ADER.py:88-93 (exact-f32 logits, one-hot CE)
 """
-import math
 
 import torch
 

@@ -477,6 +477,47 @@ int ader_herding_select(const float* rep, const long* seg, const int* quota, con
 int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
                                 int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
 
+/* ---- device-side feeder: util.py:218-262 (Sampler.sampler / exemplar_sampler: the rows of a batch by the shuffled index list) and
+ *      main.py:229 (exemplar rows appended to the train rows), as ONE launch over the GPU-resident packed rows ----------------------
+ * rows_t / rows_e [*, T+1]: packed rows of the train / exemplar Sampler (inputs right-aligned in zeros, label last); idx_t [n_t] /
+ * idx_e [n_e]: int64 row indices of this batch.  Writes seq [Bt + Be, T] = [n_t train rows | zero rows up to Bt | n_e exemplar rows |
+ * zero rows up to Be], pos [Bt] (label, 0 = padding row: weight 0 in every loss kernel), ex_pos [Be] (exemplar labels, optional) and
+ * ex_trow [Be] (idx_e as int32 = the exemplar's teacher row, -1 = padding row; optional). */
+int ader_feed_step(const int* rows_t, const long* idx_t, int n_t, int Bt, const int* rows_e, const long* idx_e, int n_e, int Be, int T,
+                   int* seq, int* pos, int* ex_pos, int* ex_trow, void* stream);
+/* out [na + nb] = a | b (the label list of a one-hot replay step: train labels, then exemplar labels, ADER.py:126-131) */
+int ader_concat_i32(const int* a, int na, const int* b, int nb, int* out, void* stream);
+
+/* ---- native step driver: main.py:220-256 -- the reference runs ONE sess.run(train_op) per step; the executor, not Python, walks the
+ *      ops.  A plan is the launch sequence of one (shape, mode) of the step: launcher calls on two lanes (0 = main stream, 1 = side
+ *      stream) and the event edges between the lanes; ader_step_enqueue walks it in ONE call (csrc/step_plan.hip) --------------------
+ * Slots: every launcher argument as one uint64 -- pointers as addresses, int / unsigned / long / size_t sign-extended, float as its
+ * IEEE bits in the low 32.  The launcher's trailing `stream` argument is a slot too and is filled with the lane's stream per step.
+ * Host descriptors (arguments that are HOST pointers: AderSeqFwd, AderDrop, pointer arrays ...) are listed as blobs and copied into
+ * the plan.  Per step, patches write inputs[input] + delta into an argument slot (blob < 0) or into 8 bytes of a blob (a pointer field
+ * of a descriptor), and every AderDrop.key listed in `keys` is set to the key of (seed, step, site) -- the host half of the dropout
+ * counter spec above.  Launchers run in list order; a WAIT op makes lane `stream` wait for everything enqueued on lane `other` so far. */
+#define ADER_STEP_MAX_ARGS 48
+#define ADER_STEP_MAX_INPUTS 16
+enum { ADER_STEP_LAUNCH = 0, ADER_STEP_WAIT = 1 };
+typedef struct { int kind, fn, stream, other, n_args, pad_; uint64_t args[ADER_STEP_MAX_ARGS]; } AderStepOp;
+typedef struct { int op, arg; const void* src; size_t bytes; } AderStepBlob;
+typedef struct { int blob, op, arg, input; size_t offset; int64_t delta; } AderStepPatch;
+typedef struct { int blob, site; size_t offset; } AderStepKey;
+typedef struct AderStepPlan AderStepPlan;
+/* index of a launcher in the plan's dispatch table (-1: not a step launcher) and its argument count */
+int ader_step_fn_index(const char* name);
+int ader_step_fn_args(int fn);
+int ader_step_plan_create(const AderStepOp* ops, int n_ops, const AderStepBlob* blobs, int n_blobs, const AderStepPatch* patches,
+                          int n_patches, const AderStepKey* keys, int n_keys, unsigned seed, AderStepPlan** out);
+int ader_step_plan_destroy(AderStepPlan* plan);
+/* returns 0, or the first failing launcher's / HIP call's code (ader_step_plan_failed_op: which op) */
+int ader_step_enqueue(AderStepPlan* plan, const uint64_t* inputs, int n_inputs, unsigned step, void* main_stream, void* side_stream);
+/* the patched ops / descriptor bytes a step would issue, without issuing them (blob_out[b]: room for blob b's bytes, or NULL) */
+int ader_step_plan_peek(AderStepPlan* plan, const uint64_t* inputs, int n_inputs, unsigned step, AderStepOp* ops_out,
+                        void* const* blob_out);
+int ader_step_plan_failed_op(const AderStepPlan* plan);
+
 /* ---- host-side feeder helper (no device work, no stream) --------------------------------------------------------------------
  * Python's random.shuffle on an int64 array given the `random` module's Mersenne-Twister state (mt_state[0..623] words, [624] index =
  * random.getstate()[1]); array and state are advanced in place exactly as CPython advances them.  The reference's Sampler

@@ -197,13 +197,8 @@ def test_pack_counts_and_global_ids_on_the_host():
     destination), the rows that travel -- checked against a brute-force loop."""
     import numpy as np
     from ader_amd import dist as adist
-    import importlib.util, os
-    spec = importlib.util.spec_from_file_location("_eng_src", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                           "ader_amd", "engine.py"))
-    src = open(spec.origin).read()
-    ns = {"np": np}
-    start = src.index("def pack_counts_host(")
-    exec(src[start:src.index("class Engine:")], ns)            # (the function is pure numpy; importing the module needs the HIP library)
+    from ader_amd.engine import pack_counts_host           # (pure numpy; importing the package does not load the HIP library)
+    ns = {"pack_counts_host": pack_counts_host}
     rs = np.random.RandomState(0)
     n, T, W, S = 37, 5, 4, 16
     seq = rs.randint(0, 70, size=(n, T)).astype(np.int32)
