@@ -231,6 +231,17 @@ def call(name, *args):
     return rc
 
 
+_fn_index = {}
+
+
+def step_fn_index(name):
+    """Index of a launcher in the native step driver's dispatch table (-1: not a step launcher)."""
+    i = _fn_index.get(name)
+    if i is None:
+        i = _fn_index[name] = load().ader_step_fn_index(name.encode())
+    return i
+
+
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()

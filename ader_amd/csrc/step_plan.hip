@@ -82,7 +82,8 @@ struct AderStepPlan {
     std::vector<size_t> blob_bytes;
     std::vector<AderStepPatch> patches;
     std::vector<AderStepKey> keys;
-    std::vector<hipEvent_t> events;                // one per WAIT op
+    std::vector<hipEvent_t> events;                // one per WAIT op, created at the first enqueue (a plan can be built without a device)
+    int n_waits = 0;
     uint32_t seed = 0;
     int failed_op = -1;
     int device = 0;
@@ -136,14 +137,8 @@ int ader_step_plan_create(const AderStepOp* ops, int n_ops, const AderStepBlob* 
     if (!rc) {
         p->patches.assign(patches, patches + n_patches);
         p->keys.assign(keys, keys + n_keys);
-        for (int i = 0; i < n_ops; ++i) {
-            if (p->ops[i].kind != ADER_STEP_WAIT) continue;
-            hipEvent_t ev;
-            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e != hipSuccess) { rc = (int)e; break; }
-            p->ops[i].fn = (int)p->events.size();          // WAIT: index of its event
-            p->events.push_back(ev);
-        }
+        for (int i = 0; i < n_ops; ++i)
+            if (p->ops[i].kind == ADER_STEP_WAIT) p->ops[i].fn = p->n_waits++;      // WAIT: index of its event (created at the first enqueue)
     }
     if (rc) {
         for (hipEvent_t ev : p->events) (void)hipEventDestroy(ev);
@@ -178,6 +173,12 @@ int ader_step_enqueue(AderStepPlan* p, const uint64_t* inputs, int n_inputs, uns
     for (const AderStepPatch& q : p->patches)
         if (q.input >= n_inputs) return -2;
     apply_patches(p, inputs, step);
+    while ((int)p->events.size() < p->n_waits) {
+        hipEvent_t ev;
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+        p->events.push_back(ev);
+    }
     void* lanes[2] = {main_stream, side_stream};
     const int n = (int)p->ops.size();
     for (int i = 0; i < n; ++i) {

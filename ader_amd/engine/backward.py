@@ -180,7 +180,11 @@ class _Backward:
         if defer and self.dp_world == 1:
             # the id-bucketed lists of the fused table update need only the inputs: build them on a side stream, under the
             # logit kernels (the one-launch forward owns every CU's LDS; the logit kernels leave room for it)
-            labs = pos if (n_ex == 0 or split_kd) else torch.cat([pos, ex_pos])
+            if n_ex == 0 or split_kd:
+                labs = pos
+            else:       # one-hot replay: train labels, then exemplar labels (a launcher, not torch.cat: recordable, no allocation)
+                labs = self.buf("labs_cat", (n_train + n_ex,), torch.int32)
+                call("ader_concat_i32", ptr(pos), n_train, ptr(ex_pos), n_ex, ptr(labs), st)
             self._lists_async(seq, labs, N)
         A = self._act
         emb = self._pp["emb"]

@@ -69,6 +69,20 @@ class _Drop:
         return (self._ref,)
 
 
+# input slots of a native launch plan (plan.py; include/ader_hip.h: ader_step_enqueue `inputs`)
+IN_SEQ, IN_POS, IN_EXPOS, IN_EXTROW, IN_TEACHER, IN_LR, IN_IDX_T, IN_IDX_E, N_INPUTS = range(9)
+
+
+class StepF(float):
+    """A float launcher argument that changes from step to step (Adam's lr_t): the plan recorder patches it from input `slot`."""
+    __slots__ = ("slot",)
+
+    def __new__(cls, v, slot):
+        o = float.__new__(cls, v)
+        o.slot = slot
+        return o
+
+
 class SectionTimer:
     """HIP-event timing of named launch groups on the stream the kernels are launched on (bench.py roofline leg).
     Events are recorded around each section; elapsed times are read back after a sync with collect()."""
@@ -173,8 +187,9 @@ def side_stream(device, main):
         for pr in (-1, 0):
             for _ in range(4):
                 s = torch.cuda.Stream(device=dev, priority=pr)
-                for rep in range(2):                              # (first pass: the runtime creates the hardware queue)
-                    torch.cuda.synchronize(dev)
+                lats = []
+                for rep in range(4):                              # (first pass: the runtime creates the hardware queue; then the
+                    torch.cuda.synchronize(dev)                   #  median of three host-timed samples -- one alone is noisy)
                     t0 = _time.perf_counter()
                     for i in range(24 if rep else 4):
                         x.add_(1.0)
@@ -183,7 +198,9 @@ def side_stream(device, main):
                             y.add_(1.0)
                         main.wait_stream(s)
                     torch.cuda.synchronize(dev)
-                    lat = (_time.perf_counter() - t0) / 24
+                    if rep:
+                        lats.append((_time.perf_counter() - t0) / 24)
+                lat = sorted(lats)[1]
                 for i in range(6):
                     big.add_(1.0)
                 ev_m.record(main)

@@ -206,7 +206,8 @@ class _Forward:
         """input_seq of a public entry point -> int32 device tensor.  A batch that arrives from the host (the reference-style feed
         dict) shows "auto" packing its density: the fraction of real positions."""
         if isinstance(seq, torch.Tensor):
-            self._density_now = None
+            if not self._keep_density:         # (a step being recorded re-enters with the device copy of a batch whose density is known)
+                self._density_now = None
         else:
             a = np.asarray(seq)
             self._density_now = float(np.count_nonzero(a)) / max(a.size, 1)

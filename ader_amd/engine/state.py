@@ -9,7 +9,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, ptr
-from .common import _NULL, _check, param_layout
+from .common import _NULL, _check, param_layout, side_stream
 
 
 class _State:
@@ -67,6 +67,13 @@ class _State:
         self.late_side_stream = True       # small-parameter gradients / Adam run beside the (HBM-bound) fused table update
         self._late, self._late_on, self._late_force = [], False, False
         self._st_ptr, self._main, self._in_step = None, None, False
+        self._side, self._side_for = None, None
+        # native step driver (plan.py): steps of a plannable form are recorded once per (shape, mode) and replayed by one C call
+        self.native_step = os.environ.get("ADER_NATIVE_STEP", "1") != "0"
+        self.plan_verify = False           # tests: every replayable step runs through Python again and is compared with its plan
+        self.plan_hits = self.plan_misses = self.plan_verified = 0
+        self.plan_errors = []
+        self._plans, self._plans_gen, self._keep_density, self._held, self._density_now = None, -1, False, None, None
         self._pin = {}
         self.atb_batch = True          # x3 mode: all weight-gradient products of a backward pass in one launch
         self._atb_q = []
@@ -288,6 +295,28 @@ class _State:
 
     def _sec(self, name):
         return self.timer.section(name) if self.timer is not None else _NULL
+
+    def _side_lane(self):
+        """The engine's second lane for the CURRENT main stream (common.side_stream probes the hardware queues once per (device, main
+        stream) of the process; resolved again when the caller moves the engine to another main stream)."""
+        m = self._main
+        if self._side is None or (self._side_for is not None and self._side_for != m.cuda_stream):      # (a lane set by hand stays)
+            self._side, self._side_for = side_stream(self.device, m), m.cuda_stream
+        return self._side
+
+    def warm_up(self):
+        """Everything a first train step would otherwise do inside the step (and inside a timed region): the side-stream probe -- a
+        64 MB scratch tensor, eight streams and ~16 device synchronisations."""
+        self._refresh_stream()
+        self._side_lane()
+        return self
+
+    def _edge(self, waiter, other):
+        """Stream `waiter` waits for everything enqueued on stream `other` so far (an event edge; recorded into a launch plan)."""
+        waiter.wait_stream(other)
+        rec = _lib.recorder
+        if rec is not None:
+            rec.wait(waiter.cuda_stream, other.cuda_stream)
 
     def _dev_i32(self, x):
         """int32 device tensor of a host array / tensor.  Host arrays go through a small ring of pinned staging buffers and an

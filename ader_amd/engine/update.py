@@ -3,12 +3,14 @@ import numpy as np
 import torch
 
 from .._lib import call, ptr
-from .common import side_stream
+from .common import IN_LR, StepF
 
 
 class _Update:
     def _lr_t(self, lr):
-        return float(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
+        """Adam's step size lr * sqrt(1 - beta2^t) / (1 - beta1^t) in float32 (tf.train.AdamOptimizer; the one launcher argument that
+        changes every step: marked for the launch-plan recorder)."""
+        return StepF(np.float32(lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p), IN_LR)
 
     def _advance_adam(self):
         self.refresh_weights()
@@ -59,9 +61,7 @@ class _Update:
         if not self.lists_side_stream:
             self._lists = self._sparse_lists(seq, lab, N)
             return
-        if getattr(self, "_side", None) is None:
-            self._side = side_stream(self.device, main)
-        self._side.wait_stream(main)         # inputs ready; also orders reuse of last step's list memory after its reader
+        self._edge(self._side_lane(), main)      # inputs ready; also orders reuse of last step's list memory after its reader
         with self._OnStream(self, self._side):
             self._lists = self._sparse_lists(seq, lab, N)
         self._lists_seq = (seq, lab)         # keep the inputs alive until the side stream has consumed them
@@ -69,7 +69,7 @@ class _Update:
     def _lists_wait(self):
         out, self._lists = self._lists, None
         if self.lists_side_stream:
-            self._main.wait_stream(self._side)       # (the lists live in persistent workspace buffers: no record_stream needed)
+            self._edge(self._main, self._side)       # (the lists live in persistent workspace buffers: no record_stream needed)
         return out
 
     def _fused_table_adam(self, lr):
@@ -105,9 +105,7 @@ class _Update:
             # it: on the small catalogs of the shipped datasets the host is only a launch or two ahead of the GPU, and with the eight
             # small launches enqueued first the update reached the queue 100 us after the backward chain had finished
             # (profiles/r5_packed/timeline_cfgY_update_late.txt)
-            if getattr(self, "_side", None) is None:
-                self._side = side_stream(self.device, main)
-            self._side.wait_stream(main)
+            self._edge(self._side_lane(), main)
         with self._sec("logits_bwd_adam"):
             if self.lx3:        # operand rows as the LDS images k_tab16x3 streams by LDS-DMA
                 img = self.buf("lbf_rep_img", (call("ader_x3_rep_image_bytes", D["Bp"]),), torch.uint8, zero=True)
@@ -146,7 +144,7 @@ class _Update:
         if overlap:
             with self._OnStream(self, self._side):
                 small_update()
-            main.wait_stream(self._side)
+            self._edge(main, self._side)
         else:
             small_update()
         self._deferred = None
@@ -157,7 +155,8 @@ class _Update:
         self._refresh_stream()
         self._in_step = True
         try:
-            return self._train_step(seq, pos, max_item, lr, **kw)
+            out = self._native_step(seq, pos, max_item, lr, kw)        # one C call per step when a launch plan exists (plan.py)
+            return out if out is not None else self._train_step(seq, pos, max_item, lr, **kw)
         finally:
             self._in_step = False
 

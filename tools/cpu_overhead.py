@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ader_amd.engine import Engine
 from bench import synth_batch
-# usage: cpu_overhead.py [cfgS|cfgY|cfgD] [pack: on|off]
+# usage: cpu_overhead.py [cfgS|cfgY|cfgD] [pack: on|off] [driver: native|python]
 w = sys.argv[1] if len(sys.argv) > 1 else "cfgS"
 N, B, E, regime = {"cfgS": (1_000_000, 512, 0, "dense"), "cfgY": (25750, 512, 102, "realistic"), "cfgD": (43105, 256, 143, "realistic")}[w]
 T = 50
@@ -12,6 +12,8 @@ dev = torch.device("cuda", 0)
 eng = Engine(N, maxlen=T, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device=dev)
 eng.pack_sessions = len(sys.argv) > 2 and sys.argv[2] == "on"
 eng.pack_density = 0.1
+eng.native_step = not (len(sys.argv) > 3 and sys.argv[3] == "python")
+eng.warm_up()
 batches = [synth_batch(B + E, T, N, 1000 * s, dev, regime) for s in range(4)]
 kw = {}
 if E:
@@ -31,6 +33,7 @@ for K in (4, 8):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print("K=%d  host enqueue %.3f ms/step   total %.3f ms/step" % (K, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3))
+print("plan hits %d, misses %d, errors %s" % (eng.plan_hits, eng.plan_misses, eng.plan_errors))
 import cProfile, pstats, io
 pr = cProfile.Profile(); pr.enable()
 for i in range(200):
