@@ -224,7 +224,7 @@ class Sampler:
         offs = np.concatenate([[0], np.cumsum(keep)])[bounds]
         flat = perm[keep]
         dev = torch.from_numpy(flat).to(self._seq_dev.device)
-        self._epoch = (flat, offs, dev, dev.to(torch.int32))
+        self._epoch = (flat, offs.tolist(), dev, dev.to(torch.int32))
 
     # -- reference surface
     def label_generator(self, session):
@@ -281,6 +281,22 @@ class Sampler:
         idx_dev = dev[o0:o1]
         self.last_idx_dev = dev32[o0:o1]            # the same row indices as an int32 device tensor (e.g. teacher rows of the batch)
         return self._seq_dev.index_select(0, idx_dev), self._lab_dev.index_select(0, idx_dev), flat[o0:o1]
+
+    def next_index_slice(self):
+        """Device-resident feeder without the gather: (idx, offset, count) -- the next batch is rows idx[offset : offset + count] of
+        the packed rows `rows_dev()` (idx: the epoch's int64 index array on the device, the shuffled order with the invalid rows
+        dropped per batch).  Same batch sequence and `random` stream as next_batch(); the gather itself belongs to the consumer
+        (Engine.train_step_fed cuts the step's inputs from it in one launch)."""
+        if self._epoch is None:
+            self._plan_epoch()
+        _, offs, dev, _ = self._epoch
+        o0, o1 = offs[self.batch_counter], offs[self.batch_counter + 1]
+        self._advance()
+        return dev, o0, o1 - o0
+
+    def rows_dev(self):
+        """The packed rows [n, maxlen+1] int32 on the device (after to_device())."""
+        return self._rows_dev
 
     def next_batch(self):
         """Fast path: (seq [b, maxlen] int32, pos [b] int32), contiguous; numpy arrays, or device tensors after to_device()."""

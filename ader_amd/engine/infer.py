@@ -101,7 +101,7 @@ class _Infer:
         """Segmented herding over label groups (util.py:436-461).  seq_rows [n,T] candidates in group order, offs [G+1],
         quota [G] = min(m, n_g).  Returns (sel [n] local indices per group span, sel_cnt [G]) as numpy."""
         self._refresh_stream()
-        from .exemplar import herding_max_steps
+        from ..exemplar import herding_max_steps
         rep = self.encode(seq_rows)
         n, G = rep.shape[0], len(quota)
         seg = torch.as_tensor(np.asarray(offs, dtype=np.int64)).to(self.device)

@@ -57,6 +57,8 @@ _BUILD_FLAGS = (
     ("device_feed", True, bool, "keep the packed training rows on the GPU and gather batches there"),
     ("eval_batch", 1024, int, "rows per evaluation launch (results do not depend on it)"),
     ("pack_sessions", "auto", str, ("auto", "on", "off")),
+    ("fed_steps", True, bool, "single GPU with --device_feed and --fixed_batches: the batch is cut on the GPU by the step's first launch "
+                              "and the step is one native call (Engine.train_step_fed); False: batches assembled by torch, as data-parallel runs do"),
     ("fixed_batches", True, bool, "pad every train / exemplar batch to its nominal row count with weight-0 rows: the feeder drops "
                                   "invalid sub-sequences, so the row count wanders by a few rows from step to step (251..256 on "
                                   "DIGINETICA) and every new count re-allocates and clears the engine's ~45 activation buffers"),
@@ -174,7 +176,20 @@ def run(args, log=print):
                 model.engine.init_params(args.random_seed)              # global_variables_initializer, main.py:213
             best_epoch, stop_counter, period_best = 1, 0, None
             for epoch in range(1, args.num_epochs + 1):
-                for _ in range(batch_num):
+                # device-fed steps: the batch (train rows, padding, exemplar rows) is cut on the GPU from the Samplers' resident rows by
+                # the step's first launch and the whole step is one native call (Engine.train_step_fed) -- same batches, same padding,
+                # same dropout counters as the branch below, which stays for data-parallel runs, the EWC baseline and host-fed batches
+                fed = bool(args.fed_steps and args.device_feed and world == 1 and args.fixed_batches and not args.ewc)
+                for _ in range(batch_num if fed else 0):
+                    idx_t, o_t, n_t = train_sampler.next_index_slice()
+                    if use_ex:
+                        idx_e, o_e, n_e = exemplar_sampler.next_index_slice()
+                        feed = (train_sampler.rows_dev(), idx_t, o_t, n_t, train_sampler.batch_size,
+                                exemplar_sampler.rows_dev(), idx_e, o_e, n_e, exemplar_sampler.batch_size)
+                    else:
+                        feed = (train_sampler.rows_dev(), idx_t, o_t, n_t, train_sampler.batch_size, None, None, 0, 0, 0)
+                    model.train_step_fed(feed, max_item, args.lr, args.dropout_rate, teacher=store.logits if use_ex else None)
+                for _ in range(0 if fed else batch_num):
                     seq, pos = train_sampler.next_batch()
                     kw = {}
                     if world > 1:

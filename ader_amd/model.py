@@ -58,6 +58,16 @@ class Ader:
             return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, ex_pos=ex_pos, lambda_=self._lambda, **kw)
         return e.train_step(seq, pos, max_item, lr, rate=dropout_rate, teacher=teacher, ex_trow=ex_trow, lambda_=self._lambda, **kw)
 
+    def train_step_fed(self, feed, max_item, lr, dropout_rate, teacher=None):
+        """One optimisation step whose batch the engine cuts on the device from the Samplers' GPU-resident rows (Engine.train_step_fed;
+        feed as described there).  The loss follows set_vanilla_loss / update_loss like train_step."""
+        e = self.engine
+        if self._loss_mode == "vanilla":
+            return e.train_step_fed(feed, max_item, lr, dropout_rate)
+        if self._loss_mode == "onehot":
+            return e.train_step_fed(feed, max_item, lr, dropout_rate, lambda_=self._lambda, onehot=True)
+        return e.train_step_fed(feed, max_item, lr, dropout_rate, teacher=teacher, lambda_=self._lambda)
+
     def encode(self, seq):
         return self.engine.encode(seq)
 

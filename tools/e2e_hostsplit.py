@@ -26,6 +26,10 @@ def wrap(cls, name, cat):
 wrap(D.Sampler, "next_batch", "next_batch")
 wrap(D.Sampler, "next_exemplar_batch", "next_exemplar_batch")
 wrap(MD.Ader, "train_step", "train_step (host enqueue)")
+wrap(MD.Ader, "train_step_fed", "train_step_fed (host enqueue)")
+wrap(D.Sampler, "next_index_slice", "next_index_slice")
+wrap(D.Sampler, "to_device", "Sampler.to_device")
+wrap(D.Sampler, "add_exemplar", "Sampler.add_exemplar")
 wrap(D.Evaluator, "evaluate", "evaluate")
 wrap(D.Sampler, "_repack", "sampler repack")
 wrap(D.Sampler, "__init__", "Sampler.__init__ (incl. repack)")

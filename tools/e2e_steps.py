@@ -16,6 +16,15 @@ def ts(self, *a, **k):
 
 
 MD.Ader.train_step = ts
+_tsf = MD.Ader.train_step_fed
+
+
+def tsf(self, *a, **k):
+    cnt["steps"] += 1
+    return _tsf(self, *a, **k)
+
+
+MD.Ader.train_step_fed = tsf
 _ev = D.Evaluator.evaluate
 
 
