@@ -79,6 +79,7 @@ _SIGS = {
     "ader_host_shuffle": [P, P, L],
     "ader_host_pack_rows": [P, P, L, I, P, P],
     "ader_host_prefix_rows": [P, P, L, I, P, P],
+    "ader_host_pack_rows_at": [P, L, P, P, L, I, P, P],
     "ader_x3_rep_image_bytes": [I],
     "ader_x3_update_pair_min_tiles": [I],
     "ader_x3_rep_image": [P, P, I, P, P],

@@ -68,6 +68,27 @@ int ader_host_pack_rows(const int32_t* flat, const int64_t* lens, int64_t n, int
     return 0;
 }
 
+// ... of sessions given as (start, length) pairs into a shared flat item array of flat_n items (ader_amd/data.py: PackedSessions -- a
+// prefix of a session is the same start with a shorter length, a split is a gather of pairs; no item is copied before the rows are cut).
+int ader_host_pack_rows_at(const int32_t* flat, int64_t flat_n, const int64_t* starts, const int64_t* lens, int64_t n, int maxlen,
+                           int32_t* rows, unsigned char* valid) {
+    if (n < 0 || maxlen < 1 || flat_n < 0 || (n > 0 && (!starts || !lens || !rows || !valid)) || (flat_n > 0 && !flat)) return -2;
+    const int64_t w = (int64_t)maxlen + 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t L = lens[i], at = starts[i];
+        if (L < 0 || at < 0 || at + L > flat_n) return -2;
+        valid[i] = L > 1;
+        if (L > 1) {
+            const int64_t k = (L - 1 < maxlen) ? L - 1 : maxlen;
+            const int32_t* src = flat + at + (L - 1 - k);
+            int32_t* dst = rows + i * w + (maxlen - k);
+            for (int64_t j = 0; j < k; ++j) dst[j] = src[j];
+            rows[i * w + maxlen] = flat[at + L - 1];
+        }
+    }
+    return 0;
+}
+
 // ... of every session AND its prefixes down to length 2 (util.py:138-143: a session of length L yields itself, then s[:L-1], ...,
 // s[:2]), in that order, straight from the flat item array -- the prefix lists themselves are not built (an evaluator needs only the
 // rows).  rows [sum_i max(1, lens[i] - 1)][maxlen + 1] ZERO on entry; valid one byte per row.

@@ -15,10 +15,116 @@ import itertools
 import math
 import os
 import random
+from collections.abc import Mapping, Sequence
 
 import numpy as np
 
 _DATA_ROOT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+# --------------------------------------------------------------------------------------- PackedSessions
+class PackedSessions(Sequence):
+    """A list of sessions (lists of item ids) held as arrays: one flat int32 item array and, per session, (start, length) into it.
+
+    The reference hands Python lists of lists from stage to stage -- DataLoader -> Sampler (prefix expansion, util.py:138-143) ->
+    split_data (util.py:188-216) -> exemplar candidates -> ExemplarGenerator (regrouped by label, util.py:382-393) -- and every stage
+    walks them element by element.  This is the same sequence surface (len, indexing, iteration, extend, ==; an element is a plain
+    list when somebody asks for one) over arrays, so the stages above run as array operations: a prefix of a session is the same
+    start with a shorter length (no copy), a split is a fancy index of (start, length), and the packed rows of the feeders are cut
+    from the flat array in native code (ader_host_pack_rows_at)."""
+    __slots__ = ("flat", "starts", "lens")
+
+    def __init__(self, flat, starts, lens):
+        self.flat = np.ascontiguousarray(flat, dtype=np.int32)
+        self.starts = np.ascontiguousarray(starts, dtype=np.int64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.int64)
+
+    # -- construction
+    @classmethod
+    def from_counts(cls, flat, counts):
+        """Sessions stored back to back in `flat`, `counts[i]` items each."""
+        counts = np.asarray(counts, dtype=np.int64)
+        starts = np.zeros(len(counts), dtype=np.int64)
+        if len(counts) > 1:
+            np.cumsum(counts[:-1], out=starts[1:])
+        return cls(flat, starts, counts)
+
+    @classmethod
+    def from_lists(cls, sessions):
+        if isinstance(sessions, PackedSessions):
+            return cls(sessions.flat, sessions.starts, sessions.lens)
+        sessions = sessions if isinstance(sessions, (list, tuple)) else list(sessions)
+        n = len(sessions)
+        lens = np.fromiter(map(len, sessions), dtype=np.int64, count=n)
+        flat = np.fromiter(itertools.chain.from_iterable(sessions), dtype=np.int32, count=int(lens.sum()))
+        return cls.from_counts(flat, lens)
+
+    @classmethod
+    def from_rows(cls, rows):
+        """Sessions of packed rows [n, maxlen+1] in the reference's stored form (util.py:433): the non-zero inputs, then the label."""
+        rows = np.asarray(rows)
+        nz = rows != 0
+        return cls.from_counts(rows[nz], nz.sum(axis=1))
+
+    # -- the sequence surface
+    def __len__(self):
+        return len(self.starts)
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            s = int(self.starts[i])
+            return self.flat[s:s + int(self.lens[i])].tolist()
+        if isinstance(i, slice):
+            return PackedSessions(self.flat, self.starts[i], self.lens[i])
+        return self.take(i)
+
+    def __iter__(self):
+        flat = self.flat
+        for s, n in zip(self.starts.tolist(), self.lens.tolist()):
+            yield flat[s:s + n].tolist()
+
+    def __eq__(self, other):
+        if isinstance(other, PackedSessions):
+            other = other.tolist()
+        return isinstance(other, (list, tuple)) and self.tolist() == list(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "PackedSessions(%d sessions, %d items)" % (len(self), int(self.lens.sum()))
+
+    def tolist(self):
+        return list(iter(self))
+
+    def take(self, idx):
+        """The sessions idx[0], idx[1], ... (no item is copied)."""
+        idx = np.asarray(idx)
+        return PackedSessions(self.flat, self.starts[idx], self.lens[idx])
+
+    def extend(self, other):
+        """list.extend: in place.  Sessions over the same flat array are appended without copying an item."""
+        if not isinstance(other, PackedSessions):
+            other = PackedSessions.from_lists(other)
+        if len(other) == 0:
+            return
+        if other.flat is self.flat:
+            shift = 0
+        else:
+            shift = len(self.flat)
+            self.flat = np.concatenate([self.flat, other.flat])
+        self.starts = np.concatenate([self.starts, other.starts + shift])
+        self.lens = np.concatenate([self.lens, other.lens])
+
+    def prefixes(self):
+        """Every session followed by its prefixes down to length 2 (the Sampler's expansion, util.py:138-143): a session of length l
+        gives lengths l, l-1, ..., 2 (itself alone when l <= 2)."""
+        counts = np.maximum(self.lens - 1, 1)
+        rep = np.repeat(np.arange(len(self), dtype=np.int64), counts)
+        first = np.zeros(len(self), dtype=np.int64)
+        if len(self) > 1:
+            np.cumsum(counts[:-1], out=first[1:])
+        k = np.arange(int(counts.sum()), dtype=np.int64) - first[rep]
+        return PackedSessions(self.flat, self.starts[rep], self.lens[rep] - k)
 
 
 # --------------------------------------------------------------------------------------- DataLoader
@@ -55,9 +161,10 @@ class DataLoader:
 
     @staticmethod
     def _group(sess, item):
-        """Sessions in first-appearance order, items in file order (dict insertion order, util.py:42-52)."""
+        """Sessions in first-appearance order, items in file order (dict insertion order, util.py:42-52), as a PackedSessions
+        (a sequence of lists held as arrays)."""
         if len(sess) == 0:
-            return []
+            return PackedSessions.from_counts(np.zeros(0, np.int32), np.zeros(0, np.int64))
         uniq, first, inv = np.unique(sess, return_index=True, return_inverse=True)
         order_of_group = np.argsort(first, kind="stable")          # groups by first appearance
         rank = np.empty_like(order_of_group)
@@ -65,12 +172,7 @@ class DataLoader:
         g = rank[inv]
         idx = np.argsort(g, kind="stable")                          # stable: keeps file order in a group
         counts = np.bincount(g, minlength=len(uniq))
-        items_sorted = item[idx]
-        out, p = [], 0
-        for c in counts:
-            out.append(items_sorted[p:p + c].tolist())
-            p += c
-        return out
+        return PackedSessions.from_counts(item[idx], counts)
 
     def train_loader(self, period):
         sess, item = self._read(period)
@@ -92,8 +194,9 @@ class DataLoader:
         # (items that survive are already members of item_set: util.py:84-85 adds nothing new)
         sessions = self._group(sess, item)
         if self.is_remove_item:
-            removed_num += sum(1 for s in sessions if len(s) == 1)
-            sessions = [s for s in sessions if len(s) != 1]
+            single = sessions.lens == 1
+            removed_num += int(single.sum())
+            sessions = sessions.take(np.flatnonzero(~single))
         info = ('Test set information: original total number of action: %d, removed number of action: %d.'
                 % (total_num, removed_num))
         return sessions, info
@@ -129,6 +232,12 @@ def pack_rows(sessions, maxlen):
     n = len(sessions)
     rows = np.zeros((n, maxlen + 1), dtype=np.int32)
     valid = np.zeros(n, dtype=bool)
+    if isinstance(sessions, PackedSessions):
+        if n:
+            from . import _lib
+            _lib.call("ader_host_pack_rows_at", sessions.flat.ctypes.data, len(sessions.flat), sessions.starts.ctypes.data, sessions.lens.ctypes.data, n,
+                      int(maxlen), rows.ctypes.data, valid.ctypes.data)
+        return rows, valid
     if n >= 512:
         from . import _lib
         lens = np.fromiter(map(len, sessions), dtype=np.int64, count=n)
@@ -159,6 +268,12 @@ class Sampler:
         if packed is not None:
             self.prepared_data = packed[0]
             self._repack(packed[1], packed[2])
+            return
+        if isinstance(data, PackedSessions):
+            # array data plane: the prefix expansion is (start, shorter length) pairs over the same flat item array, the rows are
+            # cut from it in native code; no list is built (the same rows, order and shuffle as the list path below)
+            self.prepared_data = data[:] if is_subseq else data.prefixes()
+            self._repack()
             return
         if rows_only and not is_subseq and len(data) >= 512:
             # an evaluator reads only the packed rows: they are cut for every session and its prefixes straight from the flat item
@@ -232,7 +347,23 @@ class Sampler:
         return rows[0, :self.maxlen].copy(), np.array(session[-1], dtype=np.int32)
 
     def add_exemplar(self, exemplar):
-        """exemplar: iterable of [session, teacher_logits] (util.py:173-186)."""
+        """exemplar: iterable of [session, teacher_logits] (util.py:173-186), or an ExemplarStore -- its packed rows ARE the rows of
+        its sessions (a stored session is the row's non-zero inputs and label), so nothing is unpacked and packed again; the teacher
+        logits stay the store's [E, N] tensor."""
+        if hasattr(exemplar, "rows") and hasattr(exemplar, "logits"):
+            rows = np.ascontiguousarray(np.asarray(exemplar.rows), dtype=np.int32)
+            assert rows.ndim == 2 and rows.shape[1] == self.maxlen + 1
+            if not isinstance(self.prepared_data, PackedSessions):
+                self.prepared_data = PackedSessions.from_lists(self.prepared_data)
+            n0 = len(self.prepared_data)
+            self.prepared_data.extend(PackedSessions.from_rows(rows))
+            self.logits = exemplar.logits
+            if n0:
+                old_rows, old_valid = pack_rows(self.prepared_data[:n0], self.maxlen)
+                rows = np.concatenate([old_rows, rows])
+            valid = (rows[:, self.maxlen] != 0) & (rows[:, self.maxlen - 1] != 0)      # a label and at least one input
+            self._repack(rows, valid)
+            return
         self.logits = []
         for session, logits in exemplar:
             self.prepared_data.append(session)
@@ -244,8 +375,11 @@ class Sampler:
         sidx = np.arange(n, dtype='int32')
         np.random.shuffle(sidx)
         n_train = int(np.round(n * (1. - valid_portion)))
-        valid_data = [self.prepared_data[s] for s in sidx[n_train:]]
-        train_data = [self.prepared_data[s] for s in sidx[:n_train]]
+        if isinstance(self.prepared_data, PackedSessions):
+            valid_data, train_data = self.prepared_data.take(sidx[n_train:]), self.prepared_data.take(sidx[:n_train])
+        else:
+            valid_data = [self.prepared_data[s] for s in sidx[n_train:]]
+            train_data = [self.prepared_data[s] for s in sidx[:n_train]]
         self.prepared_data = train_data
         self._repack(self._rows[sidx[:n_train]], self._valid[sidx[:n_train]])       # (a row depends on its own session only)
         return (valid_data, train_data) if return_train else valid_data
@@ -374,6 +508,12 @@ class Evaluator:
                 Evaluator._packed.pop(next(iter(Evaluator._packed)))
             Evaluator._packed[key] = (data, (smp.prepared_data, smp._rows, smp._valid))
 
+    @classmethod
+    def clear_cache(cls):
+        """Drop the packed rows kept between evaluators (main.py: at the start of every period -- the previous period's validation
+        and test lists are not held alive).  A cached list must not be mutated in place between two evaluators built from it."""
+        cls._packed.clear()
+
     def evaluate(self, epoch):
         rank, world = self.shard
         fast = getattr(self.model, "rank_targets", None)
@@ -415,28 +555,55 @@ def load_exemplars(exemplar_pre):
     return out
 
 
+class LabelGroups(Mapping):
+    """{label: [n_label, maxlen+1] int32 rows} in the order the labels are first visited, held as ONE row matrix (groups back to
+    back) + offsets: what ExemplarGenerator keeps per period (util.py:382-393 builds a dict of lists of sessions).  A mapping like the
+    dict it replaces; `rows`, `labels`, `offs` serve the selectors without re-concatenating ~10^4 slices."""
+
+    def __init__(self, labels, offs, rows):
+        self.labels, self.offs, self.rows = labels, offs, rows
+        self._at = None
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __iter__(self):
+        return iter(self.labels.tolist())
+
+    def __getitem__(self, label):
+        if self._at is None:
+            self._at = {k: i for i, k in enumerate(self.labels.tolist())}
+        i = self._at[int(label)]
+        return self.rows[self.offs[i]:self.offs[i + 1]]
+
+    @property
+    def sizes(self):
+        return np.diff(self.offs)
+
+
 def group_by_label(data, batch_size, maxlen):
     """Bucket candidate sub-sequences by label in the reference's visiting order
     (ExemplarGenerator.__init__, util.py:382-393): batches drawn from a shuffled is_subseq Sampler.
-    Returns (order of labels, {label: [n_label, maxlen+1] int32 rows}, item frequency dict)."""
+    Returns a LabelGroups: {label: [n_label, maxlen+1] int32 rows}, labels in the order of their first appearance, the rows of a label
+    in visiting order."""
     smp = Sampler(data, maxlen, batch_size, is_subseq=True)
     # One pass over the batches of the shuffled Sampler == its shuffled order with the invalid rows dropped; the pass ends with the
-    # Sampler's reshuffle (Sampler._advance), which the `random` stream sees and is therefore made here too.  Grouping: labels in the
-    # order of their first appearance, the rows of a label in visiting order (a stable sort), one gather for all rows.
+    # Sampler's reshuffle (Sampler._advance), which the `random` stream sees and is therefore made here too.  Grouping: a stable sort
+    # by label, the groups then ordered by the position of their first row; ONE gather for all rows.
     n_batches = smp.batch_num()
     order = smp._perm[smp._valid[smp._perm]] if len(smp._perm) else smp._perm
     if n_batches > 0:
         shuffle_like_python(smp._perm)
     if len(order) == 0:
-        return {}
+        return LabelGroups(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros((0, maxlen + 1), np.int32))
     labels = smp._rows[order, maxlen]
     o = np.argsort(labels, kind="stable")
     sl = labels[o]
     starts = np.flatnonzero(np.concatenate([[True], sl[1:] != sl[:-1]]))
     ends = np.concatenate([starts[1:], [len(sl)]])
-    first_seen = o[starts]                                    # position in `order` of each label's first row
-    rows_sorted = smp._rows[order[o]]
-    out = {}
-    for g in np.argsort(first_seen, kind="stable").tolist():
-        out[int(sl[starts[g]])] = rows_sorted[starts[g]:ends[g]]
-    return out
+    gs = np.argsort(o[starts], kind="stable")                 # groups by the position in `order` of their first row
+    sizes = (ends - starts)[gs]
+    offs = np.zeros(len(gs) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offs[1:])
+    pick = np.repeat(starts[gs] - offs[:-1], sizes) + np.arange(len(sl), dtype=np.int64)      # sorted positions, group after group
+    return LabelGroups(sl[starts[gs]].astype(np.int64), offs, smp._rows[order[o[pick]]])

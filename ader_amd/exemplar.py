@@ -18,8 +18,11 @@ def draw_quotas(groups, exemplar_size, disable_m, max_item):
     """Per-item exemplar quotas (util.py:393-399): multinomial(m, freq/sum(freq)) on numpy's legacy
     global RNG; `disable_m` (--equal_exemplar) uses uniform probabilities over all max_item items."""
     item_count = np.zeros(max_item)
-    for label, rows in groups.items():
-        item_count[label - 1] += len(rows)
+    if isinstance(groups, _data.LabelGroups):
+        item_count[groups.labels - 1] += groups.sizes
+    else:
+        for label, rows in groups.items():
+            item_count[label - 1] += len(rows)
     if disable_m:
         item_count = np.ones_like(item_count)
     item_prob = item_count / item_count.sum()
@@ -48,8 +51,9 @@ class ExemplarStore:
         return int(self.rows.shape[0])
 
     def sessions(self):
-        """Sessions in the reference's stored form: non-zero inputs followed by the label (util.py:433)."""
-        return [r[r != 0].tolist() for r in np.asarray(self.rows)]
+        """Sessions in the reference's stored form: non-zero inputs followed by the label (util.py:433) -- as a PackedSessions (a
+        sequence of lists held as arrays: what main.py hands on as the next period's exemplar candidates)."""
+        return _data.PackedSessions.from_rows(self.rows)
 
     # The reference keeps the exemplars in memory only (main.py:312): a crash loses them.  Here they can be written next to
     # the period's checkpoint and read back (rows + teacher logits + the catalog size they were computed for).
@@ -84,7 +88,7 @@ class ExemplarGenerator:
 
     def __init__(self, data, exemplar_size, disable_m, batch_size, maxlen, dropout_rate, max_item, shard=(0, 1)):
         self.shard = shard          # (rank, world): label groups are independent herding units
-        self.exemplars = defaultdict(list)
+        self._exemplars, self._view = defaultdict(list), None
         self.m = exemplar_size
         self.max_item = max_item
         self.maxlen = maxlen
@@ -93,13 +97,28 @@ class ExemplarGenerator:
         self.item_count = draw_quotas(self.sess_by_item, exemplar_size, disable_m, max_item)
         self.store = None
 
+    @property
+    def exemplars(self):
+        """{item: [[session, logits_row], ...]} -- the reference's `fast_exemplar` (util.py:433), built from the store when somebody
+        asks for it (main.py hands the store itself to the next period: ~30k small lists per period are not built to be re-packed)."""
+        if self._view is not None:
+            labels, counts, sel_rows, logits = self._view
+            self._view = None
+            p = 0
+            for label, c in zip(labels, counts):
+                if c or label in self._keep_empty:
+                    self._exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
+                p += c
+        return self._exemplars
+
+    def _set_view(self, labels, counts, sel_rows, logits, keep_empty=False):
+        self._keep_empty = set(labels) if keep_empty else set()
+        self._view = (list(labels), [int(c) for c in counts], sel_rows, logits)
+
     def _segments(self):
-        labels = list(self.sess_by_item.keys())
-        sizes = np.array([len(self.sess_by_item[k]) for k in labels], dtype=np.int64)
-        offs = np.zeros(len(labels) + 1, dtype=np.int64)
-        offs[1:] = np.cumsum(sizes)
-        quota = np.array([min(int(self.item_count[k - 1]), int(n)) for k, n in zip(labels, sizes)], dtype=np.int32)
-        rows = np.concatenate([self.sess_by_item[k] for k in labels]) if labels else np.zeros((0, self.maxlen + 1), np.int32)
+        g = self.sess_by_item
+        labels, offs, rows = g.labels.tolist(), g.offs, g.rows
+        quota = np.minimum(self.item_count[g.labels - 1].astype(np.int64), g.sizes).astype(np.int32)
         return labels, offs, quota, rows
 
     def herding_selection(self, sess, model):
@@ -133,12 +152,8 @@ class ExemplarGenerator:
         sel_rows = rows[keep]
         logits = model.engine.teacher_logits(sel_rows[:, :self.maxlen], self.max_item)
         self.store = ExemplarStore(sel_rows, logits, self.max_item)
-        # reference-shaped view: {item: [[session, logits_row], ...]} -- logits rows are views of the store
-        p = 0
-        for g, label in enumerate(labels):
-            c = int(sel_cnt[g])
-            self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
-            p += c
+        # reference-shaped view {item: [[session, logits_row], ...]} (logits rows are views of the store): built on demand
+        self._set_view(labels, sel_cnt[:len(labels)], sel_rows, logits, keep_empty=True)
         return int(len(keep))
 
     def loss_selection(self, sess, model, first_only=False):
@@ -170,11 +185,7 @@ class ExemplarGenerator:
         sel_rows = rows[keep]
         logits = model.engine.teacher_logits(sel_rows[:, :self.maxlen], self.max_item)
         self.store = ExemplarStore(sel_rows, logits, self.max_item)
-        p = 0
-        for label, c in zip(labels, counts):
-            if c:
-                self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
-            p += c
+        self._set_view(labels, counts, sel_rows, logits)
         return int(len(keep))
 
     def randomly_selection(self, sess, model):
@@ -194,9 +205,5 @@ class ExemplarGenerator:
         sel_rows = rows[keep]
         logits = model.engine.teacher_logits(sel_rows[:, :self.maxlen], self.max_item)
         self.store = ExemplarStore(sel_rows, logits, self.max_item)
-        p = 0
-        for label, c in zip(labels, counts):
-            if c:
-                self.exemplars[label] = [[r[r != 0].tolist(), logits[p + i]] for i, r in enumerate(sel_rows[p:p + c])]
-            p += c
+        self._set_view(labels, counts, sel_rows, logits)
         return int(len(keep))

@@ -24,7 +24,7 @@ import time
 import numpy as np
 import torch
 
-from .data import DataLoader, Evaluator, Sampler, load_exemplars
+from .data import DataLoader, Evaluator, Sampler
 from .exemplar import ExemplarGenerator
 from .model import Ader, Ewc, Saver, Session
 
@@ -128,13 +128,13 @@ def run(args, log=print):
     t_start = time.time()
     MRR_20, Recall_20, MRR_10, Recall_10 = [], [], [], []
     best_state, store = None, None
-    fast_exemplar = {}
     saver = Saver(model)
     summary = []
     for period in periods:
         log('Period %d:' % period)
         logs.write('Period %d:\n' % period)
         best_performance, performance = 0, 0
+        Evaluator.clear_cache()
         train_sess, info = dataloader.train_loader(period - 1)
         logs.write(info + '\n')
         if args.joint and period > 1:
@@ -153,12 +153,13 @@ def run(args, log=print):
         max_item = dataloader.max_item()
         use_ex = period > 1 and not baseline
         if use_ex:
-            exemplar_data_logits = load_exemplars(fast_exemplar)
-            exemplar_size = len(exemplar_data_logits)
-            exemplar_subseq = [e[0] for e in exemplar_data_logits]
+            # (the reference flattens {item: [[session, logits], ...]} into a list, main.py:54-65,176-190; the store holds the same
+            #  exemplars in the same order as packed rows + one logits tensor, and the Sampler takes them as they are)
+            exemplar_size = len(store)
+            exemplar_subseq = store.sessions()
             exemplar_batch = int(exemplar_size / batch_num)             # main.py:187
             exemplar_sampler = Sampler([], args.maxlen, exemplar_batch)
-            exemplar_sampler.add_exemplar(exemplar_data_logits)
+            exemplar_sampler.add_exemplar(store)
             if args.device_feed:
                 exemplar_sampler.to_device(model.engine.device)
             if args.ewc or args.fix_lambda:                              # main.py:196
@@ -289,8 +290,7 @@ def run(args, log=print):
                 info = 'Total saved exemplar: %d' % saved_num
                 log(info)
                 logs.write(info + '\n')
-                fast_exemplar = exemplar.exemplars
-                store = exemplar.store
+                store = exemplar.store                                   # (exemplar.exemplars: the reference's {item: [[session, logits]]} view, on demand)
                 if args.save_ckpt and rank == 0:                         # (the reference keeps exemplars in memory only)
                     d = os.path.join(out_dir, 'model', 'period%d' % period)
                     os.makedirs(d, exist_ok=True)
@@ -298,7 +298,7 @@ def run(args, log=print):
                 del exemplar
             item_num_prev = max_item
             if args.ewc:                                                 # main.py:319-323: Fisher information for the next period
-                exemplar_subseq = [e[0] for e in load_exemplars(fast_exemplar)]
+                exemplar_subseq = store.sessions()
                 model.snapshot_variables()
                 random_exemplar = random.sample(exemplar_subseq, min(len(exemplar_subseq), args.ewc_sample_num))
                 model.compute_fisher(sess, random_exemplar, 50, max_item)

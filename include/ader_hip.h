@@ -526,6 +526,10 @@ int ader_host_shuffle(uint32_t* mt_state, int64_t* x, int64_t n);
 /* The Sampler's packed rows (util.py:161-169, 226-227) of n sessions given as one flat int32 item array + lens [n]: rows [n][maxlen+1]
  * (ZERO on entry) = up to the last maxlen inputs right-aligned, then the label; valid [n] bytes = session has at least 2 items. */
 int ader_host_pack_rows(const int32_t* flat, const int64_t* lens, int64_t n, int maxlen, int32_t* rows, unsigned char* valid);
+/* ... of n sessions given as (starts[i], lens[i]) into a shared flat item array of flat_n items (a prefix of a session = the same start
+ * with a shorter length; a split = a gather of pairs): the array data plane of ader_amd/data.py (PackedSessions). */
+int ader_host_pack_rows_at(const int32_t* flat, int64_t flat_n, const int64_t* starts, const int64_t* lens, int64_t n, int maxlen,
+                           int32_t* rows, unsigned char* valid);
 /* ... of every session and its prefixes down to length 2 (util.py:138-143), in the Sampler's order, without building the prefix lists:
  * rows [sum_i max(1, lens[i] - 1)][maxlen+1] (ZERO on entry), valid one byte per row. */
 int ader_host_prefix_rows(const int32_t* flat, const int64_t* lens, int64_t n, int maxlen, int32_t* rows, unsigned char* valid);

@@ -264,3 +264,94 @@ def test_published_curves_fixture():
     for ds in cur:
         r = {k: avg(v["recall20"]) for k, v in cur[ds].items()}
         assert r["ADER"] > r["Dropout"] > r["EWC"] > r["Finetune"]
+
+
+# ---------------------------------------------------------------------------------------- array data plane (PackedSessions)
+def _rand_sessions(rs, n, hi=30000, maxlen=70):
+    return [rs.randint(1, hi, size=rs.randint(0, maxlen)).tolist() for _ in range(n)] + [[], [5], [1, 2], [1, 2, 3]]
+
+
+def test_packed_sessions_is_a_list_of_lists():
+    """PackedSessions (flat item array + (start, length) per session) behaves as the list of lists the reference passes between its
+    stages (util.py:138-143, 188-216, 382-393): len, indexing, slicing, iteration, ==, extend, and the prefix expansion."""
+    rs = np.random.RandomState(0)
+    data = _rand_sessions(rs, 300)
+    ps = D.PackedSessions.from_lists(data)
+    assert len(ps) == len(data) and ps == data and list(ps) == data and ps.tolist() == data
+    assert ps[7] == data[7] and ps[-1] == data[-1] and ps[10:20] == data[10:20]
+    idx = rs.permutation(len(data))[:50]
+    assert ps.take(idx) == [data[i] for i in idx] and ps[idx] == [data[i] for i in idx]
+    expanded = []
+    for s in data:                                             # util.py:138-143
+        expanded.append(s)
+        for cut in range(1, len(s) - 1):
+            expanded.append(s[:len(s) - cut])
+    pre = ps.prefixes()
+    assert pre == expanded and pre.flat is ps.flat             # a prefix is a shorter length over the same items
+    a, b = ps.take(idx[:20]), ps.take(idx[20:])
+    a.extend(b)                                                # same flat array: nothing copied
+    assert a == [data[i] for i in idx] and a.flat is ps.flat
+    other = _rand_sessions(rs, 40)
+    a.extend(D.PackedSessions.from_lists(other))               # another flat array
+    a.extend(other[:3])                                        # plain lists
+    assert a == [data[i] for i in idx] + other + other[:3] and ps == data
+    rows, _ = D.pack_rows(data, 50)
+    want = [r[r != 0].tolist() for r in rows]
+    assert D.PackedSessions.from_rows(rows) == want
+    import random as _r
+    _r.seed(3)
+    x = _r.sample(ps, 17)
+    _r.seed(3)
+    assert x == _r.sample(data, 17)                            # (EWC: random.sample over the exemplar sessions, main.py:229)
+
+
+@pytest.mark.parametrize("is_subseq", [False, True])
+def test_sampler_over_packed_sessions_equals_the_list_sampler(is_subseq):
+    """Same rows, validity flags, shuffled order, batches, split and RNG streams whether the Sampler is given lists or a PackedSessions."""
+    rs = np.random.RandomState(5)
+    data = _rand_sessions(rs, 700)
+    out = []
+    for packed in (False, True):
+        random.seed(2)
+        np.random.seed(2)
+        sm = D.Sampler(D.PackedSessions.from_lists(data) if packed else data, 50, 64, is_subseq=is_subseq)
+        first = (sm._rows.copy(), sm._valid.copy(), sm.data_indices, sm.prepared_data if packed else list(sm.prepared_data))
+        valid, train = sm.split_data(0.1, return_train=True)
+        batches = [sm.next_batch() for _ in range(sm.batch_num() + 3)]
+        out.append((first, valid, train, sm._rows.copy(), sm.data_indices, batches, random.random(), np.random.rand()))
+    (fa, va, ta, ra, ia, ba, xa, ya), (fb, vb, tb, rb, ib, bb, xb, yb) = out
+    assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1]) and fa[2] == fb[2] and fb[3] == fa[3]
+    assert isinstance(vb, D.PackedSessions) and vb == va and tb == ta
+    assert np.array_equal(ra, rb) and ia == ib and (xa, ya) == (xb, yb)
+    for (sa, pa), (sb, pb) in zip(ba, bb):
+        assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
+
+
+def test_exemplar_store_feeds_the_sampler_like_the_flattened_list():
+    """Sampler.add_exemplar(store) (rows taken as they are) == add_exemplar([[session, logits], ...]) (util.py:173-186): same rows,
+    same shuffle, same batches; and group_by_label over PackedSessions == over lists."""
+    import torch
+    from ader_amd.exemplar import ExemplarStore
+    rs = np.random.RandomState(9)
+    sess = [s for s in _rand_sessions(rs, 400, hi=60) if len(s) >= 2]
+    rows, valid = D.pack_rows(sess, 50)
+    assert valid.all()
+    logits = torch.arange(len(sess) * 3, dtype=torch.float32).view(len(sess), 3)
+    store = ExemplarStore(rows, logits, 3)
+    assert store.sessions() == [r[r != 0].tolist() for r in rows]
+    got = []
+    for how in ("list", "store"):
+        random.seed(4)
+        sm = D.Sampler([], 50, 16)
+        sm.add_exemplar([[s, logits[i]] for i, s in enumerate(store.sessions())] if how == "list" else store)
+        b = [sm.next_exemplar_batch() for _ in range(sm.batch_num() + 2)]
+        got.append((sm._rows.copy(), sm._valid.copy(), sm.data_indices, b, random.random(), sm.exemplar_sampler()[2]))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]) and got[0][2] == got[1][2] and got[0][4] == got[1][4]
+    for (sa, pa, ia), (sb, pb, ib) in zip(got[0][3], got[1][3]):
+        assert np.array_equal(sa, sb) and np.array_equal(pa, pb) and np.array_equal(ia, ib)
+    assert all(torch.equal(x, y) for x, y in zip(got[0][5], got[1][5]))
+    groups = []
+    for packed in (False, True):
+        random.seed(1)
+        groups.append(D.group_by_label(D.PackedSessions.from_lists(sess) if packed else sess, 32, 50))
+    assert list(groups[0]) == list(groups[1]) and all(np.array_equal(groups[0][k], groups[1][k]) for k in groups[0])
