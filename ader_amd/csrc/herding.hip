@@ -385,6 +385,8 @@ __global__ __launch_bounds__(HR_T) void k_herding_reg(HerdArgs a) {
     const int items = nC + nB + (nA + 7) / 8;
     const int* list = a.work + HR_HDR;
     for (;;) {
+        // (a pure work ticket: the list it indexes was written by the PREVIOUS launch (k_herd_work), and no workgroup reads what another
+        //  writes in this launch -- atomicity is all it needs, no ordering; tests/stress_handoffs.py runs it 200 times cold and warm)
         if (tid == 0) s_ctl[1] = atomicAdd(&a.work[3], 1);
         __syncthreads();
         const int it = uni(s_ctl[1]);

@@ -18,9 +18,8 @@
 // duration -- rounds 5a's medium class, two or three such sessions per 64-row tile, put one in nearly every batch).
 //
 // Launch 1 (k_plan_len, one workgroup per 64 sessions): the first item of every session (its ids read once, coalesced; an LDS
-// atomicMin over the positions) -> slen; the workgroup whose ticket is last then runs the scans for the whole batch (slen read
-// back with L1-bypassing loads: the lengths were stored write-through and drained before the ticket, MI355X_MICROARCH.md
-// "Valid forms") -> srow0, tile_rows, hdr.  Launch 2 (k_plan_rows, one thread per position): the per-row records.
+// atomicMin over the positions) -> slen; the workgroup whose ticket is last then runs the scans for the whole batch (release fence
+// + acq_rel ticket + acquire fence, see the hand-off comment in the kernel) -> srow0, tile_rows, hdr.  Launch 2 (k_plan_rows, one thread per position): the per-row records.
 // (The first form of this file was ONE 1,024-thread workgroup: 22-32 us for 400-600 sessions -- a single CU reads the batch's
 // 120 KB of ids at ~10 B/clock, twice.)
 //
@@ -105,13 +104,19 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_len(const int* __restrict
         }
     }
     __syncthreads();
-    // write-through (L2-visible) stores, drained by every storing wave, then the workgroup's ticket
+    // Hand-off to the last-arriving workgroup, in the memory model's own terms (the classic fence + ticket reduction): every storing
+    // thread's release fence at agent scope orders its slen stores before anything that follows the barrier; the ticket is one
+    // acq_rel read-modify-write at agent scope per workgroup, so the chain of tickets carries every earlier workgroup's release to the
+    // last arriver, whose acquire fence then makes those stores visible to all of its threads behind the barrier.  (Rounds 4-5 relied
+    // on relaxed atomics + a hand-written s_waitcnt vmcnt(0) and on what the caches happen to do; k_tabp's cold-process corruption was
+    // a hand-off of that kind.  The fences cost ~1 us per launch; tests/stress_handoffs.py hammers this launch cold and warm.)
     if (tid < ns) __hip_atomic_store(o.slen + sb + tid, T - fz_l[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (tid == 0) last_l = (__hip_atomic_fetch_add(o.hdr + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+    if (tid == 0) last_l = (__hip_atomic_fetch_add(o.hdr + 7, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!last_l) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     PST(0)
     // ================= the last workgroup: scans over all sessions
     for (int i = tid; i < B; i += PLAN_THREADS) len_l[i] = (unsigned char)__hip_atomic_load(o.slen + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
