@@ -36,6 +36,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6300.0    # MI355X_MICROARCH.md: what a pure streaming kernel reaches (frac_of_achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0
+BF16_MFMA_SUSTAINED_TFLOPS = 1370.0   # what the chip holds under the logit kernels at its power-limited ~1.4 GHz (profiles/r5x_pmc_sq.json:
+#                                       k_lx3p 0.91 MFMA-busy; the round-5 review's figure) -- the rate the shape floors below are priced at
 
 
 def synth_batch(B, T, N, seed, device, regime="dense"):
@@ -66,6 +68,43 @@ REAL_SHAPES = {  # step shapes of the real-data configurations: item
     "cfgD": ("DIGINETICA ADER, last period (BASELINE.json configs[1])", 43105, 256, 143),
     "cfgY": ("YOOCHOOSE ADER, last period (configs[2])", 25750, 512, 102),
 }
+# ... and the ADER-mode step at the headline catalog (what every period > 1 runs, ADER.py:108-137): cfg-S + 128 distilled rows, dense regime
+ADER128 = ("cfg-S + 128 distilled exemplar rows (ADER mode at the headline catalog, configs[4] + ADER.py:132-137)", 1_000_000, 512, 128)
+
+
+def shape_roofline(N, B, E, Np, positions, ms, H=150, L=2, x3=True):
+    """Work and compulsory traffic of ONE distilled train step of a shape, and the floor they imply (SURVEY 8d accounting; DESIGN.md
+    "roofline of the real shapes").  positions = real (non-padding) positions of the batch; the last block is pruned to the B + E
+    query rows (its K / V projections still run on every position).
+      logit MFMA   credited: logits + softmax readout O1 (train rows over N, exemplar rows over Np), teacher readout O2 (E x Np),
+                   table-gradient product dE (rows^T x items); executed: the same on rows padded to 128 and three bf16 passes per
+                   product (the hi/lo split) when x3
+      session MFMA credited: 5 HxH products per position and block forward, twice that backward (dX and dW); pruned last block:
+                   K, V on every position, Q / W1 / W2 on the query rows; attention products are ~2 % and left out
+      bytes        theta / Adam m / Adam v of the N rows read and written once (6 N H 4), the teacher rows read twice (readout,
+                   update), the session activations written once and read once by the backward (~24 [positions, H] tensors)
+      floor_ms     executed MFMA work at the sustained bf16 rate + bytes at the achievable HBM rate, summed: the phases of a step
+                   depend on each other (forward -> logits -> backward -> update), they do not overlap"""
+    rows, rp = B + E, ((B + 127) // 128 + (E + 127) // 128) * 128
+    logit_cred = 2.0 * H * (2.0 * B * N + 2.0 * E * Np + 1.0 * E * Np + 1.0 * B * N + 1.0 * E * Np)
+    pad = rp / float(rows)
+    logit_exec = logit_cred * pad * (3 if x3 else 1)
+    gemm_rows = (L - 1) * 5.0 * positions + 2.0 * positions + 3.0 * rows
+    sess_cred = 3.0 * 2.0 * H * H * gemm_rows
+    sess_exec = sess_cred * (3 if x3 else 1)
+    nbytes = 6.0 * N * H * 4 + 2.0 * E * Np * 4 + 2.0 * 24 * positions * H * 4
+    t_logit = logit_exec / (BF16_MFMA_SUSTAINED_TFLOPS * 1e12) * 1e3
+    t_sess = sess_exec / (BF16_MFMA_SUSTAINED_TFLOPS * 1e12) * 1e3
+    t_hbm = nbytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+    floor = t_logit + t_sess + t_hbm
+    return {"logit_flops_credited": logit_cred, "logit_flops_executed": logit_exec, "session_flops_credited": sess_cred,
+            "session_flops_executed": sess_exec, "compulsory_bytes": nbytes,
+            "floor_parts_ms": {"logit_mfma": round(t_logit, 5), "session_mfma": round(t_sess, 5), "hbm": round(t_hbm, 5)},
+            "floor_ms": round(floor, 5), "frac": round(floor / ms, 4),
+            "priced_at": {"bf16_mfma_sustained_TFLOPs": BF16_MFMA_SUSTAINED_TFLOPS, "hbm_achievable_GBps": HBM_ACHIEVABLE_GBS},
+            "credited_TFLOPs": round((logit_cred + sess_cred) / (ms * 1e-3) / 1e12, 2),
+            "executed_frac_of_bf16_peak": round((logit_exec + sess_exec) / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "hbm_frac_of_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def real_shape_line(name, dev, seconds=1.2, empty_cache=True):
@@ -74,10 +113,11 @@ def real_shape_line(name, dev, seconds=1.2, empty_cache=True):
     0.9 N items, dropout 0.3, float32 grade, packed session tiles by the engine's own rule.  Same protocol as the headline
     (warm-up, then K steps bracketed by synchronize; median of 5), sized to ~`seconds` of GPU time."""
     from ader_amd.engine import Engine, SectionTimer
-    label, N, B, E = REAL_SHAPES[name]
+    label, N, B, E = ADER128 if name == "ader128" else REAL_SHAPES[name]
+    regime = "dense" if name == "ader128" else "realistic"
     T, lr, rate = 50, 5e-4, 0.3
-    batches = [synth_batch(B + E, T, N, 1000 * s + 77, dev, "realistic") for s in range(4)]
-    eng = Engine(N, maxlen=T, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device=dev)
+    batches = [synth_batch(B + E, T, N, 1000 * s + 77, dev, regime) for s in range(4)]
+    eng = Engine(N, maxlen=T, hidden_units=150, num_blocks=2, num_heads=1, seed=0, device=dev).warm_up()
     eng.pack_density = float(np.mean([float((sq != 0).float().mean()) for sq, _ in batches]))
     Np = int(0.9 * N)
     teacher = torch.empty(E, (Np + 3) // 4 * 4, device=dev)[:, :Np]          # rows 16-byte aligned, as Engine.teacher_logits allocates them
@@ -125,8 +165,21 @@ def real_shape_line(name, dev, seconds=1.2, empty_cache=True):
             dts2.append((time.perf_counter() - t0) / K * 1e3)
         if float(np.median(dts2)) < ms:
             dts, ms = dts2, float(np.median(dts2))
+    # host side of a step: enqueue time of 8 steps on an idle GPU (nothing blocks), and how they were driven
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(8):
+        step(i)
+    host_ms = (time.perf_counter() - t0) / 8 * 1e3
+    torch.cuda.synchronize()
     pk = eng._act.get("pack")
-    out = {"workload": "step shape of %s: N=%d items, %d train + %d distilled rows, synthetic ids, realistic length law" % (label, N, B, E),
+    positions = int(pk["hdr"][2].item()) if pk is not None else (B + E) * T
+    out = {"workload": "step shape of %s: N=%d items, %d train + %d distilled rows, synthetic ids, %s" % (
+               label, N, B, E, "realistic length law" if regime == "realistic" else "dense regime (every position real)"),
+           "host_enqueue_ms": round(host_ms, 4),
+           "driver": ("native launch plan, one C call per step (%d replayed / %d recorded)" % (eng.plan_hits, eng.plan_misses)
+                      if eng.plan_hits else "Python-driven launches"),
+           "roofline": shape_roofline(N, B, E, Np, positions, ms),
            "ms_per_step": ms, "sessions_per_s": B / ms * 1e3, "rows_per_s": (B + E) / ms * 1e3, "steps": K, "reps_ms": [round(x, 4) for x in dts],
            "ms_per_step_min": round(min(dts), 4),
            "sections_ms": {k: round(v, 4) for k, v in sections.items()}, "real_positions_fraction": round(eng.pack_density, 4),
@@ -656,9 +709,9 @@ def main():
         if world == 1 and not args.no_real_shapes and args.workload == "cfgS" and not E and args.regime == "dense":
             # the workloads the reference trains on (BASELINE.json configs[1], [2]) on the driver-run line, after everything else
             real = {}
-            for nm in REAL_SHAPES:
+            for nm in list(REAL_SHAPES) + ["ader128"]:
                 try:
-                    real[nm] = real_shape_line(nm, dev)
+                    real[nm] = real_shape_line(nm, dev, seconds=2.0 if nm == "ader128" else 1.2)
                 except Exception as e:
                     real[nm] = {"failed": repr(e)}
         prec = {"bf16": "logit GEMMs: bf16 operands, fp32 accumulate + softmax; block GEMMs and attention: bf16x3 (three bf16 MFMAs "
@@ -671,7 +724,7 @@ def main():
             "metric": "train sessions/sec at batch=512 seq=50", "value": B * world * args.steps / dt, "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "x3": "bf16x3 (fp32-grade)", "f32": "f32"}[args.logits], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "x3": "bf16x3 (2^-16/product, fp32 accumulate)", "f32": "f32"}[args.logits], "data": "synthetic",
             "reps": len(dts), "reps_ms": {"median": ms, "min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
                                           "all": [round(x / args.steps * 1e3, 4) for x in dts]},
             "config": {"workload": ("synthetic %s-item catalog, seq_len=50, batch=%d/GPU, %s regime%s (BASELINE.json configs[4]%s)"

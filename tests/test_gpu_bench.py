@@ -40,6 +40,16 @@ def test_single_gpu_line_has_the_contract_fields():
     su = d["sustained"]
     assert su["steps"] == 40 and abs(su["value"] - 512 / (su["ms_per_step"] * 1e-3)) < 1e-6 * su["value"]
     assert r["frac_of_achievable"] is None or r["frac_of_achievable"] > r["frac"]
+    # the workloads the reference trains, and the ADER-mode step at the headline catalog, each with its own roofline block
+    rs = d["real_shapes"]
+    assert sorted(rs) == ["ader128", "cfgD", "cfgY"]
+    for nm, row in rs.items():
+        assert "failed" not in row, row
+        rf = row["roofline"]
+        assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["floor_ms"] / row["ms_per_step"]) < 2e-3
+        assert abs(sum(rf["floor_parts_ms"].values()) - rf["floor_ms"]) < 1e-4 and rf["logit_flops_executed"] > rf["logit_flops_credited"]
+        assert row["host_enqueue_ms"] > 0 and row["driver"].startswith("native launch plan")
+    assert rs["cfgY"]["session_tiles"] == "packed" and rs["ader128"]["session_tiles"] != "packed"
 
 
 @pytest.mark.parametrize("mode", ["catalog", "replicated"])
