@@ -230,11 +230,29 @@ class DataParallel:
         per-position rows and _exchange adds the rows of ALL ranks after the reduction (they are 15 MB per rank against 600 MB)."""
         H = eng.H
         self.max_item = int(max_item)
+        if not self.early_pays(eng, max_item):
+            return None
         works = []
         for lo, hi in bucket_ranges(eng.grad.numel(), (self.max_item + 1) * H, self.bucket_elems):
             guard.check("DataParallel._early:table", "all_reduce(async)", (hi - lo,), eng.grad.dtype)
             works.append(dist.all_reduce(eng.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return works
+
+    early = "auto"      # "auto" | "always" | "never": see early_pays
+
+    def early_pays(self, eng, max_item):
+        """Dense path: is the early (overlapped) all-reduce of the table gradient worth what it costs?  It forces the sparse
+        input-embedding rows to travel as per-position rows -- every rank receives (W - 1) x positions x (H + 1) x 4 bytes on top of
+        the all-reduce's ~2 x table bytes.  At the headline catalog (1.2 GB of all-reduce traffic against ~0.1 GB of rows) the
+        overlap wins; at the shipped datasets' catalogs (YOOCHOOSE: 31 MB against 8 x 18 MB of rows at 8 ranks) the rows cost more
+        than the whole table, so every rank scatters its rows into its gradient first and ONE dense all-reduce follows the backward
+        (_exchange's plain branch).  DESIGN.md section 5 has the byte model."""
+        if self.early != "auto":
+            return self.early == "always"
+        positions = int(eng._act["B"]) * eng.T if getattr(eng, "_act", None) else 0
+        rows_bytes = (self.world - 1) * positions * (eng.H + 1) * 4
+        table_bytes = 2 * (int(max_item) + 1) * eng.H * 4
+        return rows_bytes < table_bytes
 
     bucket_elems = 64 << 20          # 256 MB buckets: xGMI rings are per-link bound -- few, large collectives
 

@@ -193,6 +193,106 @@ def real_shape_line(name, dev, seconds=1.2, empty_cache=True):
     return out
 
 
+def dp_shape_legs(name, dev, rank, world, steps=40, warmup=8, reps=3):
+    """BASELINE.json configs[3] on the SCALE line: the YOOCHOOSE ADER step shape (reference README.md:77 scaled out: global batch
+    512 x W train rows + 102 x W distilled rows, rows of BOTH sub-batches sharded over the ranks as ader_amd/main.py shards them,
+    teacher logits replicated), weak scaling, BOTH data-parallel schemes back to back: "replicated" (every rank holds the table:
+    dense gradient all-reduce -- the plain one at this catalog size, dist.DataParallel.early_pays) and "catalog" (every rank owns 1/W
+    of the rows).  Per scheme: one guarded first step (every collective announced and compared across the ranks before it is
+    issued), then `reps` x `steps` steps bracketed by barrier + synchronize, MAX over ranks, median repetition."""
+    import torch.distributed as dist
+    from ader_amd import dist as adist
+    from ader_amd.engine import Engine, pack_counts_host
+    label, N, B, E = REAL_SHAPES[name]
+    T, H, lr, rate = 50, 150, 5e-4, 0.3
+    nb = 4
+    batches = [synth_batch(B + E, T, N, 1000 * s + 77 + rank, dev, "realistic") for s in range(nb)]
+    Np = int(0.9 * N)
+    teacher = torch.empty(E, (Np + 3) // 4 * 4, device=dev)[:, :Np]
+    teacher.copy_(torch.randn(E, Np, generator=torch.Generator().manual_seed(7)))          # (replicated, as the exemplar store is)
+    trow = torch.arange(E, dtype=torch.int32, device=dev)
+    density = float(np.mean([float((sq != 0).float().mean()) for sq, _ in batches]))
+    out = {"workload": "step shape of %s scaled out: %d ranks x (%d train + %d distilled rows), N=%d items, realistic length law "
+                       "(BASELINE.json configs[3] at %d ranks)" % (label, world, B, E, N, world), "global_batch": B * world,
+           "global_exemplar_rows": E * world, "scaling": "weak", "steps": steps, "schemes": {}}
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for mode in ("replicated", "catalog"):
+        eng = Engine(N, maxlen=T, hidden_units=H, num_blocks=2, num_heads=1, seed=0, device=dev, dp_rank=rank, dp_world=world).warm_up()
+        dp = adist.DataParallel(eng, rank, world)
+        eng.dp_mode, eng.pack_density = mode, density
+        dp.set_rows(rank * B, N, ex_row0=B * world + rank * E)
+        kw = dict(rate=rate, teacher=teacher, ex_trow=trow, lambda_=0.8, n_train_global=B * world, n_ex_global=E * world)
+        counts = [None] * nb
+        if mode == "catalog" and eng.dp_pack:
+            # split sizes of the packed row exchange from the host copy of the GLOBAL batch's ids (every rank can form it: the batches
+            # are a function of (step, rank)); for this leg's four resident batches they are computed once, ahead of the timed region
+            for s_ in range(nb):
+                rows = []
+                for r_ in range(world):
+                    sq, ps = synth_batch(B + E, T, N, 1000 * s_ + 77 + r_, "cpu", "realistic")
+                    rows.append(np.concatenate([sq.numpy().reshape(-1), ps.numpy()[:B]]).astype(np.int32))
+                counts[s_] = pack_counts_host(np.stack(rows), (B + E) * T, eng.shard_items)
+
+        def step(i):
+            sq, ps = batches[i % nb]
+            extra = {"pack_counts": counts[i % nb]} if counts[i % nb] is not None else {}
+            eng.train_step(sq, ps[:B], N, lr, **kw, **extra)
+        adist.guard.start()
+        try:
+            step(0)
+            torch.cuda.synchronize()
+        finally:
+            log_ = adist.guard.stop()
+        sys.stderr.write("\n".join(["[rank %d] real_shapes_dp %s dp_mode=%s world=%d: %d collectives per step"
+                                     % (rank, name, mode, world, len(log_))] + adist.guard.describe(rank)) + "\n")
+        sys.stderr.flush()
+        for i in range(5 + warmup):
+            step(i)
+        eng.check_status()
+        dts = []
+        for _ in range(reps):
+            sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts.append(float(t.item()) / steps * 1e3)
+        ms = float(np.median(dts))
+        # bytes RECEIVED per rank and step (model, DESIGN.md section 5)
+        W, P, span = world, eng.P, eng.layout["pos"][0]
+        small = 2.0 * (W - 1) / W * ((P - span) * 4 + 4)
+        rowsT = (B + E) * T
+        if mode == "replicated":
+            early = dp.early_pays(eng, N)
+            xb = 2.0 * (W - 1) / W * (N + 1) * H * 4 + small + ((W - 1) * rowsT * (H + 1) * 4 if early else 0.0)
+            how = ("dense all-reduce of the table gradient started under the blocks backward + per-position rows all-gathered"
+                   if early else "rows scattered locally, then ONE dense all-reduce of the whole gradient (table " "%.1f MB + %.1f MB of "
+                   "block parameters)" % ((N + 1) * H * 4 / 1e6, (P - span) * 4 / 1e6))
+        else:
+            Bp, Bk = (B + 127) // 128 * 128, (E + 127) // 128 * 128
+            n_all = rowsT + B
+            f = (W - 1) / W if eng.dp_pack else (W - 1)
+            xb = ((W - 1) * n_all * 4 + f * n_all * H * 4 + (W - 1) * (Bp + Bk) * H * 4 + (W - 1) * (Bp + 2 * Bk) * 152 * 4
+                  + (W - 1) * (3 * Bp + 6 * Bk) * 4 + f * rowsT * H * 4 + small)
+            how = "catalog-sharded table: owned rows, representations, softmax partials and gradient rows travel; nothing table-sized"
+        out["schemes"][mode] = {"ms_per_step": ms, "reps_ms": [round(x, 4) for x in dts], "sessions_per_s": B * world / ms * 1e3,
+                                "collectives_per_step": len(log_), "exchange_bytes_per_step": int(xb), "exchange": how,
+                                "packed_rows": bool(eng.dp_pack) if mode == "catalog" else None,
+                                "host_syncs_per_step": (eng.comm_syncs if mode == "catalog" else 0), "final_loss": float(eng.loss.item()),
+                                "collectives": [{"site": a_, "kind": b_, "shape": list(c_), "dtype": d_} for a_, b_, c_, d_, _ in log_]}
+        del eng, dp
+        torch.cuda.empty_cache()
+    best = min(out["schemes"], key=lambda k: out["schemes"][k]["ms_per_step"])
+    out["faster_scheme"] = best
+    return out
+
+
 def cpu_baseline(N, B, T, H, L, heads, rate, lr, E=0, Np=0):
     """Reference-equivalent CPU step (oracle/ader_ref_cpu.py: materialised [B,N] logits, one-hot CE [+ distillation against E
     teacher rows], autograd, dense TF-style Adam) timed on this host's cores.  Bounded sample: full steps of the same workload
@@ -462,6 +562,15 @@ def main():
                      "final_loss": loss_o, "steps": args.steps}
         del eng_o
         torch.cuda.empty_cache()
+
+    # ---- configs[3] (YOOCHOOSE ADER, global batch 512 x N) in the same multi-GPU invocation, both schemes: every rank takes part
+    real_dp = None
+    if world > 1 and not args.no_real_shapes and args.workload == "cfgS" and not E and args.logits == "x3":
+        try:
+            real_dp = {"cfgY": dp_shape_legs("cfgY", dev, rank, world, steps=max(10, min(40, args.steps)))}
+        except Exception as e:          # (collectives inside: a failure on one rank is fatal for all, so it is re-raised after the note)
+            sys.stderr.write("[rank %d] real_shapes_dp failed: %r\n" % (rank, e))
+            raise
 
     # ---- sustained figure: the K-step repetitions above are ~40 ms bursts on a chip that clocks down under the logit kernels
     # (MI355X_MICROARCH.md, DVFS): one multi-second region of the SAME steps, no per-kernel events, same barrier + synchronize
@@ -748,6 +857,7 @@ def main():
             "companion": comp,
             "roofline": roof, "cpu_baseline": cpu,
             "real_shapes": real,
+            "real_shapes_dp": real_dp,
         }
         print(json.dumps(out))
     if world > 1:

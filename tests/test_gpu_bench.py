@@ -72,3 +72,12 @@ def test_gpus_2_starts_its_own_ranks(mode):
     assert any(x["kind"] == "all_gather" for x in c["collectives"]["catalog"])
     for r_ in (0, 1):
         assert "[rank %d] dp_mode=%s world=2" % (r_, mode) in d["_stderr"] and "[rank %d] collective  0:" % r_ in d["_stderr"]
+    # BASELINE configs[3] on the multi-GPU line: the YOOCHOOSE ADER step shape at global batch 512 x ranks, both schemes
+    y = d["real_shapes_dp"]["cfgY"]
+    assert y["global_batch"] == 1024 and y["global_exemplar_rows"] == 204 and sorted(y["schemes"]) == ["catalog", "replicated"]
+    for nm, sc in y["schemes"].items():
+        assert sc["ms_per_step"] > 0 and abs(sc["sessions_per_s"] - 1024 / (sc["ms_per_step"] * 1e-3)) < 1e-6 * sc["sessions_per_s"]
+        assert sc["collectives_per_step"] == len(sc["collectives"]) >= 2 and sc["exchange_bytes_per_step"] > 0
+        assert "[rank 1] real_shapes_dp cfgY dp_mode=%s world=2" % nm in d["_stderr"]
+    assert y["schemes"]["replicated"]["collectives_per_step"] < y["schemes"]["catalog"]["collectives_per_step"]
+    assert abs(y["schemes"]["replicated"]["final_loss"] - y["schemes"]["catalog"]["final_loss"]) < 2e-3

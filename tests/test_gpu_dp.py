@@ -147,7 +147,9 @@ def _kd_worker(rank, world, port, out, logits, mode="replicated"):
     seq, pos, ex_seq, teacher, trow = _kd_data()
     eng = _engine(logits, rank, world)
     dp = adist.DataParallel(eng, rank, world)
-    if mode != "replicated":                     # distilled steps on the catalog-sharded table (dense / packed row exchange)
+    if mode == "replicated_early":               # the table all-reduce started under the blocks backward, rows gathered (large catalogs'
+        dp.early = "always"                      # choice; "auto" takes the plain dense all-reduce at this catalog size: dist.early_pays)
+    elif mode != "replicated":                   # distilled steps on the catalog-sharded table (dense / packed row exchange)
         eng.dp_mode = "catalog"
         eng.dp_pack = mode == "catalog_packed"
         _poison_allocator()
@@ -166,8 +168,8 @@ def _kd_worker(rank, world, port, out, logits, mode="replicated"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("logits,mode", [("f32", "replicated"), ("bf16", "replicated"), ("x3", "replicated"), ("x3", "catalog"),
-                                         ("x3", "catalog_packed")])
+@pytest.mark.parametrize("logits,mode", [("f32", "replicated"), ("bf16", "replicated"), ("x3", "replicated"), ("x3", "replicated_early"),
+                                         ("x3", "catalog"), ("x3", "catalog_packed")])
 def test_two_ranks_distilled_step_matches_single_process(logits, mode):
     """ADER-mode step under data parallelism (main.py:223-256 with the rows of BOTH sub-batches sharded, losses scaled by the
     global sub-batch sizes, dense gradient all-reduce): two ranks == one process on the whole batch.  Dropout ON: the counters of
@@ -237,7 +239,7 @@ def _rccl_worker(rank, world, port, out):
                 kinds = [k for _, k, _, _, _ in log]
                 assert len(log) >= 6 and "all_reduce" in kinds and "all_gather" in kinds, log
                 assert (mode != "catalog_packed") or "all_to_all(uneven)" in kinds, log
-                assert all("engine.py:" in site for site, _, _, _, _ in log) and len(adist.guard.describe(0)) == len(log)
+                assert all("@" in site and ".py:" in site for site, _, _, _, _ in log) and len(adist.guard.describe(0)) == len(log), log
         eng.sync_table()
         torch.cuda.synchronize()
         d = (eng.theta - want).abs()
