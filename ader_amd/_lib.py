@@ -8,6 +8,7 @@ from ctypes import c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADER_HIP_LIB") or os.path.join(_HERE, "libader_hip.so")      # (override: A/B runs of two builds)
+XLIB_PATH = os.path.join(_HERE, "libader_xcheck.so")
 
 P, I, U, F, L, Z = c_void_p, c_int, c_uint, c_float, c_long, c_size_t
 _DROP = [P]          # const AderDrop* (NULL: no dropout)
@@ -58,7 +59,6 @@ _SIGS = {
     "ader_lbf_readout_ranges": [I, I, I],
     "ader_lx3_readout_ranges": [I, I],
     "ader_lx3_fwd_kd": [P, P, I, I, I, I, I, I, I, I, P, P, P, L, P, F, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "ader_tab_update_kd": [P, P, I, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, L, P, P, P, P, P, F, F, F, F, P],
     "ader_tab_update_sh_kd": [P, P, I, I, I, I, I, I, P, P, P, P, I, P, F, P, P, P, I, P, P, L, P, P, P, P, P, F, F, F, F, P],
     "ader_lbf_merge_parts": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "ader_gather_owned": [P, P, I, I, I, I, P, P],
@@ -75,7 +75,6 @@ _SIGS = {
     "ader_lx3_fwd_kd_lnf": [P, P, I, I, I, I, I, I, I, I, P, P, P, L, P, F, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "ader_tab_grad": [P, P, P, I, I, I, I, I, P, P, P, P, P],
     "ader_tab_grad_kd": [P, P, P, I, I, I, I, I, I, P, P, P, P, L, P, P, P, P],
-    "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
     "ader_host_shuffle": [P, P, L],
     "ader_host_pack_rows": [P, P, L, I, P, P],
     "ader_host_prefix_rows": [P, P, L, I, P, P],
@@ -121,6 +120,11 @@ _SIGS = {
     "ader_step_plan_peek": [P, P, I, U, P, P],
     "ader_step_plan_failed_op": [P],
     "ader_herding_select": [P, P, P, P, I, L, I, P, P, P, P, P, P],
+}
+# cross-check kernels of the tests (libader_xcheck.so, built with -DADER_XCHECK): not in the product library
+_XSIGS = {
+    "ader_tab_update": [P, P, P, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, P, P, F, F, F, F, I, I, P, P],
+    "ader_tab_update_kd": [P, P, I, I, I, I, I, I, P, P, P, I, P, F, P, P, I, P, P, P, L, P, P, P, P, P, F, F, F, F, P],
     "ader_herding_select_generic": [P, P, P, P, I, L, I, P, P, P, P, P, P],
 }
 SEQ_MAXL = 4
@@ -222,11 +226,30 @@ def load():
 recorder = None      # ader_amd.engine.plan.Recorder while a train step is being recorded into a native launch plan, else None
 
 
+_xlib = None
+
+
+def load_xcheck():
+    """The cross-check kernels (tests only): the round-2 fused table update and the generic herding kernel under its own name."""
+    global _xlib
+    if _xlib is None:
+        if not os.path.isfile(XLIB_PATH):
+            raise AderHipError("libader_xcheck.so not built: run `python -m ader_amd.build`")
+        load()
+        lib = ctypes.CDLL(XLIB_PATH)
+        for name, argt in _XSIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argt
+            fn.restype = c_int
+        _xlib = lib
+    return _xlib
+
+
 def call(name, *args):
     """Invoke a launcher; raises on a non-zero return code."""
     if recorder is not None and name not in _NO_CHECK:
         recorder.launch(name, args)
-    rc = getattr(load(), name)(*args)
+    rc = getattr(load_xcheck() if name in _XSIGS else load(), name)(*args)
     if name not in _NO_CHECK and rc != 0:
         raise AderHipError("%s failed with code %d" % (name, rc))
     return rc

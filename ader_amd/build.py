@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libader_hip.so")
+XLIB = os.path.join(HERE, "libader_xcheck.so")      # cross-check kernels of the tests (-DADER_XCHECK): never loaded by the product path
+XCHECK_SOURCES = ("table_update.hip", "herding.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -49,17 +51,28 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    xobjs = []
+    for src in XCHECK_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, "x_" + src.replace(".hip", ".o"))
+        xobjs.append(o)
+        if force or _stale(o, [s] + headers + [os.path.abspath(__file__)]):
+            cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + ["-DADER_XCHECK", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append(("x_" + src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
         if verbose and out:
             print(out.decode())
-    if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s" % r.stdout.decode())
+    for lib, group in ((LIB, objs), (XLIB, xobjs)):
+        if force or procs or _stale(lib, group):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + group
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s" % r.stdout.decode())
     return LIB
 
 

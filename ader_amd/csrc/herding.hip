@@ -409,8 +409,8 @@ extern "C" {
 // (= number of integers k with k < 1.1*min(quota,n) in float64, computed by the host as the reference's loop does).
 // Scratch: D n_total*H + G + 64 floats (normalised columns of the groups, then the device-built work list), chosen n_total bytes
 // (zeroed here).  sel [n_total]: first sel_cnt[g] entries of each group's span are the selected LOCAL indices in selection order.
-int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total, int H,
-                                float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream) {
+static int herding_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total, int H,
+                           float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream) {
     if (G <= 0) return 0;
     if (H > HMAX) return -2;
     hipStream_t st = (hipStream_t)stream;
@@ -421,10 +421,17 @@ int ader_herding_select_generic(const float* rep, const long* seg, const int* qu
     return 0;
 }
 
+#ifdef ADER_XCHECK   // the generic kernel under its own name: kernel-vs-kernel checks of the test build only (libader_xcheck.so)
+int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total, int H,
+                                float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream) {
+    return herding_generic(rep, seg, quota, max_steps, G, n_total, H, D, chosen, sel, sel_cnt, steps_out, stream);
+}
+#endif
+
 int ader_herding_select(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total, int H,
                         float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream) {
     if (G <= 0) return 0;
-    if (H != HR_H) return ader_herding_select_generic(rep, seg, quota, max_steps, G, n_total, H, D, chosen, sel, sel_cnt, steps_out, stream);
+    if (H != HR_H) return herding_generic(rep, seg, quota, max_steps, G, n_total, H, D, chosen, sel, sel_cnt, steps_out, stream);
     hipStream_t st = (hipStream_t)stream;
     static int cus_dev[ADER_MAX_DEV] = {};
     int& cus = cus_dev[ader_cur_dev()];

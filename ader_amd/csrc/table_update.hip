@@ -577,6 +577,7 @@ int ader_tab_grad_kd(const void* rep_hi, const void* rep_lo, const float* emb, i
     return 0;
 }
 
+#ifdef ADER_XCHECK   // the round-2 fused update (64-row tiles): cross-check kernels of the test build only (libader_xcheck.so)
 // Fused: table-gradient GEMM + sparse terms + TF-Adam on table rows 1..N (+ bf16 shadow rows), in one pass.
 // sp_ids/sp_rows: the B*T input positions sorted by item id (pads = id 0 first) and their row index into sp_src [B*T,H]
 // (the masked/dropout-scaled gradient rows left by ader_embed_bwd_rows); sp_scale = sqrt(H).  tg_ids/tg_rows: the labels
@@ -652,6 +653,8 @@ int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+#endif  // ADER_XCHECK
 
 // bucket layout the caller must use for sp_start / tg_start: granularity (ids per bucket) and first id of bucket 0
 // (a tile of the update covers item ids [64j + 1, 64j + 65))

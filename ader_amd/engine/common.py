@@ -160,6 +160,7 @@ def param_layout(item_num, T, H, L, align=64, table_rows_alloc=None):
 
 
 _SIDE_STREAMS = {}
+SIDE_PROBE = {}       # (device index, main stream) -> [(overlaps, dependency latency in s, stream)] of every probed candidate
 
 
 def side_stream(device, main):
@@ -210,6 +211,7 @@ def side_stream(device, main):
                 torch.cuda.synchronize(dev)
                 overlaps = ev_s.elapsed_time(ev_m) > 0.02          # the side launch finished well before the main-stream work did
                 cand = (not overlaps, lat, s)
+                SIDE_PROBE.setdefault(key, []).append((overlaps, lat, s))
                 if best is None or cand[:2] < best[:2]:
                     best = cand
             if best is not None and not best[0]:

@@ -243,8 +243,13 @@ class _Forward:
         ref = ctypes.byref(c)
         plan_args = (B, T, int(self.row0), split, int(self.row0_ex), w1_min, w1_max, target, ref)
         call("ader_seq_pack_plan", ptr(seq), *plan_args, self._stream())
-        d = self.pack_density if self.pack_density is not None else 0.15
-        est = int(min(n, max(64, 1.25 * d * B * T + 64)))          # rows expected to exist: how the weight-gradient workgroups are shared out
+        # rows expected to exist (how the weight-gradient workgroups are shared out): this batch's own density when it came from the host,
+        # else the feeder's announcement, else -- nothing known -- the densest batch "auto" would still pack (a low guess would share a
+        # dense batch's products over too few workgroups: correct, but silently slow)
+        d = getattr(self, "_density_now", None)
+        if d is None:
+            d = self.pack_density if self.pack_density is not None else self.PACK_DENSITY_MAX
+        est = int(min(n, max(64, 1.25 * d * B * T + 64)))
         return dict(c=c, ref=ref, hdr=hdr, trows=trows, ids=ids, lpos=lpos, gpos=gpos, info=info, srow0=srow0, slen=slen,
                     B=B, rows=n, max_tiles=B, est=est, plan_args=plan_args)
 

@@ -21,6 +21,8 @@ Trainable surface (second half of this file; every forward has an autograd formu
   ader::logits_ce / logits_ce_bwd                              ADER.py:88-93 (exact-f32 logits, one-hot CE)
 """
 
+import os
+
 import torch
 
 from . import _lib
@@ -511,26 +513,39 @@ def _sqrt_f32(H):
 
 
 _STATUS = {}        # device -> int32[1]: ids outside their range seen by an op since the last check_status()
+# strict (default): an out-of-range label raises at the call that passed it (one host synchronisation per logits_ce call: these ops are
+# the autograd surface, not the engine's hot loop).  ader_amd.ops.STRICT_LABELS = False (or ADER_OPS_STRICT=0) keeps the ops free of
+# host synchronisation -- stream-ordered, capturable -- and defers the report to check_status().
+STRICT_LABELS = os.environ.get("ADER_OPS_STRICT", "1") != "0"
 
 
 def _check_labels(t, name, N, lo=0):
     """ids the kernels match by equality: an out-of-range label would silently drop its target term (the loss degrades to lse).
-    Flagged ON THE DEVICE (no host synchronisation: the ops stay stream-ordered and capturable) into a status word that
+    Strict mode raises here.  Otherwise it is flagged ON THE DEVICE (no host synchronisation) into a status word that
     ader_amd.ops.check_status() reads -- as Engine.check_status does for item ids.  0 is legal: "no target" (a weight-0 padding
     row of an equal-size data-parallel shard)."""
     if t.numel():
+        bad = ((t < lo) | (t > N)).any()
+        if STRICT_LABELS:
+            if bool(bad.item()):
+                raise RuntimeError("ader::ops: %s holds an id outside [%d, %d]" % (name, lo, N))
+            return
         st = _STATUS.get(t.device)
         if st is None:
             st = _STATUS[t.device] = torch.zeros(1, dtype=torch.int32, device=t.device)
-        st.bitwise_or_(((t < lo) | (t > N)).any().to(torch.int32))
+        st.bitwise_or_(bad.to(torch.int32))
 
 
 def check_status():
-    """Raise if an op of this module has seen an id outside its range since the last call (one host synchronisation)."""
+    """Raise if an op of this module has seen an id outside its range since the last call (one host synchronisation per device that
+    ran an op).  Every device's flag is read and cleared before anything is raised."""
+    bad = []
     for dev, st in _STATUS.items():
         if int(st.item()):
-            st.zero_()
-            raise RuntimeError("ader::ops: a label / row id outside its valid range was passed to a logits_ce op on %s" % (dev,))
+            bad.append(str(dev))
+        st.zero_()
+    if bad:
+        raise RuntimeError("ader::ops: a label / row id outside its valid range was passed to a logits_ce op on %s" % ", ".join(bad))
 
 
 def _x3_fwd_scratch(N, Bp, dev):

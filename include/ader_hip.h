@@ -346,32 +346,14 @@ int ader_tab_grad_kd(const void* rep_hi, const void* rep_lo, const float* emb, i
                      int Np, const int* lab, const float* wrow, const float* off, const float* teacher, long ldt, const int* trow,
                      const float* tlse2, float* demb, void* stream);
 
-/* Fused table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both sorted by
- * item id) + tf.train.AdamOptimizer (ADER.py:96) on table rows 1..N of emb/adam_m/adam_v, one workgroup per 64-row tile.
- * The table gradient is never written to memory and the item parameters are read ONCE (GEMM operand and Adam input come
- * from the same LDS-resident tile in bf16 mode).  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t).
- * rep_lo != NULL selects x3 mode.  shadow: bf16 [item_num+1][168] copy of the table, rows rewritten after the update
- * (NULL: none; never written in x3 mode).  extra_grad: dense fp32 gradient [item_num+1, H] (table layout) added row by row
- * before the update, or NULL -- the table gradient of rows that did not go through this path (distilled exemplar rows,
- * ADER.py:132-137).
- * Bucket layout of the sorted lists: bucket j covers ids [g*j + id0, g*(j+1) + id0) with g = ader_fused_bucket_gran(),
- * id0 = ader_fused_bucket_id0(). */
-int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int item_num, int B, int Bp, int H, int N,
-                    const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
-                    const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, float* emb,
-                    float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
-                    int tile_count, const float* extra_grad, void* stream);
-/* ... and for a DISTILLED step at float32 grade (x3; layout and arguments as ader_lx3_fwd_kd left them; ADER.py:132-137) */
-int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int Bp, int kd_row0, int H, int N, int Np,
-                       const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
-                       const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow,
-                       const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
-                       float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
-/* The float32-grade (x3) fused update on 16x16x32 tiles, three workgroups per CU (csrc/table_update_x3.hip: k_tab16x3): same
- * arithmetic and arguments as ader_tab_update(rep_lo != NULL) / ader_tab_update_kd, plus rep_img: the operand rows rearranged into
+/* Fused table update at float32 grade (x3), csrc/table_update_x3.hip: table-gradient GEMM + sparse terms (input-embedding rows sp_*,
+ * one-hot targets tg_*, both sorted by item id) + tf.train.AdamOptimizer (ADER.py:96) on table rows 1..N of emb / adam_m / adam_v in ONE
+ * pass; the table gradient is never written to memory.  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t).  extra_grad: dense fp32 gradient
+ * [item_num+1, H] added row by row before the update, or NULL.  Bucket layout of the sorted lists: bucket j covers ids
+ * [g*j + id0, g*(j+1) + id0) with g = ader_fused_bucket_gran(), id0 = ader_fused_bucket_id0().  rep_img: the operand rows rearranged into
  * the bank-conflict-free LDS images that the kernel streams by LDS-DMA (ader_x3_rep_image from the two planes rep_hi / rep_lo
  * [Bp,168]; ader_x3_rep_image_bytes(Bp) bytes, 16-byte aligned; Bp % 32 == 0).  Replaces the dense-Adam + table-gradient op
- * sites ADER.py:91-96 for the item table, as ader_tab_update does. */
+ * sites ADER.py:91-96 for the item table. */
 int ader_x3_rep_image_bytes(int Bp);
 /* kernel choice between the update's two kernels: catalogs of more than `tiles` 64-row tiles take a pair of tiles per workgroup (k_tab32x3),
  * smaller ones a single tile (k_tab16x3); default 0 = pairs always; negative: query only.  Returns the previous value. */
@@ -472,11 +454,6 @@ int ader_pack_plan(const int* ids_g, int W, int n_all, int n_pos, int rank, int 
  * any other H <= 256: the generic kernel.  Both follow the canonical float32 spec of oracle/herding_ref.py bit for bit. */
 int ader_herding_select(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
                         int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
-/* the generic kernel for any H <= 256 (one 256-thread workgroup per group, D streamed from L2 every iteration; D needs only
- * n_total*H floats): what ader_herding_select runs for H != 150, exported for kernel-vs-kernel checks and A/B timing */
-int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
-                                int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
-
 /* ---- device-side feeder: util.py:218-262 (Sampler.sampler / exemplar_sampler: the rows of a batch by the shuffled index list) and
  *      main.py:229 (exemplar rows appended to the train rows), as ONE launch over the GPU-resident packed rows ----------------------
  * rows_t / rows_e [*, T+1]: packed rows of the train / exemplar Sampler (inputs right-aligned in zeros, label last); idx_t [n_t] /
@@ -517,6 +494,38 @@ int ader_step_enqueue(AderStepPlan* plan, const uint64_t* inputs, int n_inputs, 
 int ader_step_plan_peek(AderStepPlan* plan, const uint64_t* inputs, int n_inputs, unsigned step, AderStepOp* ops_out,
                         void* const* blob_out);
 int ader_step_plan_failed_op(const AderStepPlan* plan);
+
+/* ---- cross-check kernels: NOT part of the product library.  Built only into libader_xcheck.so (ader_amd/build.py compiles
+ *      table_update.hip and herding.hip a second time with -DADER_XCHECK) and loaded only by the tests that compare kernel against
+ *      kernel: the round-2 fused table update on 64-row tiles (x3 with rep_lo != NULL, bf16 "resident" form with rep_lo == NULL) and
+ *      the generic herding kernel under its own name. ------------------------------------------------------------------------------- */
+#ifdef ADER_XCHECK
+/* Fused table update: table-gradient GEMM + sparse terms (input-embedding rows sp_*, one-hot targets tg_*, both sorted by
+ * item id) + tf.train.AdamOptimizer (ADER.py:96) on table rows 1..N of emb/adam_m/adam_v, one workgroup per 64-row tile.
+ * The table gradient is never written to memory and the item parameters are read ONCE (GEMM operand and Adam input come
+ * from the same LDS-resident tile in bf16 mode).  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t).
+ * rep_lo != NULL selects x3 mode.  shadow: bf16 [item_num+1][168] copy of the table, rows rewritten after the update
+ * (NULL: none; never written in x3 mode).  extra_grad: dense fp32 gradient [item_num+1, H] (table layout) added row by row
+ * before the update, or NULL -- the table gradient of rows that did not go through this path (distilled exemplar rows,
+ * ADER.py:132-137).
+ * Bucket layout of the sorted lists: bucket j covers ids [g*j + id0, g*(j+1) + id0) with g = ader_fused_bucket_gran(),
+ * id0 = ader_fused_bucket_id0(). */
+int ader_tab_update(const void* rep_hi, const void* rep_lo, void* shadow, int item_num, int B, int Bp, int H, int N,
+                    const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                    const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow, float* emb,
+                    float* adam_m, float* adam_v, float lr_t, float beta1, float beta2, float eps, int tile_begin,
+                    int tile_count, const float* extra_grad, void* stream);
+/* ... and for a DISTILLED step at float32 grade (x3; layout and arguments as ader_lx3_fwd_kd left them; ADER.py:132-137) */
+int ader_tab_update_kd(const void* rep_hi, const void* rep_lo, int item_num, int Bp, int kd_row0, int H, int N, int Np,
+                       const float* off, const int* sp_ids, const int* sp_rows, int n_sp, const float* sp_src, float sp_scale,
+                       const int* tg_ids, const int* tg_rows, int n_tg, const int* tile_meta, const float* wrow,
+                       const float* teacher, long ldt, const int* trow, const float* tlse2, float* emb, float* adam_m,
+                       float* adam_v, float lr_t, float beta1, float beta2, float eps, void* stream);
+/* the generic kernel for any H <= 256 (one 256-thread workgroup per group, D streamed from L2 every iteration; D needs only
+ * n_total*H floats): what ader_herding_select runs for H != 150, exported for kernel-vs-kernel checks and A/B timing */
+int ader_herding_select_generic(const float* rep, const long* seg, const int* quota, const int* max_steps, int G, long n_total,
+                                int H, float* D, unsigned char* chosen, int* sel, int* sel_cnt, int* steps_out, void* stream);
+#endif /* ADER_XCHECK */
 
 /* ---- host-side feeder helper (no device work, no stream) --------------------------------------------------------------------
  * Python's random.shuffle on an int64 array given the `random` module's Mersenne-Twister state (mt_state[0..623] words, [624] index =

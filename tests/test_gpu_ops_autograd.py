@@ -169,13 +169,25 @@ def test_x3_fast_path_ops_step_the_table_like_the_engine_bitwise(mode):
         ta, tb = a.view(getattr(a, buf), "emb"), b.view(getattr(b, buf), "emb")
         assert torch.equal(ta, tb), name
     assert float(a.view(a.adam_v, "emb")[1:N + 1].abs().max()) > 0
-    # a label outside [0, N] is flagged on the device (no host synchronisation inside the op: stream-ordered, capturable) and raises at
-    # the next ops.check_status() -- never a silent lse-only loss; 0 = "no target" (a weight-0 padding row) is legal
+    # a label outside [0, N] never degrades the loss silently to lse-only: by default (ops.STRICT_LABELS) the op that receives it raises;
+    # with strict off it is flagged on the device (no host synchronisation inside the op: stream-ordered, capturable) and raises at the
+    # next ops.check_status(), which clears the flag.  0 = "no target" (a weight-0 padding row) is legal
     ader_amd.ops.check_status()
     bad = pos_d.clone()
     bad[0] = N + 1
-    torch.ops.ader.logits_ce_x3(rep.detach(), emb, bad, torch.from_numpy(ex_pos).to(dev), N, w_train, w_ex) \
-        if mode != "kd" else torch.ops.ader.logits_ce_x3_kd(rep.detach(), emb, bad, torch.from_numpy(trow).to(dev), teacher, N, 1.0, 1.0)
+
+    def call_bad():
+        if mode != "kd":
+            return torch.ops.ader.logits_ce_x3(rep.detach(), emb, bad, torch.from_numpy(ex_pos).to(dev), N, w_train, w_ex)
+        return torch.ops.ader.logits_ce_x3_kd(rep.detach(), emb, bad, torch.from_numpy(trow).to(dev), teacher, N, 1.0, 1.0)
+    assert ader_amd.ops.STRICT_LABELS
     with pytest.raises(RuntimeError):
-        ader_amd.ops.check_status()
-    ader_amd.ops.check_status()                                            # (the flag is cleared by the raise)
+        call_bad()
+    ader_amd.ops.STRICT_LABELS = False
+    try:
+        call_bad()
+        with pytest.raises(RuntimeError):
+            ader_amd.ops.check_status()
+        ader_amd.ops.check_status()                                        # (the flag was cleared by the raise)
+    finally:
+        ader_amd.ops.STRICT_LABELS = True

@@ -9,30 +9,37 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_every_engine_of_a_process_steps_at_the_same_speed():
+def test_every_engine_of_a_process_gets_the_probed_side_stream():
+    """Six engines of one process (torch's stream pool advanced between them, as other users of it would): all run their second lane on
+    the ONE stream the probe picked, and that stream is good by the probe's own measure -- it overlaps with the main stream and its
+    cross-stream dependency latency is within 1.5x of the best overlapping candidate's (the slow hardware queue answers ~5x slower).
+    The engines' step times are printed, not asserted: a wall-clock ratio on a shared box is a flake, the probe's relative measure is not."""
     import bench
     from ader_amd.engine import Engine, side_stream
+    from ader_amd.engine.common import SIDE_PROBE
     dev = torch.device("cuda:0")
     _, N, B, E = bench.REAL_SHAPES["cfgY"]
     T = 50
     seq, pos = bench.synth_batch(B, T, N, 5, dev, "realistic")
     ms = []
     for k in range(6):
-        torch.cuda.Stream(device=dev, priority=-1)            # (advance torch's round-robin pool, as other users of it would)
+        torch.cuda.Stream(device=dev, priority=-1)            # (advance torch's round-robin pool)
         eng = Engine(N, maxlen=T, seed=0, device=dev)
         eng.pack_density = 0.1
         for i in range(10):
             eng.train_step(seq, pos, N, 5e-4, rate=0.3)
-        best = None
-        for rep in range(3):                                   # (best of three: the host of a shared box is not quiet)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(150):
-                eng.train_step(seq, pos, N, 5e-4, rate=0.3)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 150 * 1e3
-            best = dt if best is None else min(best, dt)
-        ms.append(best)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(100):
+            eng.train_step(seq, pos, N, 5e-4, rate=0.3)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) / 100 * 1e3)
         assert eng._side is side_stream(dev, torch.cuda.current_stream())
         eng.check_status()
-    assert max(ms) < 1.6 * min(ms), ms                         # (an engine on the slow hardware queue stepped 3.2x slower)
+    print("step ms of the six engines:", [round(x, 3) for x in ms])
+    (key, cands), = [(k_, v) for k_, v in SIDE_PROBE.items() if k_[1] == torch.cuda.current_stream().cuda_stream]
+    chosen = side_stream(dev, torch.cuda.current_stream())
+    ok = [c for c in cands if c[0]]
+    assert ok, "no candidate stream overlapped with the main stream: %r" % (cands,)
+    mine = [c for c in cands if c[2] is chosen]
+    assert len(mine) == 1 and mine[0][0] and mine[0][1] <= 1.5 * min(c[1] for c in ok), (mine, [(c[0], c[1]) for c in cands])
