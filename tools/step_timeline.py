@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-first = 'k_plan_len' if any(r['Kernel_Name'].startswith('k_plan_len') for r in rows) else 'k_seq_fwd'
+first = next(k for k in ('k_feed_step', 'k_plan_len', 'k_seq_fwd') if any(r['Kernel_Name'].startswith(k) for r in rows))
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(first)]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
