@@ -64,6 +64,13 @@ class _Update:
         self._edge(self._side_lane(), main)      # inputs ready; also orders reuse of last step's list memory after its reader
         with self._OnStream(self, self._side):
             self._lists = self._sparse_lists(seq, lab, N)
+            pl_ = self._pending_loss
+            if pl_ is not None:
+                # the loss scalar feeds nothing in this step: its (single-workgroup) sum rides behind the lists on the side lane -- the
+                # row losses are complete (the edge above follows the logit forward) -- instead of heading the side lane's chain beside
+                # the table update, which at the shipped datasets' shapes ends a few microseconds after the update does
+                call("ader_lbf_sum", ptr(pl_[0]), pl_[1], ptr(self.loss), self._stream())
+                self._pending_loss = None
         self._lists_seq = (seq, lab)         # keep the inputs alive until the side stream has consumed them
 
     def _lists_wait(self):
