@@ -518,16 +518,25 @@ class Evaluator:
         rank, world = self.shard
         fast = getattr(self.model, "rank_targets", None)
         mine = []                    # [(batch index, ranks)] of the batches this rank evaluates
+        todo = []                    # fast path: (batch index, seq, pos) of this rank's batches, ranked by ONE call below
         for b in range(self.evaluate_sampler.batch_num()):
             seq, pos = self.evaluate_sampler.next_batch()       # every rank walks the same batch sequence
             if len(pos) == 0 or b % world != rank:
                 continue
             if fast is not None:
-                r = [int(x) for x in fast(seq, pos, self.max_item)]
+                todo.append((b, seq, pos))
             else:
                 pred = self.model.predict(self.sess, seq, list(range(1, self.max_item + 1)))
-                r = [int(p[i - 1]) for p, i in zip(pred, pos)]
-            mine.append((b, r))
+                mine.append((b, [int(p[i - 1]) for p, i in zip(pred, pos)]))
+        if todo:
+            # the rank of a row's target depends on that row alone: all batches of the evaluation go through ONE rank_targets call
+            # (chunked on the device, one copy of the ranks back) instead of a host round trip per batch
+            r = np.asarray(self.model.rank_targets(np.concatenate([s_ for _, s_, _ in todo]), np.concatenate([p_ for _, _, p_ in todo]),
+                                                   self.max_item)).tolist()
+            o = 0
+            for b, _, pos in todo:
+                mine.append((b, r[o:o + len(pos)]))
+                o += len(pos)
         if world > 1:                # ranks back in batch order on every rank: the metric sums run in the reference's order
             from . import dist as _dist
             mine = sorted(x for part in _dist.gather_lists(mine, world) for x in part)

@@ -326,6 +326,8 @@ class _State:
                 return x
             return x.to(device=self.device, dtype=torch.int32).contiguous()
         a = np.ascontiguousarray(x, dtype=np.int32)
+        if a.nbytes > (1 << 20):          # a whole evaluation set, not a step's batch: one plain copy (no ring of pinned buffers per shape)
+            return torch.from_numpy(a).to(self.device)
         ring = self._pin.setdefault(a.shape, {"bufs": [], "evs": [], "i": 0})
         if len(ring["bufs"]) < 8:
             ring["bufs"].append(torch.empty(a.shape, dtype=torch.int32).pin_memory())
