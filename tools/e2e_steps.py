@@ -25,6 +25,26 @@ def tsf(self, *a, **k):
 
 
 MD.Ader.train_step_fed = tsf
+PLANS = {}
+_ei0 = MD.Engine.__init__
+
+
+def eng_init(self, *a, **k):
+    _ei0(self, *a, **k)
+    PLANS.clear()
+    PLANS["engine"] = self
+
+
+MD.Engine.__init__ = eng_init
+
+
+class _P(dict):
+    def __str__(self):
+        e = self.get("engine")
+        return "-" if e is None else "%d replayed, %d recorded, %d errors" % (e.plan_hits, e.plan_misses, len(e.plan_errors))
+
+
+PLANS = _P()
 _ev = D.Evaluator.evaluate
 
 
@@ -61,5 +81,5 @@ for spec in sys.argv[1:]:
         out = M.run(args, log=lambda s="": None)
         torch.cuda.synchronize()
         a = out["average"]
-        print("%-22s Recall@20 %.2f MRR@20 %.2f | %.1f s, %d train steps, %d evaluations" % (
-            name, 100 * a["recall20"], 100 * a["mrr20"], time.perf_counter() - t0, cnt["steps"], cnt["evals"]), flush=True)
+        print("%-22s Recall@20 %.2f MRR@20 %.2f | %.1f s, %d train steps, %d evaluations | plans: %s" % (
+            name, 100 * a["recall20"], 100 * a["mrr20"], time.perf_counter() - t0, cnt["steps"], cnt["evals"], PLANS), flush=True)
