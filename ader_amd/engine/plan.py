@@ -194,6 +194,22 @@ class StepPlan:
             pass
 
 
+class _Slice:
+    """The tail of a device index array from address `p` on, with the three methods the recorder asks of an input tensor."""
+
+    def __init__(self, t, p):
+        self.t, self.p = t, p
+
+    def data_ptr(self):
+        return self.p
+
+    def numel(self):
+        return max(0, self.t.numel() - (self.p - self.t.data_ptr()) // self.t.element_size())
+
+    def element_size(self):
+        return self.t.element_size()
+
+
 class _Native:
     # ---------------------------------------------------------------------------------------- native step driver
     def _plan_state(self):
@@ -410,18 +426,5 @@ class _Native:
             self.plan_hits += 1
             return self.loss
         # record / verify through the generic path: the index arrays as address ranges, the slices' addresses as their inputs
-        class _At:                                        # (a view of an epoch array that starts at the batch's slice)
-            def __init__(self, t, p):
-                self.t, self.p = t, p
-
-            def data_ptr(self):
-                return self.p
-
-            def numel(self):
-                return max(0, self.t.numel() - (self.p - self.t.data_ptr()) // 8)
-
-            def element_size(self):
-                return 8
-
-        tensors = tuple((slot, None if t is None else _At(t, p)) for (slot, t), p in zip(tens, (pt, pe)))
+        tensors = tuple((slot, None if t is None else _Slice(t, p)) for (slot, t), p in zip(tens, (pt, pe)))
         return self._plan_run(key, tensors, (), lr, python_step)

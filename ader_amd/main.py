@@ -111,6 +111,7 @@ def run(args, log=print):
     args.dropout_rate = 0 if (args.ewc or args.finetune) else args.dropout_rate      # main.py:141
     dev_index = (local % max(torch.cuda.device_count(), 1)) if world > 1 else args.device_num
     model = (Ewc if args.ewc else Ader)(item_num, args, device="cuda:%d" % dev_index, dp_rank=rank, dp_world=world)   # main.py:144
+    model.engine.warm_up()          # the side-stream probe (a scratch tensor, eight streams, ~16 synchronisations): here, not inside the first step
     dp = adist.DataParallel(model.engine, rank, world)
     if world > 1:
         # data-parallel scheme: "replicated" = every rank holds the table, dense gradient all-reduce (overlapped

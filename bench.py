@@ -443,7 +443,7 @@ def main():
 
     def make_engine(logits, dp_mode=None):
         eng_ = Engine(N, maxlen=T, hidden_units=H, num_blocks=L, num_heads=heads, seed=0, device=dev, logits_dtype=logits,
-                      dp_rank=rank, dp_world=world)
+                      dp_rank=rank, dp_world=world).warm_up()
         dp_ = adist.DataParallel(eng_, rank, world)
         if world > 1 and (logits == "x3" or (logits == "bf16" and not E)):     # (distilled rows on the sharded table: float32 grade)
             eng_.dp_mode = dp_mode or args.dp_mode
