@@ -264,3 +264,40 @@ def test_collective_guard_names_the_rank_and_the_call_site_on_a_mismatch():
         assert "site_c" in res[r]["shape"] and "rank %d" % r in res[r]["shape"] and "[4, 5]" in res[r]["shape"].replace("(", "[").replace(")", "]")
         assert "diverged" in res[r]["site"] and "site_d" in res[r]["site"] and "site_e" in res[r]["site"]
         assert "site_f" in res[r]["splits"] and "expects" in res[r]["splits"]
+
+
+def test_dense_path_picks_plain_or_overlapped_allreduce_by_bytes():
+    """DataParallel.early_pays (no GPU, no process group): the overlapped table all-reduce forces the sparse rows to travel as
+    per-position rows -- (W - 1) x positions x (H + 1) x 4 bytes per rank -- so it is taken only where the table outweighs them:
+    at the headline catalog, not at the shipped datasets' (DESIGN.md section 5's byte model)."""
+    from ader_amd import dist as adist
+
+    class _Eng:
+        T, H = 50, 150
+
+        def __init__(self, rows):
+            self._act = {"B": rows}
+
+    dp = adist.DataParallel.__new__(adist.DataParallel)
+    dp.world, dp.early = 8, "auto"
+    assert dp.early_pays(_Eng(512), 1_000_000)                  # cfg-S: 1.2 GB of all-reduce traffic against 0.1 GB of rows
+    assert not dp.early_pays(_Eng(614), 25_750)                 # YOOCHOOSE (configs[3]): 31 MB against 8 x 18 MB
+    assert not dp.early_pays(_Eng(399), 43_105)                 # DIGINETICA
+    dp.world = 2
+    assert dp.early_pays(_Eng(614), 25_750)                     # two ranks: one peer's rows (18 MB) against 31 MB
+    dp.early = "never"
+    assert not dp.early_pays(_Eng(512), 1_000_000)
+    dp.early = "always"
+    assert dp.early_pays(_Eng(614), 25_750)
+
+
+def test_shape_roofline_accounting():
+    """bench.shape_roofline: the floor is the sum of its parts, executed work exceeds credited work by the row padding and the three
+    passes, and the YOOCHOOSE shape lands where the round-5 review priced it (~75 us)."""
+    import bench
+    r = bench.shape_roofline(25750, 512, 102, int(0.9 * 25750), 3078, 0.384)
+    assert abs(sum(r["floor_parts_ms"].values()) - r["floor_ms"]) < 1e-4 and 0.065 < r["floor_ms"] < 0.080
+    assert abs(r["frac"] - r["floor_ms"] / 0.384) < 1e-3
+    assert r["logit_flops_executed"] > 3 * r["logit_flops_credited"] and r["session_flops_executed"] == 3 * r["session_flops_credited"]
+    big = bench.shape_roofline(1_000_000, 512, 128, 900_000, 640 * 50, 3.0)
+    assert big["floor_ms"] > 2.0 and big["floor_parts_ms"]["logit_mfma"] > big["floor_parts_ms"]["hbm"] > big["floor_parts_ms"]["session_mfma"]
