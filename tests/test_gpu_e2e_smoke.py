@@ -85,6 +85,34 @@ def test_two_data_parallel_ranks_of_the_driver_match_one_process():
     assert abs(sa[0] - sb[0]) <= 0.02 * sa[0], (sa, sb)           # herding on slightly different representations
 
 
+@pytest.mark.parametrize("dp_mode", ["replicated", "catalog"])
+def test_two_ranks_of_the_driver_at_float32_grade_in_both_schemes(dp_mode):
+    """The same at float32 grade (the default arithmetic) with `--dp_mode` spelled out: "replicated" = the plain dense all-reduce the
+    shipped catalogs get from `auto` (dist.DataParallel.early_pays), "catalog" = every rank owns half of the table rows, distilled
+    steps included.  Two periods, three epochs; test metrics within a point of the single process (the trajectories differ by the
+    summation order of the exchanged gradients and what early stopping makes of it)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--dataset", "DIGINETICA", "--max_periods", "2", "--num_epochs", "3"]
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+        for name, cmd in (("one", [sys.executable, "-m", "ader_amd.main"] + common + ["--results_root", os.path.join(d, "a")]),
+                          ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29541", "-m", "ader_amd.main"] + common +
+                           ["--dist_backend", "gloo", "--dp_mode", dp_mode, "--results_root", os.path.join(d, "b")])):
+            p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+            text = p.stdout.decode()
+            assert p.returncode == 0, text[-3000:]
+            tests_ = re.findall(r"test \(MRR@20: ([0-9.]+), RECALL@20: ([0-9.]+)", text)
+            assert len(tests_) == 2, text[-3000:]
+            res[name] = [tuple(map(float, t)) for t in tests_]
+    for (m1, r1), (m2, r2) in zip(res["one"], res["two"]):
+        assert abs(r1 - r2) < 0.01 and abs(m1 - m2) < 0.01, res
+
+
 def test_period_1_training_curve_tracks_the_oracle_epoch_by_epoch(golden_dir):
     """End-to-end pin of the HIP path against the CPU oracle on real data: DIGINETICA period 1, float32 grade, the reference's default
     flags, eight epochs.  tests/golden/oracle_period1.json holds the validation Recall@20 / MRR@20 the ORACLE reached epoch by epoch
