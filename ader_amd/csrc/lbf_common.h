@@ -2,7 +2,22 @@
 #pragma once
 #include "common.h"
 
+// -DADER_X3_F16 (experiment of round 6, tools/ab_f16x3.sh; NOT the product build): the operand pieces of the float32-grade logit
+// FORWARD (k_lx3_prep, k_lx3p) as fp16 hi / lo on operands pre-scaled by exact powers of two -- 11 + 11 mantissa bits instead of 8 + 8 at
+// the same three MFMAs (tools/probe_f16x3.hip).  The scales keep the lo pieces in fp16's normal range: representations x 2^3, table
+// x 2^8, probabilities x 2^8 (added to the exponent); the accumulators are scaled back where the kernel stores them.  Only the forward
+// entry points are valid in such a build (the update kernels still read the planes as bf16).
+#ifdef ADER_X3_F16
+typedef _Float16 bf16;
+#define X3_SR 8.0f
+#define X3_SE 256.0f
+#define X3_SPL 8.0f
+#else
 typedef __bf16 bf16;
+#define X3_SR 1.0f
+#define X3_SE 1.0f
+#define X3_SPL 0.0f
+#endif
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -13,20 +28,35 @@ typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define RESCALE_THR 6.0f        // lazy online-softmax rescale threshold (log2 units): p <= 2^6
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef ADER_X3_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 // accumulator row of register `reg` for lane half hh (C/D layout of the 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
 // 4(k) x 16(n) transposed LDS read: lane (q = (lane&15)>>2, p = lane&3) supplies the address of row k0+q, cols n0+4p..;
 // lane i of the 16-lane group receives column n0+i of rows k0..k0+3.
+#ifdef ADER_X3_F16
+typedef short i16x4_tr __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4_tr __attribute__((address_space(3)))*)p));
+}
+#else
 __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
 }
+#endif
 
 typedef __attribute__((address_space(3))) bf16 lds_bf16;
 __device__ __forceinline__ bf16x4 tr_read3(const lds_bf16* p) {
+#ifdef ADER_X3_F16
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4_tr __attribute__((address_space(3)))*)p));
+#else
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+#endif
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void k_lx3_prep(const float* __restrict__ rep,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp * LDR) return;
     const int b = i / LDR, c = i - b * LDR;
-    const float x = (b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f;
+    const float x = ((b < B && c < H) ? rep[(size_t)b * H + c] : 0.0f) * X3_SR;      // (X3_SR = 1 in the product build)
     const bf16 h = (bf16)x, l = (bf16)(x - (float)h);
     rep_hi[i] = h;
     rep_lo[i] = l;

@@ -289,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void k_lx3g(Lx3Args a) {
 // MFMAs; the rescale test (a branch) stays in front.  Same arithmetic in the same order as k_lx3g: bit-equal results.
 template <int HT>
 __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
+    // (product build: LOG2E_S = LOG2E and the two factors are 1: the compiler folds them; -DADER_X3_F16: see lbf_common.h)
+    constexpr float LOG2E_S = LOG2E / (X3_SR * X3_SE);
+    constexpr float X3_INV_P = 1.0f / (X3_SPL == 0.0f ? 1.0f : 256.0f), X3_INV_PE = X3_INV_P / X3_SE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [2 buffers][block image]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
         _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                   \
             const int p_ = qb + 8 * r;                          /* piece 37 = channels 148, 149 and two floats of the next row */ \
             float x_[4];                                        /* pieces 38, 39 = channels 152..159: zeros (no branch) */ \
-            x_[0] = (r == 4 && p_ >= 38) ? 0.f : sc[r][0]; x_[1] = (r == 4 && p_ >= 38) ? 0.f : sc[r][1]; \
-            x_[2] = (r == 4 && p_ >= 37) ? 0.f : sc[r][2]; x_[3] = (r == 4 && p_ >= 37) ? 0.f : sc[r][3]; \
+            x_[0] = (r == 4 && p_ >= 38) ? 0.f : sc[r][0] * X3_SE; x_[1] = (r == 4 && p_ >= 38) ? 0.f : sc[r][1] * X3_SE; \
+            x_[2] = (r == 4 && p_ >= 37) ? 0.f : sc[r][2] * X3_SE; x_[3] = (r == 4 && p_ >= 37) ? 0.f : sc[r][3] * X3_SE; \
             bf16x4 h_, l_;                                                                                \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) { h_[j] = (bf16)x_[j]; l_[j] = (bf16)(x_[j] - (float)h_[j]); } \
             *(bf16x4*)(dst_ + dstb + 4 * X3B_KC * r) = h_;                                                \
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
     // softmax of ONE pair of logits of the current block (elements 2 q_, 2 q_ + 1 of S): p = exp2(s log2e - m), running sum in
     // element order (the order of k_lx3g: bit-equal results), hi / lo split into packed pairs
 #define P3_PAIR(q_)                                                                                       \
-    { const float p0_ = __builtin_amdgcn_exp2f(fmaf(S[2 * (q_)], LOG2E, nm));                             \
-      const float p1_ = __builtin_amdgcn_exp2f(fmaf(S[2 * (q_) + 1], LOG2E, nm));                         \
+    { const float p0_ = __builtin_amdgcn_exp2f(fmaf(S[2 * (q_)], LOG2E_S, nm));                             \
+      const float p1_ = __builtin_amdgcn_exp2f(fmaf(S[2 * (q_) + 1], LOG2E_S, nm));                         \
       ls += p0_; ls += p1_;                                                                               \
       bf16x2 h_; h_[0] = (bf16)p0_; h_[1] = (bf16)p1_;                                                    \
       bf16x2 l_; l_[0] = (bf16)(p0_ - (float)h_[0]); l_[1] = (bf16)(p1_ - (float)h_[1]);                  \
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
         }                                                                                                 \
         float tmax = S[0];                                                                                \
         _Pragma("unroll") for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, S[j]);                          \
-        float t2 = tmax * LOG2E;                                                                          \
+        float t2 = tmax * LOG2E_S;                                                                          \
         if (__any(t2 > m_run + RESCALE_THR)) {                                                            \
             t2 = fmaxf(t2, __shfl_xor(t2, 32, 64));                                                       \
             const float m_new = (t2 > m_run + RESCALE_THR) ? t2 : m_run;                                  \
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
                 _Pragma("unroll") for (int nb = 0; nb < 5; ++nb) O[nb][j] *= ar;                          \
             }                                                                                             \
         }                                                                                                 \
-        const float nm = -m_run;                                                                          \
+        const float nm = (X3_SPL == 0.0f) ? -m_run : X3_SPL - m_run;     /* (product build: -m_run) */            \
         float ls = 0.0f;                                                                                  \
         uint32_t ph2[8], pl2[8];                           /* P hi / lo as packed bf16 pairs */
     // ... and behind it: the block in flight goes to LDS, then the readout O += P^T . E of the current block
@@ -534,8 +537,8 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
             Sn = mfma_bf16(A_[1], rh[ks], Sn);
             __builtin_amdgcn_sched_barrier(0);
             if (ks < 8) {                                   // exp of pair ks
-                S[2 * ks] = __builtin_amdgcn_exp2f(fmaf(S[2 * ks], LOG2E, nm));
-                S[2 * ks + 1] = __builtin_amdgcn_exp2f(fmaf(S[2 * ks + 1], LOG2E, nm));
+                S[2 * ks] = __builtin_amdgcn_exp2f(fmaf(S[2 * ks], LOG2E_S, nm));
+                S[2 * ks + 1] = __builtin_amdgcn_exp2f(fmaf(S[2 * ks + 1], LOG2E_S, nm));
             }
             __builtin_amdgcn_sched_barrier(0);
             Sn = mfma_bf16(A_[0], rl[ks], Sn);
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
                 O[r] = mfma_bf16(pl0, v0, O[r]);
                 __builtin_amdgcn_sched_barrier(0);
                 {   const int p_ = qb + 8 * r;                  // pieces 38, 39 = channels 152..159: zeros (no branch)
-                    x_[0] = (r == 4 && p_ >= 38) ? 0.f : sc[r][0]; x_[1] = (r == 4 && p_ >= 38) ? 0.f : sc[r][1];
-                    x_[2] = (r == 4 && p_ >= 37) ? 0.f : sc[r][2]; x_[3] = (r == 4 && p_ >= 37) ? 0.f : sc[r][3];
+                    x_[0] = (r == 4 && p_ >= 38) ? 0.f : sc[r][0] * X3_SE; x_[1] = (r == 4 && p_ >= 38) ? 0.f : sc[r][1] * X3_SE;
+                    x_[2] = (r == 4 && p_ >= 37) ? 0.f : sc[r][2] * X3_SE; x_[3] = (r == 4 && p_ >= 37) ? 0.f : sc[r][3] * X3_SE;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 O[r] = mfma_bf16(pl1, v1, O[r]);
@@ -668,13 +671,13 @@ __global__ __launch_bounds__(256, 2) void k_lx3p(Lx3Args a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (hh == 0) {
         a.pm[(size_t)range * a.Bp + b0 + r32] = m_run;
-        a.pl[(size_t)range * a.Bp + b0 + r32] = l_tot;
+        a.pl[(size_t)range * a.Bp + b0 + r32] = l_tot * X3_INV_P;
     }
     float* o = a.pO + ((size_t)range * a.Bp + b0) * HP;
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r32] = O[nb][j];
+        for (int j = 0; j < 16; ++j) o[(size_t)acc_row(j, hh) * HP + 32 * nb + r32] = O[nb][j] * X3_INV_PE;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -17,7 +17,11 @@ __host__ __device__ __forceinline__ constexpr int x3_kc_off(int kc) { return X3_
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
+#ifdef ADER_X3_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 // channel of lane c16 in the 16-channel block cb of a transposed read / of the product it feeds (k-chunks 4Q + o and 4Q + o + 2
 // with Q = cb >> 1, o = cb & 1)

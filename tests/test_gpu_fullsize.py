@@ -114,13 +114,22 @@ def _fp64_step_reference(E, rep, lab, w, chunk=50_000):
     return lse, loss, drep
 
 
+# Bounds of the float32-grade (bf16x3) kernels at full size against fp64, normalised by the tensor's max.  Round 6: set from what the
+# kernels MEASURE (printed by the test: lse 1.5e-7, loss 8e-8, dRep 6e-8, Adam m 3.6e-6, Adam v 2.1e-5, theta 1.6e-9 absolute) with
+# a 5-15x margin -- rounds 2-5 held them to the exact-f32 kernels' written bounds (2e-5 / 2e-5 / 3e-4 / 3e-4 / 6e-4 / 2e-6), 20-300x
+# looser than what the three-pass products deliver: at the level of a step's outputs "float32 grade" means float32 rounding
+# (an fp32 log-sum-exp of ~13.8 has an ulp of 9.5e-7 = 7e-8 relative; profiles/ab_f16x3_forward_r6.txt: fp16 operand pieces do not
+# move lse or loss at all and tighten dRep by 1.3-7x)
+LSE_BOUND, LOSS_BOUND, DREP_BOUND, M_BOUND, V_BOUND, THETA_BOUND = 1e-6, 5e-7, 1e-6, 3e-5, 1e-4, 2e-8
+
+
 @pytest.mark.parametrize("n_items", [N, N - 75])
 def test_x3_headline_kernels_against_float64_at_full_size(batch, n_items):
     """The credited kernels AT the credited size (B = 512, N = 10^6: k_lx3p's 31,250 table blocks, k_tab32x3's 7,813 tile
     pairs, the last one half a pair; N - 75: a ragged tail tile): one fused train step of the float32-grade path against a
     float64 restatement computed from the same parameters and the device's own representation / input-gradient rows --
-    per-row log-sum-exp, loss and dRep of ALL 512 rows at the bounds of the exact-f32 kernels (loss 2e-5, gradients 3e-4
-    normalised), and theta / Adam m / Adam v of three 64-row table tiles (the first, a middle one, the tail tile) after the
+    per-row log-sum-exp, loss and dRep of ALL 512 rows at bounds set from the measured errors (lse 1e-6, loss 5e-7, dRep 1e-6
+    normalised: float32 rounding), and theta / Adam m / Adam v of three 64-row table tiles (the first, a middle one, the tail tile) after the
     fused update against a dense float64 TF-Adam of those rows (ADER.py:91-96)."""
     seq, pos = batch
     pos = np.minimum(pos, n_items).astype(np.int32)
@@ -140,10 +149,13 @@ def test_x3_headline_kernels_against_float64_at_full_size(batch, n_items):
     w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
     lse64, loss64, drep64 = _fp64_step_reference(E0[:n_items + 1], rep, lab, w)
     lse_dev = eng._ws["lg_lse"][:B].double()
-    assert float((lse_dev - lse64).abs().max()) < 2e-5 * float(lse64.abs().max())
-    assert abs(float(loss.item()) - float(loss64)) < 2e-5 * abs(float(loss64))
     drep_dev = eng._ws["drep"][:B].double()
-    assert float((drep_dev - drep64).abs().max()) < 3e-4 * float(drep64.abs().max())
+    measured = {"lse": float((lse_dev - lse64).abs().max()) / float(lse64.abs().max()),
+                "loss": abs(float(loss.item()) - float(loss64)) / abs(float(loss64)),
+                "drep": float((drep_dev - drep64).abs().max()) / float(drep64.abs().max())}
+    assert measured["lse"] < LSE_BOUND, measured
+    assert measured["loss"] < LOSS_BOUND, measured
+    assert measured["drep"] < DREP_BOUND, measured
     # table rows: dE[n] = sum_b w_b (p[b,n] - [label_b = n]) rep_b  +  sqrt(H) * sum_{(b,t): seq[b,t] = n} g[b,t]
     g_rows = eng._last_g.double()                                          # [B*T, H] masked / dropout-scaled input-gradient rows
     ids = torch.as_tensor(seq.reshape(-1).astype(np.int64), device=dev)
@@ -167,9 +179,12 @@ def test_x3_headline_kernels_against_float64_at_full_size(batch, n_items):
         m_dev = eng.view(eng.adam_m, "emb")[r0:r1].double()
         v_dev = eng.view(eng.adam_v, "emb")[r0:r1].double()
         th_dev = eng.param("emb")[r0:r1].double()
-        assert float((m_dev - m64).abs().max()) < 3e-4 * float(m64.abs().max()), r0
-        assert float((v_dev - v64).abs().max()) < 6e-4 * float(v64.abs().max()), r0
-        assert float((th_dev - th64).abs().max()) < 2e-6, r0               # the Adam bound of DESIGN.md 2
+        measured["m@%d" % r0] = float((m_dev - m64).abs().max()) / float(m64.abs().max())
+        measured["v@%d" % r0] = float((v_dev - v64).abs().max()) / float(v64.abs().max())
+        measured["theta@%d" % r0] = float((th_dev - th64).abs().max())
+        assert measured["m@%d" % r0] < M_BOUND and measured["v@%d" % r0] < V_BOUND, (r0, measured)
+        assert measured["theta@%d" % r0] < THETA_BOUND, (r0, measured)
+    print("full size, N = %d, measured against fp64: %s" % (n_items, {k: float("%.3g" % v) for k, v in measured.items()}))
     # rows past max_item are never touched
     if n_items < N:
         assert torch.equal(eng.param("emb")[n_items + 1:], E0[n_items + 1:])
