@@ -266,7 +266,7 @@ def test_bf16_logits_path_matches_bf16_aware_oracle(cfg, mode):
 def test_x3_logits_path_matches_exact_oracle(cfg, mode, gemm):
     """logits_dtype="x3": the flash logit kernels with every product as three bf16 MFMAs on hi/lo operand splits (fp32
     accumulate): float32-grade, so it is held to the SAME bounds as the exact-f32 kernels against the plain float64 oracle
-    (no bf16-aware oracle): loss 2e-5, every gradient 3e-4 normalised with exact-f32 block GEMMs (6e-4 with the bf16x3 block
+    (no bf16-aware oracle): loss 2e-6, every gradient 5e-5 normalised with exact-f32 block GEMMs (6e-4 with the bf16x3 block
     GEMMs, which are handed their own ReLU decisions as in test_loss_and_gradients_match_oracle).  Reference arithmetic:
     ADER.py:91-93 (fp32)."""
     item_num, T, H, L, heads, B, N = cfg
@@ -290,10 +290,16 @@ def test_x3_logits_path_matches_exact_oracle(cfg, mode, gemm):
     masks = relu_masks_of(eng) if gemm == "x3" else None
     ol, og = R.loss_and_grads(_params(eng, torch.float64), seq, pos, N, L, heads, training=True, rate=0.3, seed=3, step=2,
                               relu_masks=masks, **okw)
-    assert abs(float(loss.item()) - float(ol)) < 2e-5 * max(1.0, abs(float(ol)))
+    # (round 6: bounds from what is measured -- loss 1.5e-7; gradients 1.2e-5 with exact-f32 block GEMMs, worst on the key bias, whose
+    #  true gradient is zero and which is normalised by the 1e-4 floor; up to 4.1e-4 on that same tensor with the bf16x3 block GEMMs)
+    assert abs(float(loss.item()) - float(ol)) < 2e-6 * max(1.0, abs(float(ol)))
+    worst = ("", 0.0)
     for k in eng.layout:
         e = nerr(eng.gradient(k).cpu().numpy(), og[k].numpy(), floor=1e-4)
-        assert e < (6e-4 if gemm == "x3" else 3e-4), (k, e)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < (6e-4 if gemm == "x3" else 5e-5), (k, e)
+    print("x3 logits path, %s / %s block GEMMs: loss err %.2e, worst gradient %s %.2e" % (
+        mode, gemm, abs(float(loss.item()) - float(ol)) / max(1.0, abs(float(ol))), worst[0], worst[1]))
     assert np.all(eng.gradient("emb")[0].cpu().numpy() == 0)
     assert np.all(eng.gradient("emb")[N + 1:].cpu().numpy() == 0)
 
